@@ -1,0 +1,169 @@
+/*
+ * tokenhmr_hip.h — C ABI of the MI355X-native TokenHMR inference engine (libtokenhmr_hip.so).
+ *
+ * The reference (saidwivedi/TokenHMR) has no FFI: its seam is the Python method
+ *     model, cfg = load_tokenhmr(ckpt, model_cfg)          tokenhmr/lib/models/__init__.py:3-26
+ *     out = model(batch)                                    tokenhmr/lib/models/tokenhmr.py:330-338
+ * called from tokenhmr/eval.py:147, tokenhmr/demo.py:78, tokenhmr/track.py:39.
+ * This header is what a ctypes binding for that seam binds; the Python
+ * facade tokenhmr_amd/model.py is exactly such a binding.
+ *
+ * Conventions
+ *   - plain C types only; every pointer named *_dev is a device (HBM) pointer owned by the caller
+ *     (e.g. torch.Tensor.data_ptr()); the engine owns its weight arena and scratch arena.
+ *   - all tensors are fp32, contiguous, row-major in the reference's own layouts.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous
+ *     on it.  thmr_forward performs no allocation and no host synchronisation.
+ *   - return value: 0 on success, negative thmr_status on failure; thmr_last_error() gives text.
+ *   - one engine per GPU / per caller thread; not re-entrant.
+ */
+#ifndef TOKENHMR_HIP_H
+#define TOKENHMR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define THMR_ABI_VERSION 1
+
+typedef enum {
+    THMR_OK = 0,
+    THMR_ERR_INVALID = -1,      /* bad argument / shape / missing tensor */
+    THMR_ERR_HIP = -2,          /* a HIP runtime call failed */
+    THMR_ERR_STATE = -3,        /* call order violated (e.g. forward before weights are finalised) */
+    THMR_ERR_NOMEM = -4
+} thmr_status;
+
+typedef struct thmr_engine thmr_engine;
+
+/* Architecture knobs.  Everything else (192 tokens, 1280 dim, 16x80 heads, 160x2048 tokens ...)
+ * is fixed by the reference (vit.py:12-24, tokenhmr_release.yaml:65-81) and baked into kernels. */
+typedef struct {
+    int32_t abi_version;        /* must be THMR_ABI_VERSION */
+    int32_t vit_depth;          /* 32 for ViT-H (vit.py:17); smaller only for tests */
+    int32_t dec_depth;          /* 6 (tokenhmr_release.yaml:74) */
+    int32_t max_batch;          /* crops per thmr_forward call the scratch arena is sized for */
+    int32_t device;             /* HIP device ordinal */
+    int32_t reserved[3];
+} thmr_config;
+
+/* One named tensor of the reference checkpoint contract:
+ *   'backbone.*' / 'smpl_head.*'   tokenhmr/lib/utils/misc.py:242-256 (load_pretrained)
+ *   'decoder.decoder.*', 'quantizer.codebook'   tokenization/models/vanilla_pose_vqvae.py:299-301 */
+typedef struct {
+    const char* name;
+    const void* data;           /* fp32, contiguous, reference layout */
+    int64_t     numel;
+    int32_t     on_device;      /* 0: host pointer, 1: device pointer */
+    int32_t     reserved;
+} thmr_tensor_desc;
+
+/* SMPL constants (replaces smplx.SMPLLayer buffers + joint_regressor_extra,
+ * tokenhmr/lib/models/smpl_wrapper.py:11-25).  Host or device pointers (all same side). */
+typedef struct {
+    const float*   v_template;      /* (6890,3) */
+    const float*   shapedirs;       /* (6890,3,10) */
+    const float*   posedirs;        /* (207,20670)  smplx layout */
+    const float*   J_regressor;     /* (24,6890) */
+    const float*   lbs_weights;     /* (6890,24) */
+    const float*   J19_regressor;   /* (19,6890)  SMPL_to_J19.pkl */
+    const int32_t* parents;         /* (24) kinematic tree, parents[0] = -1 */
+    const int32_t* extra_verts;     /* (21) smplx vertex_ids['smplh'] */
+    const int32_t* joint_map;       /* (25) smpl_wrapper.py:19-20 */
+    int32_t        on_device;
+    int32_t        reserved;
+} thmr_smpl_desc;
+
+/* Output buffers of one forward (tokenhmr.py:156-188).  Any pointer may be NULL (= not wanted). */
+typedef struct {
+    float*   pred_cam;              /* (B,3) */
+    float*   rotmat;                /* (B,24,3,3): [:,0] = global_orient, [:,1:] = body_pose */
+    float*   betas;                 /* (B,10) */
+    float*   cls_logits_softmax;    /* (B,160,2048) */
+    float*   pred_cam_t;            /* (B,3) */
+    float*   focal_length;          /* (B,2) */
+    float*   pred_keypoints_3d;     /* (B,44,3) */
+    float*   pred_vertices;         /* (B,6890,3) */
+    float*   pred_keypoints_2d;     /* (B,44,2) */
+    int32_t* token_idx;             /* (B,160) argmax_k logits, lowest index on ties */
+    /* optional taps for parity tests */
+    float*   vit_features;          /* (B,192,1280) token-major last_norm output */
+    float*   token_out;             /* (B,1024) */
+    float*   cls_logits;            /* (B,160,2048) raw logits */
+    float*   pose6d;                /* (B,144) */
+} thmr_outputs;
+
+/* kernel-class ids for the built-in HIP-event profiler (bench.py roofline leg) */
+enum {
+    THMR_PROF_GEMM_QKV = 0, THMR_PROF_GEMM_PROJ = 1, THMR_PROF_GEMM_FC1 = 2, THMR_PROF_GEMM_FC2 = 3,
+    THMR_PROF_ATTN = 4, THMR_PROF_LN = 5, THMR_PROF_PATCH = 6, THMR_PROF_DEC_KV = 7,
+    THMR_PROF_HEAD = 8, THMR_PROF_LBS = 9, THMR_PROF_NUM = 10
+};
+typedef struct {
+    double  ms;         /* sum of HIP-event durations on the launch stream */
+    double  flops;      /* algorithmic flops (2*MAC) of those launches */
+    double  bytes;      /* algorithmic HBM bytes of those launches */
+    int64_t launches;
+} thmr_prof_entry;
+
+int         thmr_abi_version(void);
+const char* thmr_build_info(void);
+
+/* Bytes the engine needs; lets the caller allocate the arenas itself (e.g. as torch tensors so
+ * that torch.distributed/RCCL can broadcast the weight arena). */
+int thmr_arena_bytes(const thmr_config* cfg, size_t* weight_bytes, size_t* scratch_bytes);
+
+/* weight_arena_dev / scratch_arena_dev may be NULL: the engine then hipMallocs and owns them. */
+int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_arena_dev, thmr_engine** out);
+void thmr_destroy(thmr_engine* e);
+const char* thmr_last_error(const thmr_engine* e);   /* e may be NULL: last global error */
+
+/* Weight ingest — replaces load_pretrained/prepare_statedict (misc.py:215-256) and
+ * DecodeTokens.load_weights (vanilla_pose_vqvae.py:299-301).  May be called several times with
+ * disjoint subsets; unknown names are an error (strict=True semantics). */
+int thmr_load_weights(thmr_engine* e, const thmr_tensor_desc* tensors, size_t n, void* stream);
+int thmr_load_smpl(thmr_engine* e, const thmr_smpl_desc* smpl, void* stream);
+/* Checks every required tensor arrived and builds derived layouts (conv/codebook repacks,
+ * J_template/J_shapedirs).  Also the hook to call after an external broadcast into the arena. */
+int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* stream);
+int thmr_weight_arena(thmr_engine* e, void** ptr_dev, size_t* bytes);
+
+/* The hot path: TokenHMR.forward (tokenhmr.py:330-338 -> forward_step :135-188).
+ * img_dev: (B,3,256,256) fp32 normalised RGB crops.  1 <= B <= max_batch. */
+int thmr_forward(thmr_engine* e, const float* img_dev, int32_t B, const thmr_outputs* out, void* stream);
+
+/* Sub-paths (configs 2 of BASELINE.json and unit parity). */
+int thmr_vit_forward(thmr_engine* e, const float* img_dev, int32_t B, float* feats_dev /*(B,192,1280)*/, void* stream);
+int thmr_head_forward(thmr_engine* e, const float* ctx_dev /*(B,192,1280)*/, int32_t B, const thmr_outputs* out, void* stream);
+/* SMPL forward (smpl_wrapper.py:27-41 over smplx lbs) + projection (geometry.py:86-124) */
+int thmr_lbs_forward(thmr_engine* e, const float* rotmat_dev /*(B,24,3,3)*/, const float* betas_dev /*(B,10)*/,
+                     const float* cam_dev /*(B,3) or NULL*/, int32_t B, float* verts_dev, float* joints_dev,
+                     float* cam_t_dev, float* kp2d_dev, void* stream);
+/* QuantizeEMAReset.quantize (tokenization/models/quantize_cnn.py:80-86): argmin_k ||x-c_k||^2 in the
+ * reference's expanded form; x (rows,256) -> idx (rows) int32; optional dist (rows,2048). */
+int thmr_vq_argmin(thmr_engine* e, const float* x_dev, int32_t rows, int32_t* idx_dev, float* dist_dev, void* stream);
+
+/* Stateless operator entry points (unit parity of individual kernels; no engine needed). */
+/* C[M,N] = epilogue(A[M,K] . W[N,K]^T); epi: 0 none, 1 +bias, 2 +bias gelu(erf), 3 +bias relu,
+ * 4 resid + (acc+bias), 5 (+bias)*qscale on cols < qcols.  K % 32 == 0. lda/ldc in elements. */
+int thmr_op_gemm(const float* A_dev, int64_t lda, const float* W_dev, const float* bias_dev, const float* resid_dev,
+                 float* C_dev, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi, float qscale, int32_t qcols,
+                 int32_t variant, void* stream);
+int thmr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,
+                      int32_t rows, int32_t D, float eps, int32_t relu, void* stream);
+/* ViT global attention over 192 tokens, 16 heads x 80 (vit.py:113-122); qkv (B,192,3840) with q pre-scaled. */
+int thmr_op_vit_attention(const float* qkv_dev, float* out_dev /*(B,192,1280)*/, int32_t B, void* stream);
+/* rot6d_to_rotmat (geometry.py:64-84): (n,6) -> (n,3,3) */
+int thmr_op_rot6d(const float* x_dev, float* R_dev, int32_t n, void* stream);
+
+/* Built-in profiler: HIP events recorded on the launch stream around each kernel class. */
+int thmr_prof_enable(thmr_engine* e, int32_t on);
+int thmr_prof_collect(thmr_engine* e, thmr_prof_entry* entries /*[THMR_PROF_NUM]*/, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOKENHMR_HIP_H */
