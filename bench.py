@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""Benchmark of the TokenHMR inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1; for N>1 launch via torch.distributed.run)
+
+A step = one pass of the hot path over one batch of 64 synthetic 256x256 crops per GPU
+(BASELINE.json configs[2]: full TokenHMR = ViT-H + token decoder + VQ lookup/decode + SMPL LBS,
+batch 64 per GPU, fp32 end to end like the reference's inference).  `--workload vit` times
+configs[1] (ViT-H encoder only).  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+GFLOP_PER_CROP = {"full": 252.10, "vit": 248.01}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step")
+    ap.add_argument("--workload", choices=["full", "vit"], default="full")
+    ap.add_argument("--vit-depth", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crops", type=int, default=8)
+    ap.add_argument("--no-gather", action="store_true", help="skip the per-step packed all-gather at N>1")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, tok, smpl, workload, n_crops):
+    """The oracle (CPU restatement pinned bit-exact to the reference's modules) on this host's cores."""
+    from oracle import tokenhmr_oracle as O
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(4001)
+    img = torch.randn(n_crops, 3, 256, 256, generator=g)
+    fn = (lambda: O.forward(img, sd, tok, smpl, cfg)) if workload == "full" else (lambda: O.vit_forward(img, sd, cfg))
+    with torch.no_grad():
+        fn()                       # warm-up
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+    best = min(ts)
+    return {"value": n_crops / best, "unit": "crops/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch CPU fp32, {cores} threads), {workload} path, best of 2 passes over {n_crops} crops after 1 warm-up"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import __graft_entry__
+    from tokenhmr_amd import _cabi
+    if not os.path.exists(_cabi.LIB_PATH):
+        if rank == 0:
+            __graft_entry__.build()
+        if world > 1:
+            dist.barrier()
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd import weights as W, dist as D
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    from tokenhmr_amd.engine import Engine
+
+    cfg = HMRConfig(vit_depth=a.vit_depth)
+    B = a.batch
+    eng = Engine(cfg, max_batch=B, device=dev)
+    sd = tok = smpl = None
+    if rank == 0:
+        # rank 0 "reads the checkpoint" (synthetic: no network for real weights) ...
+        sd, tok, smpl = W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0), make_synthetic_smpl(cfg, 0)
+        eng.load_state(sd, tok)
+        eng.load_smpl(smpl)
+    if world > 1:
+        torch.cuda.synchronize()
+        D.broadcast_weights(eng, src=0)        # ... and ONE RCCL broadcast replicates the packed arena
+        torch.cuda.synchronize()
+    eng.finalize(assume_all_loaded=(rank != 0))
+
+    g = torch.Generator().manual_seed(4000 + rank)
+    img = torch.randn(B, 3, 256, 256, generator=g).to(dev)     # resident in HBM before timing
+    outs = eng._alloc_outputs(B, taps=False, want_probs=True)
+    feats = torch.empty(B, 192, 1280, device=dev)
+    gather = world > 1 and not a.no_gather and a.workload == "full"
+
+    def step():
+        if a.workload == "vit":
+            eng.vit_forward(img, out=feats)
+            return None
+        o = eng.forward(img, outputs=outs)
+        if gather:
+            return D.all_gather_records(D.pack_records(o), B * world)
+        return None
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    eng.prof_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    eng.prof_enable(False)
+    prof = eng.prof_collect()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_crops = B * world * a.steps
+        value = total_crops / elapsed
+        # dominant kernel = the GEMM class with the largest share of the timed region
+        gemms = {k: v for k, v in prof.items() if k.startswith("gemm_") and v["launches"] > 0}
+        dom = max(gemms, key=lambda k: gemms[k]["ms"]) if gemms else None
+        roof = None
+        if dom:
+            d = gemms[dom]
+            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            all_ms = sum(v["ms"] for v in gemms.values())
+            all_tf = sum(v["flops"] for v in gemms.values()) / (all_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": f"gemm_f32_kernel ({dom})", "achieved": round(tf, 2),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": None, "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],
+                    "flops_per_launch": d["flops"] / d["launches"],
+                    "all_gemm_achieved": round(all_tf, 2), "all_gemm_frac": round(all_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                    "path_tflops": round(value / world * GFLOP_PER_CROP[a.workload] / 1e3, 2),
+                    "classes_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in prof.items() if v["launches"]}}
+            lbs = prof.get("lbs")
+            if lbs and lbs["launches"]:
+                gbs = lbs["bytes"] / (lbs["ms"] * 1e-3) / 1e9
+                roof["lbs_hbm"] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_ms": round(lbs["ms"] / lbs["launches"], 4)}
+        cpu = None
+        if world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baseline(cfg, sd, tok, smpl, a.workload, a.cpu_crops)
+        line = {
+            "metric": "crops_per_sec", "value": round(value, 2), "unit": "crops/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("TokenHMR full path (ViT-H/16 + 6-layer token decoder + VQ lookup/decode + SMPL LBS), "
+                                    "256x256 crops, random-init weights" if a.workload == "full" else
+                                    "ViT-H/16 encoder only, 256x256 crops, random-init weights"),
+                       "batch_per_gpu": B, "global_batch": B * world, "vit_depth": cfg.vit_depth,
+                       "parallelism": f"dp{world}", "allgather_outputs": bool(gather)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if cpu:
+            line["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,10 @@ const char* thmr_build_info(void);
  * that torch.distributed/RCCL can broadcast the weight arena). */
 int thmr_arena_bytes(const thmr_config* cfg, size_t* weight_bytes, size_t* scratch_bytes);
 
+/* Enumerate the checkpoint contract the engine expects (name + element count), index = 0..count-1.
+ * Returns the number of tensors; name/numel may be NULL.  No GPU needed. */
+int thmr_spec(const thmr_config* cfg, int32_t index, const char** name, int64_t* numel);
+
 /* weight_arena_dev / scratch_arena_dev may be NULL: the engine then hipMallocs and owns them. */
 int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_arena_dev, thmr_engine** out);
 void thmr_destroy(thmr_engine* e);

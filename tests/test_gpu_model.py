@@ -1,0 +1,262 @@
+"""End-to-end parity (-m gpu): the HIP path through the C ABI vs (a) the CPU oracle on the same seeded
+inputs and (b) the committed golden tensors produced by the reference's own modules.
+
+Tolerances (fp32 kernels vs a CPU fp32 oracle, differences are summation order only):
+  ViT features 2e-3 abs (values O(1-10) after 32 residual blocks), token_out 1e-3, logits 1e-3,
+  token indices exactly equal wherever the oracle's top-2 logit gap > 1e-2 (and the mismatch
+  fraction is reported), rotmats 1e-4, vertices / joints 1e-4 m (0.1 mm), kp2d 1e-3.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+VERT_STRIDE = 13
+SAMPLE_TOKENS = [0, 5, 77, 100, 191]
+
+
+def _assets(cfg, seed=0):
+    from tokenhmr_amd import weights as W
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    return W.make_synthetic_state(cfg, seed), W.make_synthetic_tokenizer(cfg, seed), make_synthetic_smpl(cfg, seed)
+
+
+def _inputs(B, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(4000 + seed)
+    return torch.randn(B, 3, 256, 256, generator=g, dtype=torch.float32)
+
+
+@pytest.fixture(scope="module")
+def small(built_lib, cuda_dev):
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd.model import TokenHMR
+    cfg = HMRConfig(vit_depth=2, dec_depth=2)
+    sd, tok, smpl = _assets(cfg)
+    model = TokenHMR.from_state(cfg, sd, tok, smpl, max_batch=4, device=cuda_dev)
+    model.return_taps = True
+    return cfg, sd, tok, smpl, model
+
+
+def _check_against(out, ref, gap, tag):
+    """out: HIP dict (cpu tensors); ref: dict with the same keys."""
+    def md(a, b):
+        return (a - b).abs().max().item()
+    rep = {}
+    rep["vit"] = md(out["vit_features"], ref["vit_features"])
+    rep["token_out"] = md(out["token_out"], ref["token_out"])
+    rep["logits"] = md(out["cls_logits"], ref["cls_logits"])
+    rep["rot"] = md(torch.cat([out["pred_smpl_params"]["global_orient"], out["pred_smpl_params"]["body_pose"]], 1), ref["rotmat"])
+    rep["betas"] = md(out["pred_smpl_params"]["betas"], ref["betas"])
+    rep["cam"] = md(out["pred_cam"], ref["cam"])
+    rep["verts"] = md(out["pred_vertices"], ref["verts"])
+    rep["joints"] = md(out["pred_keypoints_3d"], ref["joints"])
+    rep["kp2d"] = md(out["pred_keypoints_2d"], ref["kp2d"])
+    idx_eq = out["token_idx"] == ref["token_idx"]
+    safe = gap > 1e-2
+    rep["idx_mismatch_frac"] = 1.0 - idx_eq.float().mean().item()
+    print(f"[{tag}] " + " ".join(f"{k}={v:.2e}" for k, v in rep.items()))
+    assert rep["vit"] < 2e-3 and rep["token_out"] < 1e-3 and rep["logits"] < 1e-3, rep
+    assert idx_eq[safe].all(), "token index differs where the top-2 logit gap > 1e-2"
+    assert rep["idx_mismatch_frac"] < 0.02, rep
+    assert rep["rot"] < 1e-4 and rep["betas"] < 1e-4 and rep["cam"] < 1e-4, rep
+    assert rep["verts"] < 1e-4 and rep["joints"] < 1e-4, rep      # 0.1 mm
+    assert rep["kp2d"] < 1e-3, rep
+
+
+def test_small_vs_oracle(small):
+    from oracle import tokenhmr_oracle as O
+    cfg, sd, tok, smpl, model = small
+    img = _inputs(2)
+    out = model({"img": img.to(model.engine.device)})
+    with torch.no_grad():
+        orc = O.forward(img, sd, tok, smpl, cfg)
+    outc = _to_cpu(out)
+    top2 = orc["cls_logits"].topk(2, dim=-1).values
+    ref = dict(vit_features=orc["vit_features"], token_out=orc["token_out"], cls_logits=orc["cls_logits"],
+               rotmat=torch.cat([orc["pred_smpl_params"]["global_orient"], orc["pred_smpl_params"]["body_pose"]], 1),
+               betas=orc["pred_smpl_params"]["betas"], cam=orc["pred_cam"], verts=orc["pred_vertices"],
+               joints=orc["pred_keypoints_3d"], kp2d=orc["pred_keypoints_2d"], token_idx=orc["token_idx"])
+    _check_against(outc, ref, top2[..., 0] - top2[..., 1], "small vs oracle")
+    # remaining reference-dict entries
+    assert torch.allclose(outc["cls_logits_softmax"], orc["cls_logits_softmax"], atol=1e-5)
+    assert torch.allclose(outc["pred_cam_t"], orc["pred_cam_t"], rtol=1e-4, atol=1e-3)
+    assert torch.equal(outc["focal_length"], orc["focal_length"])
+    assert torch.allclose(outc["pose6d"], orc["pose6d"], atol=1e-4)
+    # reference output contract: keys, shapes, dtypes (tokenhmr.py:156-188)
+    B = 2
+    shapes = {"pred_cam": (B, 3), "pred_cam_t": (B, 3), "focal_length": (B, 2), "pred_keypoints_3d": (B, 44, 3),
+              "pred_vertices": (B, 6890, 3), "pred_keypoints_2d": (B, 44, 2), "cls_logits_softmax": (B, 160, 2048)}
+    for k, s in shapes.items():
+        assert tuple(out[k].shape) == s and out[k].dtype == torch.float32 and out[k].is_cuda
+    assert tuple(out["pred_smpl_params"]["global_orient"].shape) == (B, 1, 3, 3)
+    assert tuple(out["pred_smpl_params"]["body_pose"].shape) == (B, 23, 3, 3)
+    assert tuple(out["pred_smpl_params"]["betas"].shape) == (B, 10)
+
+
+def _to_cpu(o):
+    return {k: ({kk: vv.cpu() for kk, vv in v.items()} if isinstance(v, dict) else v.cpu()) for k, v in o.items()}
+
+
+def _check_golden(model, cfg, sd, tok, name):
+    from tokenhmr_amd import weights as W
+    g = np.load(os.path.join(GOLDEN_DIR, name))
+    vd, dd, B, seed = [int(v) for v in g["meta"]]
+    assert (vd, dd) == (cfg.vit_depth, cfg.dec_depth)
+    assert abs(W.checksum(sd) - g["weights_checksum"][0]) < 1e-6 * max(1.0, abs(g["weights_checksum"][0])), \
+        "synthetic weight generator drifted from the one that produced the golden file"
+    img = _inputs(B, seed)
+    assert abs(float(img.double().sum()) - g["img_checksum"][0]) < 1e-6
+    out = _to_cpu(model({"img": img.to(model.engine.device)}))
+    T = lambda k: torch.from_numpy(g[k])  # noqa: E731
+
+    def md(a, b):
+        return (a - b).abs().max().item()
+    rep = dict(
+        vit=md(out["vit_features"][:, SAMPLE_TOKENS, :], T("vit_features_sample")),
+        token_out=md(out["token_out"], T("token_out")),
+        logits=md(out["cls_logits"][:, ::16, :][:, :, ::8], T("logits_sample")),
+        pose6d=md(out["pose6d"], T("pose6d")),
+        rot=md(torch.cat([out["pred_smpl_params"]["global_orient"], out["pred_smpl_params"]["body_pose"]], 1), T("rotmat")),
+        betas=md(out["pred_smpl_params"]["betas"], T("betas")), cam=md(out["pred_cam"], T("cam")),
+        verts=md(out["pred_vertices"][:, ::VERT_STRIDE], T("verts_sample")), joints=md(out["pred_keypoints_3d"], T("joints")),
+        kp2d=md(out["pred_keypoints_2d"], T("kp2d")))
+    idx_eq = out["token_idx"] == T("token_idx")
+    safe = T("top2_gap") > 1e-2
+    rep["idx_mismatch_frac"] = 1.0 - idx_eq.float().mean().item()
+    print(f"[golden {name}] " + " ".join(f"{k}={v:.2e}" for k, v in rep.items()))
+    assert rep["vit"] < 2e-3 and rep["token_out"] < 1e-3 and rep["logits"] < 1e-3, rep
+    assert idx_eq[safe].all() and rep["idx_mismatch_frac"] < 0.02, rep
+    assert rep["pose6d"] < 1e-4 and rep["rot"] < 1e-4 and rep["betas"] < 1e-4 and rep["cam"] < 1e-4, rep
+    assert rep["verts"] < 1e-4 and rep["joints"] < 1e-4 and rep["kp2d"] < 1e-3, rep
+
+
+def test_small_vs_golden(small):
+    cfg, sd, tok, smpl, model = small
+    _check_golden(model, cfg, sd, tok, "small_d2.npz")
+
+
+def test_full_depth_vs_golden(built_lib, cuda_dev):
+    """ViT-H depth 32 + 6-layer decoder: the release architecture, B=2, vs tensors the reference's own modules produced."""
+    from tokenhmr_amd.config import RELEASE
+    from tokenhmr_amd.model import TokenHMR
+    sd, tok, smpl = _assets(RELEASE)
+    model = TokenHMR.from_state(RELEASE, sd, tok, smpl, max_batch=2, device=cuda_dev)
+    model.return_taps = True
+    _check_golden(model, RELEASE, sd, tok, "full_d32.npz")
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_batch_invariance_and_determinism(small):
+    """Crops are independent units: a crop's outputs must not depend on its batch position or batch size,
+    and two runs must agree bit for bit (deterministic reduction orders everywhere)."""
+    cfg, sd, tok, smpl, model = small
+    img = _inputs(4, seed=3).to(model.engine.device)
+    a = model({"img": img})
+    b = model({"img": img})
+    for k in ("pred_vertices", "pred_keypoints_3d", "pred_cam", "cls_logits"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["token_idx"], b["token_idx"])
+    single = model({"img": img[2:3]})
+    assert torch.equal(single["pred_vertices"][0], a["pred_vertices"][2])
+    assert torch.equal(single["token_idx"][0], a["token_idx"][2])
+    chunked = model.__class__.forward  # chunking path: batch > max_batch
+    model.max_batch, old = 2, model.max_batch
+    try:
+        c = model({"img": img})
+    finally:
+        model.max_batch = old
+    assert torch.equal(c["pred_vertices"], a["pred_vertices"]) and torch.equal(c["token_idx"], a["token_idx"])
+    assert chunked is not None
+
+
+def test_lbs_standalone_b64(small):
+    """LBS at the bench batch size (64 crops, 2 crop groups + ragged vertex chunk) vs the restated smplx oracle,
+    plus size-independent properties: identity pose & zero betas reproduce v_template; a global rotation
+    rotates every vertex rigidly."""
+    from oracle import tokenhmr_oracle as O
+    cfg, sd, tok, smpl, model = small
+    eng = model.engine
+    # engine was created with max_batch=4 -> use a dedicated engine for B=64
+    from tokenhmr_amd.model import TokenHMR
+    m64 = TokenHMR.from_state(cfg, sd, tok, smpl, max_batch=64, device=eng.device)
+    g = torch.Generator().manual_seed(7)
+    B = 64
+    R = O.rot6d_to_rotmat(torch.randn(B, 144, generator=g)).view(B, 24, 3, 3)
+    betas = torch.randn(B, 10, generator=g)
+    cam = torch.tensor([0.9, 0.05, -0.02]).repeat(B, 1) + 0.05 * torch.randn(B, 3, generator=g)
+    verts, joints, cam_t, kp2d = m64.engine.lbs_forward(R.to(eng.device), betas.to(eng.device), cam.to(eng.device))
+    rv, rj = O.smpl_forward(R[:, :1], R[:, 1:], betas, smpl)
+    f = cfg.focal_length * torch.ones(B, 2)
+    rct = torch.stack([cam[:, 1], cam[:, 2], 2 * f[:, 0] / (cfg.img_size * cam[:, 0] + 1e-9)], -1)
+    rk = O.perspective_projection(rj, rct, f / cfg.img_size)
+    assert (verts.cpu() - rv).abs().max() < 1e-4 and (joints.cpu() - rj).abs().max() < 1e-4
+    assert torch.allclose(cam_t.cpu(), rct, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(kp2d.cpu(), rk, rtol=1e-4, atol=1e-3)
+    # identity pose, zero betas -> template
+    I = torch.eye(3).expand(3, 24, 3, 3).contiguous()
+    v0, j0, _, _ = m64.engine.lbs_forward(I.to(eng.device), torch.zeros(3, 10, device=eng.device))
+    assert (v0.cpu() - smpl["v_template"][None]).abs().max() < 2e-6
+    # rigid global rotation about the root joint
+    Rg = O.rot6d_to_rotmat(torch.randn(1, 6, generator=g))[0]
+    Rr = I.clone()
+    Rr[:, 0] = Rg
+    v1, _, _, _ = m64.engine.lbs_forward(Rr.to(eng.device), torch.zeros(3, 10, device=eng.device))
+    J0 = (smpl["J_regressor"] @ smpl["v_template"])[0]
+    expect = (smpl["v_template"] - J0) @ Rg.T + J0
+    assert (v1.cpu()[0] - expect).abs().max() < 1e-5
+
+
+def test_vq_argmin(small):
+    """QuantizeEMAReset.quantize (quantize_cnn.py:80-86): indices equal to the oracle wherever the oracle's best and
+    second-best distances differ by more than 1e-3 (fp32 expanded-form distances ~ 5e2 here), plus the golden
+    indices the reference's own module produced, and the exact round trip quantize(codebook[k]) == k."""
+    from oracle import tokenhmr_oracle as O
+    cfg, sd, tok, smpl, model = small
+    cb = tok["quantizer.codebook"]
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1000, 256, generator=g)
+    idx, dist = model.engine.vq_argmin(x.to(model.engine.device), want_dist=True)
+    ridx, rdist = O.vq_quantize(x, cb)
+    assert (dist.cpu() - rdist).abs().max() < 1e-3
+    two = rdist.topk(2, dim=-1, largest=False).values
+    safe = (two[:, 1] - two[:, 0]) > 1e-3
+    assert torch.equal(idx.cpu()[safe].long(), ridx[safe])
+    assert safe.float().mean() > 0.95
+    # codebook rows quantise to themselves (distance 0 vs >> 0): exact, size-independent
+    self_idx = model.engine.vq_argmin(cb.to(model.engine.device))
+    assert torch.equal(self_idx.cpu().long(), torch.arange(2048))
+    gold = np.load(os.path.join(GOLDEN_DIR, "small_d2.npz"))
+    gi = model.engine.vq_argmin(torch.from_numpy(gold["vq_in"]).to(model.engine.device)).cpu()
+    rgi, rgd = O.vq_quantize(torch.from_numpy(gold["vq_in"]), cb)
+    two = rgd.topk(2, dim=-1, largest=False).values
+    ok = (two[:, 1] - two[:, 0]) > 1e-3
+    assert torch.equal(gi[ok].long(), torch.from_numpy(gold["vq_idx"]).long()[ok])
+
+
+def test_errors_are_loud(small):
+    from tokenhmr_amd._cabi import EngineError
+    cfg, sd, tok, smpl, model = small
+    with pytest.raises(ValueError):
+        model.engine.forward(torch.zeros(1, 3, 224, 224, device=model.engine.device))
+    with pytest.raises(ValueError):
+        model.engine.forward(torch.zeros(9, 3, 256, 256, device=model.engine.device))   # > max_batch
+    with pytest.raises(RuntimeError):
+        model({"img": torch.zeros(1, 3, 256, 256)})                                      # CPU tensor: no fallback
+    from tokenhmr_amd.engine import Engine
+    e = Engine(cfg, max_batch=1, device=model.engine.device)
+    with pytest.raises(EngineError):
+        e.forward(torch.zeros(1, 3, 256, 256, device=model.engine.device))               # weights not finalized
+    bad = dict(sd)
+    bad.pop("backbone.last_norm.bias")
+    e.load_state(bad, tok)
+    e.load_smpl(smpl)
+    with pytest.raises(EngineError):
+        e.finalize()                                                                     # strict: missing tensor
+    with pytest.raises(KeyError):
+        e.load_state({"backbone.not_a_tensor": torch.zeros(1)})

@@ -1,0 +1,142 @@
+"""Per-kernel parity (-m gpu): each HIP kernel, called through the C ABI, against the plain fp32
+torch CPU statement of the same reference op.  Tolerances are written next to each check: the HIP
+kernels are exact-fp32 (fmaf-chain MFMA), so differences vs. MKL/oneDNN are summation-order only."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _gemm_ref(a, w, bias, resid, epi, qscale, qcols):
+    c = a.double() @ w.double().t()
+    if epi != "none":
+        c = c + bias.double()
+    if epi == "bias_gelu":
+        c = F.gelu(c)
+    elif epi == "bias_relu":
+        c = F.relu(c)
+    elif epi == "bias_resid":
+        c = resid.double() + c
+    elif epi == "bias_qscale":
+        c[:, :qcols] = c[:, :qcols] * qscale
+    elif epi == "bias_pos":
+        M = a.shape[0]
+        t = torch.arange(M) % 192
+        c = (c + resid.double()[1 + t]) + resid.double()[0]
+    return c.float()
+
+
+# (M, N, K): exact tiles, ragged M/N edges, tiny N, K = one tile, the real ViT shapes at B=2
+SHAPES = [(128, 128, 32), (256, 320, 64), (384, 1280, 1280), (200, 72, 96), (130, 6, 1536), (37, 31, 64),
+          (384, 3840, 1280), (384, 1280, 5120), (1, 160, 64), (1344, 512, 512)]
+
+
+@pytest.mark.parametrize("variant", ["128x128", "128x160", "auto"])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_gemm_shapes(built_lib, cuda_dev, shape, variant):
+    from tokenhmr_amd import ops
+    M, N, K = shape
+    a, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(N, seed=3)
+    out = ops.gemm(a.to(cuda_dev), w.to(cuda_dev), b.to(cuda_dev), epi="bias", variant=variant).cpu()
+    ref = _gemm_ref(a, w, b, None, "bias", 1.0, 0)
+    # fp32 fmaf chain vs fp64: |err| <~ 1e-6 * sum|a*w| ~ 1e-6*sqrt(K); allow 2e-5 abs at |C| ~ 1
+    assert torch.allclose(out, ref, atol=3e-5, rtol=1e-5), (out - ref).abs().max()
+
+
+@pytest.mark.parametrize("epi", ["none", "bias", "bias_gelu", "bias_relu", "bias_resid", "bias_qscale", "bias_pos"])
+def test_gemm_epilogues(built_lib, cuda_dev, epi):
+    from tokenhmr_amd import ops
+    M, N, K = 384, 256, 128          # M = 2*192 so that the pos-embed row index wraps
+    a, w, b = _rand(M, K, seed=4), _rand(N, K, seed=5, scale=0.1), _rand(N, seed=6)
+    resid = _rand(193, N, seed=7) if epi == "bias_pos" else _rand(M, N, seed=7)
+    kw = dict(qscale=80 ** -0.5, qcols=100)
+    out = ops.gemm(a.to(cuda_dev), w.to(cuda_dev), None if epi == "none" else b.to(cuda_dev),
+                   resid.to(cuda_dev) if epi in ("bias_resid", "bias_pos") else None, epi=epi, **kw).cpu()
+    ref = _gemm_ref(a, w, b, resid, epi, kw["qscale"], kw["qcols"])
+    assert torch.allclose(out, ref, atol=2e-5, rtol=1e-5), (out - ref).abs().max()
+
+
+def test_gemm_asymmetric_identity(built_lib, cuda_dev):
+    """A = I with an asymmetric W catches a transposed C write (guide rule: always A=I with asymmetric B)."""
+    from tokenhmr_amd import ops
+    n = 256
+    a = torch.eye(n)
+    w = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 1000.0
+    out = ops.gemm(a.to(cuda_dev), w.to(cuda_dev), epi="none").cpu()
+    assert torch.equal(out, w.t().contiguous())
+
+
+@pytest.mark.parametrize("shape", [(64, 1024, 1024), (64, 512, 1024), (5, 31, 1024), (64, 10240, 1024), (100, 48, 64), (2, 1024, 512)])
+@pytest.mark.parametrize("epi", ["none", "bias", "bias_gelu", "bias_resid"])
+def test_gemm_skinny(built_lib, cuda_dev, shape, epi):
+    from tokenhmr_amd import ops
+    M, N, K = shape
+    a, w, b, r = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(N, seed=3), _rand(M, N, seed=4)
+    out = ops.gemm(a.to(cuda_dev), w.to(cuda_dev), None if epi == "none" else b.to(cuda_dev),
+                   r.to(cuda_dev) if epi == "bias_resid" else None, epi=epi, variant="skinny").cpu()
+    ref = _gemm_ref(a, w, b, r, epi, 1.0, 0)
+    assert torch.allclose(out, ref, atol=3e-5, rtol=1e-5), (out - ref).abs().max()
+
+
+def test_gemm_deterministic(built_lib, cuda_dev):
+    from tokenhmr_amd import ops
+    a, w = _rand(384, 1280, seed=1).to(cuda_dev), _rand(1280, 1280, seed=2, scale=0.03).to(cuda_dev)
+    assert torch.equal(ops.gemm(a, w), ops.gemm(a, w))
+
+
+@pytest.mark.parametrize("rows,D,eps,relu", [(384, 1280, 1e-6, False), (7, 1280, 1e-6, False), (64, 1024, 1e-5, False),
+                                              (2, 10240, 1e-5, True), (320, 64, 1e-5, True), (3, 64, 1e-5, False)])
+def test_layernorm(built_lib, cuda_dev, rows, D, eps, relu):
+    from tokenhmr_amd import ops
+    x = _rand(rows, D, seed=1, scale=3.0) + 0.7
+    g, b = 1 + 0.1 * _rand(D, seed=2), 0.1 * _rand(D, seed=3)
+    out = ops.layernorm(x.to(cuda_dev), g.to(cuda_dev), b.to(cuda_dev), eps, relu).cpu()
+    ref = F.layer_norm(x, (D,), g, b, eps)
+    if relu:
+        ref = F.relu(ref)
+    assert torch.allclose(out, ref, atol=5e-6, rtol=1e-5), (out - ref).abs().max()
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_vit_attention(built_lib, cuda_dev, B):
+    """vit.py:113-122 on random q,k,v (q pre-scaled as the QKV epilogue would)."""
+    from tokenhmr_amd import ops
+    qkv = _rand(B, 192, 3840, seed=11)
+    qkv[:, :, :1280] *= 80 ** -0.5
+    out = ops.vit_attention(qkv.to(cuda_dev)).cpu()
+    t = qkv.reshape(B, 192, 3, 16, 80).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    ref = ((q @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B, 192, 1280)
+    assert torch.allclose(out, ref, atol=5e-6, rtol=1e-5), (out - ref).abs().max()
+
+
+def test_vit_attention_peaked(built_lib, cuda_dev):
+    """Large score spread (one dominant key per query) exercises the max-subtraction path."""
+    from tokenhmr_amd import ops
+    qkv = _rand(1, 192, 3840, seed=12)
+    qkv[:, :, :2560] *= 6.0
+    out = ops.vit_attention(qkv.to(cuda_dev)).cpu()
+    t = qkv.reshape(1, 192, 3, 16, 80).permute(2, 0, 3, 1, 4)
+    ref = ((t[0] @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]).transpose(1, 2).reshape(1, 192, 1280)
+    assert torch.isfinite(out).all()
+    assert torch.allclose(out, ref, atol=2e-5, rtol=1e-4), (out - ref).abs().max()
+
+
+def test_rot6d(built_lib, cuda_dev):
+    from tokenhmr_amd import ops
+    from oracle import tokenhmr_oracle as O
+    x = _rand(4, 144, seed=5)
+    out = ops.rot6d_to_rotmat(x.to(cuda_dev)).cpu()
+    ref = O.rot6d_to_rotmat(x)
+    assert torch.allclose(out, ref, atol=1e-6), (out - ref).abs().max()
+    eye = torch.eye(3).expand_as(out)
+    assert torch.allclose(out @ out.transpose(1, 2), eye, atol=1e-5)      # orthonormal (size-independent property)
+    assert torch.allclose(torch.linalg.det(out), torch.ones(out.shape[0]), atol=1e-5)

@@ -1,0 +1,132 @@
+"""CPU (-m "not gpu"): pin the oracle.
+
+1. oracle/tokenhmr_oracle.py vs the golden tensors that the REFERENCE'S OWN modules produced in the
+   build container (oracle/gen_golden.py): bit-level agreement is expected because both run the same
+   torch CPU kernels — any deviation means the restatement diverged from the reference.
+2. when /root/reference is present, the same check live against the imported reference modules.
+The SMPL stage is restated from smplx==0.1.28 (absent offline): parity unpinned there; only internal
+consistency properties are checked.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from tokenhmr_amd.config import HMRConfig, RELEASE
+from tokenhmr_amd import weights as W
+from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+from oracle import tokenhmr_oracle as O
+
+SAMPLE_TOKENS = [0, 5, 77, 100, 191]
+VERT_STRIDE = 13
+
+
+def _inputs(B, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(4000 + seed)
+    return torch.randn(B, 3, 256, 256, generator=g, dtype=torch.float32)
+
+
+def _run(name):
+    g = np.load(os.path.join(GOLDEN_DIR, name))
+    vd, dd, B, seed = [int(v) for v in g["meta"]]
+    cfg = HMRConfig(vit_depth=vd, dec_depth=dd)
+    sd, tok, smpl = W.make_synthetic_state(cfg, seed), W.make_synthetic_tokenizer(cfg, seed), make_synthetic_smpl(cfg, seed)
+    assert abs(W.checksum(sd) - g["weights_checksum"][0]) <= 1e-9 * abs(g["weights_checksum"][0])
+    assert abs(W.checksum(tok) - g["weights_checksum"][1]) <= 1e-9 * abs(g["weights_checksum"][1])
+    img = _inputs(B, seed)
+    assert abs(float(img.double().sum()) - g["img_checksum"][0]) < 1e-9
+    with torch.no_grad():
+        out = O.forward(img, sd, tok, smpl, cfg)
+    return g, out, (cfg, sd, tok, smpl)
+
+
+def _compare(g, out, tol):
+    T = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    pairs = {
+        "vit_features_sample": out["vit_features"][:, SAMPLE_TOKENS, :],
+        "token_out": out["token_out"],
+        "logits_sample": out["cls_logits"][:, ::16, :][:, :, ::8],
+        "pose6d": out["pose6d"],
+        "betas": out["pred_smpl_params"]["betas"],
+        "cam": out["pred_cam"],
+        "rotmat": torch.cat([out["pred_smpl_params"]["global_orient"], out["pred_smpl_params"]["body_pose"]], 1),
+        "cam_t": out["pred_cam_t"],
+        "verts_sample": out["pred_vertices"][:, ::VERT_STRIDE],
+        "joints": out["pred_keypoints_3d"],
+        "kp2d": out["pred_keypoints_2d"],
+        "probs_max": out["cls_logits_softmax"].max(-1).values,
+    }
+    for k, v in pairs.items():
+        d = (v - T(k)).abs().max().item()
+        assert d <= tol, (k, d)
+    assert torch.equal(out["token_idx"], T("token_idx"))
+
+
+def test_oracle_matches_reference_golden_small():
+    g, out, _ = _run("small_d2.npz")
+    _compare(g, out, tol=1e-6)   # same torch CPU kernels as the reference run; thread-count effects only
+
+
+def test_oracle_matches_reference_golden_full_depth():
+    g, out, _ = _run("full_d32.npz")
+    _compare(g, out, tol=2e-5)   # 32 blocks deep; allow for MKL thread-partition differences on other hosts
+
+
+def test_vq_quantize_matches_reference_golden():
+    g = np.load(os.path.join(GOLDEN_DIR, "small_d2.npz"))
+    tok = W.make_synthetic_tokenizer(HMRConfig(vit_depth=2, dec_depth=2), 0)
+    idx, _ = O.vq_quantize(torch.from_numpy(g["vq_in"]), tok["quantizer.codebook"])
+    assert torch.equal(idx.int(), torch.from_numpy(g["vq_idx"]))
+
+
+def test_live_reference_when_present():
+    from oracle import ref_import
+    if not ref_import.available():
+        pytest.skip("/root/reference not mounted (GPU box): golden fixtures cover this")
+    from oracle import gen_golden
+    cfg = HMRConfig(vit_depth=1, dec_depth=1)
+    sd, tok, smpl = W.make_synthetic_state(cfg, 5), W.make_synthetic_tokenizer(cfg, 5), make_synthetic_smpl(cfg, 5)
+    img = _inputs(1, 5)
+    ref = gen_golden.reference_forward(img, cfg, sd, tok, smpl)
+    with torch.no_grad():
+        out = O.forward(img, sd, tok, smpl, cfg)
+    assert torch.equal(ref["vit_features"], out["vit_features"])
+    assert torch.equal(ref["cls_logits"], out["cls_logits"])
+    assert torch.equal(ref["pose6d"], out["pose6d"])
+    assert torch.equal(ref["kp2d"], out["pred_keypoints_2d"])
+
+
+def test_nearest_index_matches_torch_upsample():
+    """vanilla_pose_vqvae.py:139-141 nn.Upsample(size): the oracle's index table == what torch does."""
+    for tin, tout in zip(RELEASE.vq_lengths[:-1], RELEASE.vq_lengths[1:]):
+        x = torch.arange(tin, dtype=torch.float32).view(1, 1, tin)
+        y = torch.nn.Upsample(size=tout)(x).view(-1).long()
+        assert torch.equal(y, O.nearest_index(tin, tout))
+    assert RELEASE.vq_lengths == [160, 125, 90, 55, 21]
+
+
+def test_smpl_restatement_properties():
+    """smplx is absent (parity unpinned): check the restated LBS for internal consistency."""
+    cfg = RELEASE
+    smpl = make_synthetic_smpl(cfg, 0)
+    I = torch.eye(3).expand(2, 24, 3, 3)
+    v, j = O.smpl_forward(I[:, :1], I[:, 1:], torch.zeros(2, 10), smpl)
+    assert (v - smpl["v_template"][None]).abs().max() < 1e-5
+    assert j.shape == (2, 44, 3)
+    Jt = smpl["J_regressor"] @ smpl["v_template"]
+    assert torch.allclose(j[0, 8], Jt[0], atol=1e-5)          # openpose 8 (MidHip) <- SMPL joint 0
+    g = torch.Generator().manual_seed(1)
+    Rg = O.rot6d_to_rotmat(torch.randn(1, 6, generator=g))[0]
+    R = I.clone()
+    R[:, 0] = Rg
+    v2, _ = O.smpl_forward(R[:, :1], R[:, 1:], torch.zeros(2, 10), smpl)
+    assert torch.allclose(v2[0], (smpl["v_template"] - Jt[0]) @ Rg.T + Jt[0], atol=1e-5)
+
+
+def test_token_indices_tie_break_lowest():
+    logits = torch.zeros(1, 2, 8)
+    logits[0, 0, [3, 5]] = 1.0
+    logits[0, 1, 7] = 2.0
+    assert O.token_indices(logits).tolist() == [[3, 7]]

@@ -1,0 +1,115 @@
+"""ctypes binding of include/tokenhmr_hip.h (libtokenhmr_hip.so).
+
+There is NO CPU fallback: if the shared library is missing or a symbol is absent this module
+raises, so a GPU box can never silently run anything but the HIP path.
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtokenhmr_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "tokenhmr_hip.h")
+
+ABI_VERSION = 1
+PROF_NAMES = ["gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "attention", "layernorm", "patch_embed",
+              "dec_kv", "head", "lbs"]
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("vit_depth", C.c_int32), ("dec_depth", C.c_int32),
+                ("max_batch", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64),
+                ("on_device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SmplDesc(C.Structure):
+    _fields_ = [("v_template", C.c_void_p), ("shapedirs", C.c_void_p), ("posedirs", C.c_void_p),
+                ("J_regressor", C.c_void_p), ("lbs_weights", C.c_void_p), ("J19_regressor", C.c_void_p),
+                ("parents", C.c_void_p), ("extra_verts", C.c_void_p), ("joint_map", C.c_void_p),
+                ("on_device", C.c_int32), ("reserved", C.c_int32)]
+
+
+OUTPUT_FIELDS = ["pred_cam", "rotmat", "betas", "cls_logits_softmax", "pred_cam_t", "focal_length",
+                 "pred_keypoints_3d", "pred_vertices", "pred_keypoints_2d", "token_idx",
+                 "vit_features", "token_out", "cls_logits", "pose6d"]
+
+
+class Outputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in OUTPUT_FIELDS]
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double), ("launches", C.c_int64)]
+
+
+def declared_symbols():
+    """Every function the header declares (used by the symbol-export test)."""
+    with open(HEADER) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(thmr_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    if missing:
+        raise RuntimeError(f"libtokenhmr_hip.so lacks symbols declared in tokenhmr_hip.h: {missing}")
+    vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+    lib.thmr_abi_version.restype = C.c_int
+    lib.thmr_build_info.restype = C.c_char_p
+    lib.thmr_last_error.restype = C.c_char_p
+    lib.thmr_last_error.argtypes = [vp]
+    lib.thmr_arena_bytes.argtypes = [C.POINTER(Config), C.POINTER(sz), C.POINTER(sz)]
+    lib.thmr_spec.argtypes = [C.POINTER(Config), i32, C.POINTER(C.c_char_p), C.POINTER(i64)]
+    lib.thmr_create.argtypes = [C.POINTER(Config), vp, vp, C.POINTER(vp)]
+    lib.thmr_destroy.argtypes = [vp]
+    lib.thmr_destroy.restype = None
+    lib.thmr_load_weights.argtypes = [vp, C.POINTER(TensorDesc), sz, vp]
+    lib.thmr_load_smpl.argtypes = [vp, C.POINTER(SmplDesc), vp]
+    lib.thmr_finalize_weights.argtypes = [vp, i32, vp]
+    lib.thmr_weight_arena.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    lib.thmr_forward.argtypes = [vp, vp, i32, C.POINTER(Outputs), vp]
+    lib.thmr_vit_forward.argtypes = [vp, vp, i32, vp, vp]
+    lib.thmr_head_forward.argtypes = [vp, vp, i32, C.POINTER(Outputs), vp]
+    lib.thmr_lbs_forward.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    lib.thmr_vq_argmin.argtypes = [vp, vp, i32, vp, vp, vp]
+    lib.thmr_op_gemm.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, i32, i32, vp]
+    lib.thmr_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, i32, vp]
+    lib.thmr_op_vit_attention.argtypes = [vp, vp, i32, vp]
+    lib.thmr_op_rot6d.argtypes = [vp, vp, i32, vp]
+    lib.thmr_prof_enable.argtypes = [vp, i32]
+    lib.thmr_prof_collect.argtypes = [vp, C.POINTER(ProfEntry), i32]
+    for name in declared_symbols():
+        fn = getattr(lib, name)
+        if name not in ("thmr_build_info", "thmr_last_error", "thmr_destroy"):
+            fn.restype = C.c_int
+    if lib.thmr_abi_version() != ABI_VERSION:
+        raise RuntimeError("libtokenhmr_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def check(rc, engine=None):
+    if rc != 0:
+        lib = load()
+        msg = lib.thmr_last_error(engine)
+        raise EngineError(f"tokenhmr_hip error {rc}: {msg.decode() if msg else '?'}")

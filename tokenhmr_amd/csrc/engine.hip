@@ -1,0 +1,829 @@
+// TokenHMR inference engine + C ABI (include/tokenhmr_hip.h).
+//
+// One engine per GPU: owns a packed weight arena (reference checkpoint tensors at fixed offsets, so a
+// single RCCL broadcast of the arena replicates the model) and a static activation arena sized for
+// max_batch crops; thmr_forward launches the whole path on the caller's stream with no allocation
+// and no host synchronisation.
+//
+// Hot path orchestrated here (reference: tokenhmr/lib/models/tokenhmr.py:135-188 forward_step):
+//   ViT-H            vit.py:320-343          -> vit_forward()
+//   decoder + head   token_head.py:65-128    -> head_forward()
+//   SMPL + camera    smpl_wrapper.py:27-41, geometry.py:86-124, tokenhmr.py:165-187 -> lbs()
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/tokenhmr_hip.h"
+#include "common.h"
+
+namespace {
+
+constexpr int TOK = 192, DIM = 1280, HEADS = 16, MLP = 5120;
+constexpr int E = 1024, INNER = 512, DEC_MLP = 1024;
+constexpr int TN = 160, NCLS = 2048, HID = 64, HID_INTER = 256, TOK_INTER = 64, MIX = 4;
+constexpr int CODE = 256, VQW = 512, VQJ = 21;
+constexpr int NV = 6890, NJ = 24, NB = 10, NP = 207;
+constexpr float VIT_EPS = 1e-6f, LN_EPS = 1e-5f;
+constexpr float FOCAL = 5000.0f, IMG = 256.0f;
+
+thread_local std::string g_last_error;
+
+struct Slot {
+    size_t off = 0;       // float offset in the weight arena
+    int64_t numel = 0;
+    bool loaded = false;
+};
+
+struct ProfRec {
+    int cls;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct thmr_engine {
+    thmr_config cfg{};
+    int vit_depth = 32, dec_depth = 6, max_batch = 0;
+    float* warena = nullptr;
+    float* sarena = nullptr;
+    bool own_w = false, own_s = false;
+    size_t wfloats = 0, sfloats = 0;
+    std::unordered_map<std::string, Slot> slots;
+    std::vector<std::string> required;
+    bool smpl_loaded = false, finalized = false;
+    std::string err;
+    // derived / constant regions (float offsets in weight arena)
+    size_t o_kv_all = 0, o_ro_w = 0, o_ro_b = 0;
+    size_t o_convp[7] = {0};      // repacked k=3 convs: 0,3,6,9,12, res0.conv1, res1.conv1, 14.1, 15 -> see conv_names
+    size_t o_cbT = 0, o_cnorm = 0, o_idx = 0;   // idx tables as int32 within the float arena
+    size_t o_smpl_vt = 0, o_smpl_sd = 0, o_smpl_pd = 0, o_smpl_jr = 0, o_smpl_w = 0, o_smpl_j19 = 0, o_smpl_int = 0,
+           o_smpl_jt = 0, o_smpl_jsd = 0;
+    std::vector<size_t> convp;    // repacked conv offsets, index by conv id
+    int vq_len[5] = {160, 125, 90, 55, 21};
+    // scratch offsets (floats)
+    struct {
+        size_t x, h, big;
+        size_t dx, dh, dv, dq, dca, dff, ro;
+        size_t mt, cf, cf2, y1, tT, u, yt, y, s, z0, zh, nl, nl2;
+        size_t feat, gat, act0, act1, act2, bpose, tokidx;
+        size_t A, pf, Jtr, rot, betas, cam, camt, verts, joints, pose6d;
+        size_t total;
+    } so{};
+    // profiler
+    bool prof_on = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_next = 0;
+
+    float* W(const std::string& name) {
+        auto it = slots.find(name);
+        if (it == slots.end()) { err = "internal: unknown weight " + name; return nullptr; }
+        return warena + it->second.off;
+    }
+    float* S(size_t off) { return sarena + off; }
+};
+
+namespace {
+
+size_t align64(size_t f) { return (f + 63) & ~size_t(63); }   // 256-byte alignment in floats
+
+int fail(thmr_engine* e, int code, const std::string& msg) {
+    if (e) e->err = msg;
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_OK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (call);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(e, THMR_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e));  \
+    } while (0)
+
+#define LAUNCH_OK(call)                                                                       \
+    do {                                                                                      \
+        int _r = (call);                                                                      \
+        if (_r != 0) {                                                                        \
+            hipError_t _e = hipGetLastError();                                                \
+            return fail(e, _r == -1 ? THMR_ERR_INVALID : THMR_ERR_HIP,                        \
+                        std::string(#call) + " failed: " + hipGetErrorString(_e));            \
+        }                                                                                     \
+    } while (0)
+
+// ---- the reference checkpoint contract, mirrored by tokenhmr_amd/weights.py::spec ----
+void build_spec(int vit_depth, int dec_depth, std::vector<std::pair<std::string, int64_t>>& out) {
+    auto add = [&](const std::string& n, int64_t numel) { out.emplace_back(n, numel); };
+    auto lin = [&](const std::string& n, int64_t o, int64_t i, bool bias = true) {
+        add(n + ".weight", o * i);
+        if (bias) add(n + ".bias", o);
+    };
+    auto ln = [&](const std::string& n, int64_t d) { add(n + ".weight", d); add(n + ".bias", d); };
+    add("backbone.pos_embed", (TOK + 1) * DIM);
+    add("backbone.patch_embed.proj.weight", (int64_t)DIM * 768);
+    add("backbone.patch_embed.proj.bias", DIM);
+    for (int i = 0; i < vit_depth; ++i) {
+        const std::string p = "backbone.blocks." + std::to_string(i) + ".";
+        ln(p + "norm1", DIM);
+        lin(p + "attn.qkv", 3 * DIM, DIM);
+        lin(p + "attn.proj", DIM, DIM);
+        ln(p + "norm2", DIM);
+        lin(p + "mlp.fc1", MLP, DIM);
+        lin(p + "mlp.fc2", DIM, MLP);
+    }
+    ln("backbone.last_norm", DIM);
+    const std::string T = "smpl_head.transformer.";
+    add(T + "pos_embedding", E);
+    lin(T + "to_token_embedding", E, 1);
+    for (int l = 0; l < dec_depth; ++l) {
+        const std::string p = T + "transformer.layers." + std::to_string(l) + ".";
+        ln(p + "0.norm", E);
+        lin(p + "0.fn.to_qkv", 3 * INNER, E, false);
+        lin(p + "0.fn.to_out.0", E, INNER);
+        ln(p + "1.norm", E);
+        lin(p + "1.fn.to_kv", 2 * INNER, DIM, false);
+        lin(p + "1.fn.to_q", INNER, E, false);
+        lin(p + "1.fn.to_out.0", E, INNER);
+        ln(p + "2.norm", E);
+        lin(p + "2.fn.net.0", DEC_MLP, E);
+        lin(p + "2.fn.net.3", E, DEC_MLP);
+    }
+    lin("smpl_head.decpose_grot", 6, E);
+    lin("smpl_head.decshape", 10, E);
+    lin("smpl_head.deccam", 3, E);
+    lin("smpl_head.decpose_hands", 12, E);
+    const std::string C = "smpl_head.decpose.";
+    lin(C + "mixer_trans.ff.0", (int64_t)TN * HID, E);
+    ln(C + "mixer_trans.ff.1", (int64_t)TN * HID);
+    for (int m = 0; m < MIX; ++m) {
+        const std::string p = C + "mixer_head." + std::to_string(m) + ".";
+        ln(p + "layernorm1", HID);
+        lin(p + "MLP_token.ff.0", TOK_INTER, TN);
+        lin(p + "MLP_token.ff.3", TN, TOK_INTER);
+        ln(p + "layernorm2", HID);
+        lin(p + "MLP_channel.ff.0", HID_INTER, HID);
+        lin(p + "MLP_channel.ff.3", HID, HID_INTER);
+    }
+    lin(C + "mixer_norm_layer.ff.0", HID, HID);
+    ln(C + "mixer_norm_layer.ff.1", HID);
+    lin(C + "class_pred_layer", NCLS, HID);
+    add("smpl_head.init_body_pose", 144);
+    add("smpl_head.init_betas", 10);
+    add("smpl_head.init_cam", 3);
+    // tokenizer.pth ['net']
+    auto conv = [&](const std::string& n, int64_t co, int64_t ci, int64_t k) { add(n + ".weight", co * ci * k); add(n + ".bias", co); };
+    conv("decoder.decoder.0", VQW, CODE, 3);
+    for (int i : {3, 6, 9, 12}) conv("decoder.decoder." + std::to_string(i), VQW, VQW, 3);
+    for (int b : {0, 1}) {
+        conv("decoder.decoder.14.0.model." + std::to_string(b) + ".conv1", VQW, VQW, 3);
+        conv("decoder.decoder.14.0.model." + std::to_string(b) + ".conv2", VQW, VQW, 1);
+    }
+    conv("decoder.decoder.14.1", VQW, VQW, 3);
+    conv("decoder.decoder.15", 6, VQW, 3);
+    add("quantizer.codebook", (int64_t)NCLS * CODE);
+}
+
+// k=3 convs that need the [co][k*ci+ci] repack, in execution order
+const char* const kConv3[] = {"decoder.decoder.0", "decoder.decoder.3", "decoder.decoder.6", "decoder.decoder.9",
+                              "decoder.decoder.12", "decoder.decoder.14.0.model.0.conv1",
+                              "decoder.decoder.14.0.model.1.conv1", "decoder.decoder.14.1", "decoder.decoder.15"};
+const int kConv3Ci[] = {CODE, VQW, VQW, VQW, VQW, VQW, VQW, VQW, VQW};
+const int kConv3Co[] = {VQW, VQW, VQW, VQW, VQW, VQW, VQW, VQW, 6};
+
+void layout_weights(thmr_engine* e) {
+    std::vector<std::pair<std::string, int64_t>> spec;
+    build_spec(e->vit_depth, e->dec_depth, spec);
+    size_t off = 0;
+    // contiguous groups first: to_kv of all layers -> one (dec_depth*1024, 1280) matrix; read-outs -> (31,1024)+(31)
+    e->o_kv_all = off;
+    for (int l = 0; l < e->dec_depth; ++l) {
+        const std::string n = "smpl_head.transformer.transformer.layers." + std::to_string(l) + ".1.fn.to_kv.weight";
+        e->slots[n] = Slot{off, (int64_t)2 * INNER * DIM, false};
+        off += (size_t)2 * INNER * DIM;
+    }
+    off = align64(off);
+    e->o_ro_w = off;
+    const char* ro_names[] = {"smpl_head.decpose_grot", "smpl_head.decshape", "smpl_head.deccam", "smpl_head.decpose_hands"};
+    const int ro_n[] = {6, 10, 3, 12};
+    for (int i = 0; i < 4; ++i) {
+        e->slots[std::string(ro_names[i]) + ".weight"] = Slot{off, (int64_t)ro_n[i] * E, false};
+        off += (size_t)ro_n[i] * E;
+    }
+    off += E;   // 32nd (padding) row so a clamped row read stays inside the arena
+    off = align64(off);
+    e->o_ro_b = off;
+    for (int i = 0; i < 4; ++i) {
+        e->slots[std::string(ro_names[i]) + ".bias"] = Slot{off, ro_n[i], false};
+        off += ro_n[i];
+    }
+    off = align64(off + 1);
+    for (auto& kv : spec) {
+        e->required.push_back(kv.first);
+        if (e->slots.count(kv.first)) continue;
+        e->slots[kv.first] = Slot{off, kv.second, false};
+        off = align64(off + (size_t)kv.second);
+    }
+    // derived regions
+    e->convp.resize(9);
+    for (int i = 0; i < 9; ++i) {
+        e->convp[i] = off;
+        off = align64(off + (size_t)kConv3Co[i] * kConv3Ci[i] * 3);
+    }
+    e->o_cbT = off;   off = align64(off + (size_t)NCLS * CODE);
+    e->o_cnorm = off; off = align64(off + NCLS);
+    e->o_idx = off;   off = align64(off + 4 * 160);
+    // SMPL constants
+    e->o_smpl_vt = off;  off = align64(off + (size_t)NV * 3);
+    e->o_smpl_sd = off;  off = align64(off + (size_t)NV * 30);
+    e->o_smpl_pd = off;  off = align64(off + (size_t)NP * NV * 3);
+    e->o_smpl_jr = off;  off = align64(off + (size_t)NJ * NV);
+    e->o_smpl_w = off;   off = align64(off + (size_t)NV * NJ);
+    e->o_smpl_j19 = off; off = align64(off + (size_t)19 * NV);
+    e->o_smpl_int = off; off = align64(off + 128);       // parents(24) | extra(21) | jmap(25) as int32
+    e->o_smpl_jt = off;  off = align64(off + NJ * 3);
+    e->o_smpl_jsd = off; off = align64(off + NJ * 30);
+    e->wfloats = off;
+}
+
+void layout_scratch(thmr_engine* e) {
+    const size_t B = (size_t)e->max_batch, M = B * TOK;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off = align64(off + n); return o; };
+    auto& s = e->so;
+    s.x = take(M * DIM);
+    s.h = take(M * DIM);
+    s.big = take(M * 6144);
+    s.dx = take(B * E); s.dh = take(B * E); s.dv = take(B * INNER); s.dq = take(B * INNER); s.dca = take(B * INNER);
+    s.dff = take(B * DEC_MLP); s.ro = take(B * 32);
+    s.mt = take(B * TN * HID); s.cf = take(B * TN * HID); s.cf2 = take(B * TN * HID);
+    s.y1 = take(B * TN * HID); s.tT = take(B * HID * TN); s.u = take(B * HID * TOK_INTER); s.yt = take(B * HID * TN);
+    s.y = take(B * TN * HID); s.s = take(B * TN * HID); s.z0 = take(B * TN * HID); s.zh = take(B * TN * HID_INTER);
+    s.nl = take(B * TN * HID); s.nl2 = take(B * TN * HID);
+    s.feat = take(B * TN * CODE);
+    s.gat = take(B * 125 * 3 * VQW);                 // largest gather: T=125, 3*512 (> 160*768)
+    s.act0 = take(B * TN * VQW); s.act1 = take(B * TN * VQW); s.act2 = take(B * TN * VQW);
+    s.bpose = take(B * 128); s.tokidx = take(B * TN);
+    s.A = take(B * NJ * 12); s.pf = take(B * NP + 1); s.Jtr = take(B * NJ * 3);
+    s.rot = take(B * NJ * 9); s.betas = take(B * NB); s.cam = take(B * 3); s.camt = take(B * 3);
+    s.verts = take(B * NV * 3); s.joints = take(B * 132); s.pose6d = take(B * 144);
+    s.total = off;
+    e->sfloats = off;
+}
+
+// ---- profiler helpers ----
+struct ProfScope {
+    thmr_engine* e;
+    hipStream_t s;
+    bool on;
+    size_t rec = 0;
+    ProfScope(thmr_engine* e_, hipStream_t s_, int cls, double flops, double bytes) : e(e_), s(s_), on(e_->prof_on) {
+        if (!on) return;
+        if (e->ev_next + 2 > e->ev_pool.size()) {
+            for (int i = 0; i < 512; ++i) {
+                hipEvent_t ev;
+                if (hipEventCreate(&ev) != hipSuccess) { on = false; return; }
+                e->ev_pool.push_back(ev);
+            }
+        }
+        ProfRec r{cls, flops, bytes, e->ev_pool[e->ev_next], e->ev_pool[e->ev_next + 1]};
+        e->ev_next += 2;
+        (void)hipEventRecord(r.e0, s);
+        e->prof.push_back(r);
+        rec = e->prof.size() - 1;
+    }
+    ~ProfScope() {
+        if (on) (void)hipEventRecord(e->prof[rec].e1, s);
+    }
+};
+
+GemmArgs mk(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
+            float* C, int64_t ldc, int M, int N, int K) {
+    GemmArgs a{};
+    a.A = A; a.W = W; a.bias = bias; a.resid = resid; a.C = C;
+    a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
+    a.M = M; a.N = N; a.K = K; a.qscale = 1.f; a.qcols = 0;
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------- ViT-H
+int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipStream_t st) {
+    const int M = B * TOK;
+    float* x = e->S(e->so.x);
+    float* h = e->S(e->so.h);
+    float* big = e->S(e->so.big);
+    {   // patch embed: crop + pad + im2col, then GEMM (+bias, +pos_embed)   vit.py:341,170-176,327
+        ProfScope ps(e, st, THMR_PROF_PATCH, 2.0 * M * 768.0 * DIM,
+                     4.0 * (B * 3.0 * 256 * 192 + (double)M * DIM + 768.0 * DIM));
+        LAUNCH_OK(launch_im2col_patch(img, big, B, st));
+        GemmArgs a = mk(big, 768, e->W("backbone.patch_embed.proj.weight"), 768, e->W("backbone.patch_embed.proj.bias"),
+                        e->W("backbone.pos_embed"), 0, x, DIM, M, DIM, 768);
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS_POS, -1, st));
+    }
+    const float qscale = 1.0f / sqrtf(80.0f);   // head_dim ** -0.5  (vit.py:101)
+    for (int i = 0; i < e->vit_depth; ++i) {
+        const std::string p = "backbone.blocks." + std::to_string(i) + ".";
+        {
+            ProfScope ps(e, st, THMR_PROF_LN, 0, 8.0 * M * DIM);
+            LAUNCH_OK(launch_layernorm(x, e->W(p + "norm1.weight"), e->W(p + "norm1.bias"), h, M, DIM, VIT_EPS, 0, st));
+        }
+        {   // qkv Linear; q columns scaled in the epilogue (vit.py:112,116)
+            ProfScope ps(e, st, THMR_PROF_GEMM_QKV, 2.0 * M * DIM * 3.0 * DIM, 4.0 * ((double)M * DIM + 3.0 * DIM * DIM + 3.0 * M * DIM));
+            GemmArgs a = mk(h, DIM, e->W(p + "attn.qkv.weight"), DIM, e->W(p + "attn.qkv.bias"), nullptr, 0, big, 3 * DIM, M,
+                            3 * DIM, DIM);
+            a.qscale = qscale; a.qcols = DIM;
+            LAUNCH_OK(launch_gemm(a, EPI_BIAS_QSCALE, -1, st));
+        }
+        {
+            ProfScope ps(e, st, THMR_PROF_ATTN, 4.0 * B * HEADS * 192.0 * 192.0 * 80.0, 4.0 * (4.0 * M * DIM));
+            LAUNCH_OK(launch_vit_attention(big, h, B, st));
+        }
+        {   // proj + residual (vit.py:123,149)
+            ProfScope ps(e, st, THMR_PROF_GEMM_PROJ, 2.0 * M * DIM * (double)DIM, 4.0 * (3.0 * M * DIM + (double)DIM * DIM));
+            GemmArgs a = mk(h, DIM, e->W(p + "attn.proj.weight"), DIM, e->W(p + "attn.proj.bias"), x, DIM, x, DIM, M, DIM, DIM);
+            LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, -1, st));
+        }
+        {
+            ProfScope ps(e, st, THMR_PROF_LN, 0, 8.0 * M * DIM);
+            LAUNCH_OK(launch_layernorm(x, e->W(p + "norm2.weight"), e->W(p + "norm2.bias"), h, M, DIM, VIT_EPS, 0, st));
+        }
+        {   // fc1 + exact GELU (vit.py:83-84)
+            ProfScope ps(e, st, THMR_PROF_GEMM_FC1, 2.0 * M * DIM * (double)MLP, 4.0 * ((double)M * DIM + (double)DIM * MLP + (double)M * MLP));
+            GemmArgs a = mk(h, DIM, e->W(p + "mlp.fc1.weight"), DIM, e->W(p + "mlp.fc1.bias"), nullptr, 0, big, MLP, M, MLP, DIM);
+            LAUNCH_OK(launch_gemm(a, EPI_BIAS_GELU, -1, st));
+        }
+        {   // fc2 + residual (vit.py:85,150)
+            ProfScope ps(e, st, THMR_PROF_GEMM_FC2, 2.0 * M * DIM * (double)MLP, 4.0 * ((double)M * MLP + (double)DIM * MLP + 2.0 * M * DIM));
+            GemmArgs a = mk(big, MLP, e->W(p + "mlp.fc2.weight"), MLP, e->W(p + "mlp.fc2.bias"), x, DIM, x, DIM, M, DIM, MLP);
+            LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, -1, st));
+        }
+    }
+    {   // last_norm (vit.py:335); kept token-major (the :337 permute is undone by token_head.py:69)
+        ProfScope ps(e, st, THMR_PROF_LN, 0, 8.0 * M * DIM);
+        LAUNCH_OK(launch_layernorm(x, e->W("backbone.last_norm.weight"), e->W("backbone.last_norm.bias"),
+                                   feats_out ? feats_out : h, M, DIM, VIT_EPS, 0, st));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- head
+int conv3(thmr_engine* e, int conv_id, const float* in, int Tin, int Tout, const int32_t* src, int dil, int prerelu,
+          const float* bias, int epi, const float* resid, float* outp, int B, hipStream_t st) {
+    const int ci = kConv3Ci[conv_id], co = kConv3Co[conv_id];
+    float* gat = e->S(e->so.gat);
+    LAUNCH_OK(launch_conv3_gather(in, gat, src, B, Tin, Tout, ci, dil, prerelu, st));
+    GemmArgs a = mk(gat, 3 * ci, e->warena + e->convp[conv_id], 3 * ci, bias, resid, co, outp, co, B * Tout, co, 3 * ci);
+    LAUNCH_OK(launch_gemm(a, epi, 0, st));
+    return 0;
+}
+
+int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* out, hipStream_t st) {
+    auto& so = e->so;
+    const int M = B * TOK;
+    float* big = e->S(so.big);
+    const int ldkv = e->dec_depth * 2 * INNER;
+    {   // K8: to_kv of all decoder layers in ONE GEMM on the un-normalised context (pose_transformer.py:102,113)
+        ProfScope ps(e, st, THMR_PROF_DEC_KV, 2.0 * M * DIM * (double)ldkv, 4.0 * ((double)M * DIM + (double)ldkv * DIM + (double)M * ldkv));
+        GemmArgs a = mk(ctx, DIM, e->warena + e->o_kv_all, DIM, nullptr, nullptr, 0, big, ldkv, M, ldkv, DIM);
+        LAUNCH_OK(launch_gemm(a, EPI_NONE, -1, st));
+    }
+    ProfScope ps_head(e, st, THMR_PROF_HEAD, 2.0 * B * (6.0 * 4.2e6 + 116.7e6 + 167.8e6 + 705.0e6), 0);
+    float *dx = e->S(so.dx), *dh = e->S(so.dh), *dv = e->S(so.dv), *dq = e->S(so.dq), *dca = e->S(so.dca), *dff = e->S(so.dff);
+    const std::string T = "smpl_head.transformer.";
+    LAUNCH_OK(launch_decoder_init(e->W(T + "to_token_embedding.bias"), e->W(T + "pos_embedding"), dx, B, E, st));
+    for (int l = 0; l < e->dec_depth; ++l) {
+        const std::string p = T + "transformer.layers." + std::to_string(l) + ".";
+        // self-attention over ONE token: softmax of a single score == 1, so out = to_out(v)  (pose_transformer.py:75-86)
+        LAUNCH_OK(launch_layernorm(dx, e->W(p + "0.norm.weight"), e->W(p + "0.norm.bias"), dh, B, E, LN_EPS, 0, st));
+        {
+            GemmArgs a = mk(dh, E, e->W(p + "0.fn.to_qkv.weight") + (size_t)2 * INNER * E, E, nullptr, nullptr, 0, dv, INNER, B, INNER, E);
+            LAUNCH_OK(launch_gemm_skinny(a, EPI_NONE, st));
+        }
+        {
+            GemmArgs a = mk(dv, INNER, e->W(p + "0.fn.to_out.0.weight"), INNER, e->W(p + "0.fn.to_out.0.bias"), dx, E, dx, E, B, E, INNER);
+            LAUNCH_OK(launch_gemm_skinny(a, EPI_BIAS_RESID, st));
+        }
+        // cross-attention (pose_transformer.py:111-124)
+        LAUNCH_OK(launch_layernorm(dx, e->W(p + "1.norm.weight"), e->W(p + "1.norm.bias"), dh, B, E, LN_EPS, 0, st));
+        {
+            GemmArgs a = mk(dh, E, e->W(p + "1.fn.to_q.weight"), E, nullptr, nullptr, 0, dq, INNER, B, INNER, E);
+            LAUNCH_OK(launch_gemm_skinny(a, EPI_NONE, st));
+        }
+        LAUNCH_OK(launch_cross_attn(dq, big, ldkv, l * 2 * INNER, dca, B, st));
+        {
+            GemmArgs a = mk(dca, INNER, e->W(p + "1.fn.to_out.0.weight"), INNER, e->W(p + "1.fn.to_out.0.bias"), dx, E, dx, E, B, E, INNER);
+            LAUNCH_OK(launch_gemm_skinny(a, EPI_BIAS_RESID, st));
+        }
+        // feed-forward (pose_transformer.py:40-52)
+        LAUNCH_OK(launch_layernorm(dx, e->W(p + "2.norm.weight"), e->W(p + "2.norm.bias"), dh, B, E, LN_EPS, 0, st));
+        {
+            GemmArgs a = mk(dh, E, e->W(p + "2.fn.net.0.weight"), E, e->W(p + "2.fn.net.0.bias"), nullptr, 0, dff, DEC_MLP, B, DEC_MLP, E);
+            LAUNCH_OK(launch_gemm_skinny(a, EPI_BIAS_GELU, st));
+        }
+        {
+            GemmArgs a = mk(dff, DEC_MLP, e->W(p + "2.fn.net.3.weight"), DEC_MLP, e->W(p + "2.fn.net.3.bias"), dx, E, dx, E, B, E, DEC_MLP);
+            LAUNCH_OK(launch_gemm_skinny(a, EPI_BIAS_RESID, st));
+        }
+    }
+    if (out && out->token_out) HIP_OK(hipMemcpyAsync(out->token_out, dx, sizeof(float) * B * E, hipMemcpyDeviceToDevice, st));
+
+    // read-outs: one (31,1024) GEMV-class GEMM (token_head.py:99-105)
+    float* ro = e->S(so.ro);
+    {
+        GemmArgs a = mk(dx, E, e->warena + e->o_ro_w, E, e->warena + e->o_ro_b, nullptr, 0, ro, 32, B, 31, E);
+        LAUNCH_OK(launch_gemm_skinny(a, EPI_BIAS, st));
+    }
+    // token classifier (token_classifier.py:89-104)
+    const std::string C = "smpl_head.decpose.";
+    float *mt = e->S(so.mt), *cf = e->S(so.cf), *cf2 = e->S(so.cf2);
+    {
+        GemmArgs a = mk(dx, E, e->W(C + "mixer_trans.ff.0.weight"), E, e->W(C + "mixer_trans.ff.0.bias"), nullptr, 0, mt, TN * HID, B, TN * HID, E);
+        LAUNCH_OK(launch_gemm_skinny(a, EPI_BIAS, st));
+    }
+    LAUNCH_OK(launch_layernorm(mt, e->W(C + "mixer_trans.ff.1.weight"), e->W(C + "mixer_trans.ff.1.bias"), cf, B, TN * HID, LN_EPS, 1, st));
+    const int R = B * TN;
+    for (int m = 0; m < MIX; ++m) {   // MixerLayer, heads/modules.py:55-63
+        const std::string p = C + "mixer_head." + std::to_string(m) + ".";
+        float *y1 = e->S(so.y1), *tT = e->S(so.tT), *u = e->S(so.u), *yt = e->S(so.yt), *y = e->S(so.y), *s = e->S(so.s),
+              *z0 = e->S(so.z0), *zh = e->S(so.zh);
+        LAUNCH_OK(launch_layernorm(cf, e->W(p + "layernorm1.weight"), e->W(p + "layernorm1.bias"), y1, R, HID, LN_EPS, 0, st));
+        LAUNCH_OK(launch_transpose(y1, tT, B, TN, HID, st));                                   // (B,160,64)->(B,64,160)
+        {
+            GemmArgs a = mk(tT, TN, e->W(p + "MLP_token.ff.0.weight"), TN, e->W(p + "MLP_token.ff.0.bias"), nullptr, 0, u, TOK_INTER, B * HID, TOK_INTER, TN);
+            LAUNCH_OK(launch_gemm(a, EPI_BIAS_GELU, 0, st));
+        }
+        {
+            GemmArgs a = mk(u, TOK_INTER, e->W(p + "MLP_token.ff.3.weight"), TOK_INTER, e->W(p + "MLP_token.ff.3.bias"), nullptr, 0, yt, TN, B * HID, TN, TOK_INTER);
+            LAUNCH_OK(launch_gemm(a, EPI_BIAS, 0, st));
+        }
+        LAUNCH_OK(launch_transpose(yt, y, B, HID, TN, st));                                    // (B,64,160)->(B,160,64)
+        LAUNCH_OK(launch_add_ln64(cf, y, e->W(p + "layernorm2.weight"), e->W(p + "layernorm2.bias"), s, z0, R, LN_EPS, st));
+        {
+            GemmArgs a = mk(z0, HID, e->W(p + "MLP_channel.ff.0.weight"), HID, e->W(p + "MLP_channel.ff.0.bias"), nullptr, 0, zh, HID_INTER, R, HID_INTER, HID);
+            LAUNCH_OK(launch_gemm(a, EPI_BIAS_GELU, 0, st));
+        }
+        {   // out = (x + y) + z
+            GemmArgs a = mk(zh, HID_INTER, e->W(p + "MLP_channel.ff.3.weight"), HID_INTER, e->W(p + "MLP_channel.ff.3.bias"), s, HID, cf2, HID, R, HID, HID_INTER);
+            LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, 0, st));
+        }
+        std::swap(cf, cf2);
+    }
+    float *nl = e->S(so.nl), *nl2 = e->S(so.nl2);
+    {
+        GemmArgs a = mk(cf, HID, e->W(C + "mixer_norm_layer.ff.0.weight"), HID, e->W(C + "mixer_norm_layer.ff.0.bias"), nullptr, 0, nl, HID, R, HID, HID);
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS, 0, st));
+    }
+    LAUNCH_OK(launch_layernorm(nl, e->W(C + "mixer_norm_layer.ff.1.weight"), e->W(C + "mixer_norm_layer.ff.1.bias"), nl2, R, HID, LN_EPS, 1, st));
+    // logits / softmax / token index; KV in `big` is dead after the decoder, so logits+probs live there
+    float* logits = (out && out->cls_logits) ? out->cls_logits : big;
+    float* probs = (out && out->cls_logits_softmax) ? out->cls_logits_softmax : big + (size_t)R * NCLS;
+    int32_t* tokidx = (out && out->token_idx) ? out->token_idx : reinterpret_cast<int32_t*>(e->S(so.tokidx));
+    {
+        GemmArgs a = mk(nl2, HID, e->W(C + "class_pred_layer.weight"), HID, e->W(C + "class_pred_layer.bias"), nullptr, 0, logits, NCLS, R, NCLS, HID);
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS, 0, st));
+    }
+    LAUNCH_OK(launch_softmax_argmax2048(logits, probs, tokidx, R, st));
+    // soft codebook lookup: probs @ codebook (quantize_cnn.py:92-93) as a GEMM against codebook^T
+    float* feat = e->S(so.feat);
+    {
+        GemmArgs a = mk(probs, NCLS, e->warena + e->o_cbT, NCLS, nullptr, nullptr, 0, feat, CODE, R, CODE, NCLS);
+        LAUNCH_OK(launch_gemm(a, EPI_NONE, 0, st));
+    }
+    // VQ decoder (vanilla_pose_vqvae.py:135-154), channels-last (B,T,C)
+    float *a0 = e->S(so.act0), *a1 = e->S(so.act1), *a2 = e->S(so.act2);
+    const int32_t* idxt = reinterpret_cast<const int32_t*>(e->warena + e->o_idx);
+    const std::string d = "decoder.decoder.";
+    if (int r = conv3(e, 0, feat, 160, 160, nullptr, 1, 0, e->W(d + "0.bias"), EPI_BIAS_RELU, nullptr, a0, B, st)) return r;
+    const char* up_bias[] = {"3.bias", "6.bias", "9.bias", "12.bias"};
+    float* cur = a0;
+    float* nxt = a1;
+    for (int i = 0; i < 4; ++i) {
+        if (int r = conv3(e, 1 + i, cur, e->vq_len[i], e->vq_len[i + 1], idxt + i * 160, 1, 0, e->W(d + up_bias[i]),
+                          EPI_BIAS_RELU, nullptr, nxt, B, st)) return r;
+        std::swap(cur, nxt);
+    }
+    const int Tq = VQJ;
+    for (int blk = 0; blk < 2; ++blk) {   // ResConv1DBlock, resnet.py:49-69 (dilation 3 then 1)
+        const std::string p = d + "14.0.model." + std::to_string(blk) + ".";
+        const int dil = blk == 0 ? 3 : 1;
+        if (int r = conv3(e, 5 + blk, cur, Tq, Tq, nullptr, dil, 1, e->W(p + "conv1.bias"), EPI_BIAS_RELU, nullptr, a2, B, st)) return r;
+        GemmArgs a = mk(a2, VQW, e->W(p + "conv2.weight"), VQW, e->W(p + "conv2.bias"), cur, VQW, nxt, VQW, B * Tq, VQW, VQW);
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, 0, st));
+        std::swap(cur, nxt);
+    }
+    if (int r = conv3(e, 7, cur, Tq, Tq, nullptr, 1, 0, e->W(d + "14.1.bias"), EPI_BIAS, nullptr, nxt, B, st)) return r;
+    float* bpose = e->S(so.bpose);
+    if (int r = conv3(e, 8, nxt, Tq, Tq, nullptr, 1, 0, e->W(d + "15.bias"), EPI_BIAS, nullptr, bpose, B, st)) return r;
+    // assemble + rot6d + camera (token_head.py:103-127, tokenhmr.py:165-169)
+    float* rot = (out && out->rotmat) ? out->rotmat : e->S(so.rot);
+    float* betas = (out && out->betas) ? out->betas : e->S(so.betas);
+    float* cam = (out && out->pred_cam) ? out->pred_cam : e->S(so.cam);
+    float* camt = (out && out->pred_cam_t) ? out->pred_cam_t : e->S(so.camt);
+    LAUNCH_OK(launch_assemble(ro, 32, bpose, e->W("smpl_head.init_body_pose"), e->W("smpl_head.init_betas"),
+                              e->W("smpl_head.init_cam"), out ? out->pose6d : nullptr, rot, betas, cam, camt,
+                              out ? out->focal_length : nullptr, FOCAL, IMG, B, st));
+    return 0;
+}
+
+int lbs(thmr_engine* e, const float* rot, const float* betas, const float* camt, int B, float* verts, float* joints,
+        float* kp2d, hipStream_t st) {
+    auto& so = e->so;
+    ProfScope ps(e, st, THMR_PROF_LBS, 2.0 * B * 8.1e6, 4.0 * (B * (NV * 3.0 + 132 + 226) + 4.95e6));
+    const int32_t* ints = reinterpret_cast<const int32_t*>(e->warena + e->o_smpl_int);
+    if (!verts) verts = e->S(so.verts);
+    LAUNCH_OK(launch_lbs(rot, betas, camt, e->warena + e->o_smpl_jt, e->warena + e->o_smpl_jsd, ints,
+                         e->warena + e->o_smpl_vt, e->warena + e->o_smpl_sd, e->warena + e->o_smpl_pd,
+                         e->warena + e->o_smpl_w, e->warena + e->o_smpl_j19, ints + 24, ints + 48, e->S(so.A), e->S(so.pf),
+                         e->S(so.Jtr), verts, joints, kp2d, FOCAL / IMG, B, st));
+    return 0;
+}
+
+int check_ready(thmr_engine* e, int B) {
+    if (!e) return fail(nullptr, THMR_ERR_INVALID, "null engine");
+    if (!e->finalized) return fail(e, THMR_ERR_STATE, "weights not finalized: call thmr_finalize_weights first");
+    if (B < 1 || B > e->max_batch) return fail(e, THMR_ERR_INVALID, "batch " + std::to_string(B) + " outside [1, max_batch=" + std::to_string(e->max_batch) + "]");
+    return 0;
+}
+
+}  // namespace
+
+// =============================================================================================== C ABI
+extern "C" {
+
+int thmr_abi_version(void) { return THMR_ABI_VERSION; }
+const char* thmr_build_info(void) { return "tokenhmr_hip gfx950 fp32-mfma " __DATE__ " " __TIME__; }
+
+const char* thmr_last_error(const thmr_engine* e) { return e ? e->err.c_str() : g_last_error.c_str(); }
+
+static int validate_cfg(const thmr_config* cfg) {
+    if (!cfg) return fail(nullptr, THMR_ERR_INVALID, "null config");
+    if (cfg->abi_version != THMR_ABI_VERSION) return fail(nullptr, THMR_ERR_INVALID, "abi_version mismatch");
+    if (cfg->vit_depth < 1 || cfg->vit_depth > 64 || cfg->dec_depth < 1 || cfg->dec_depth > 6 || cfg->max_batch < 1 ||
+        cfg->max_batch > 4096)
+        return fail(nullptr, THMR_ERR_INVALID, "config out of range (vit_depth 1..64, dec_depth 1..6, max_batch 1..4096)");
+    return 0;
+}
+
+int thmr_arena_bytes(const thmr_config* cfg, size_t* weight_bytes, size_t* scratch_bytes) {
+    if (int r = validate_cfg(cfg)) return r;
+    thmr_engine tmp;
+    tmp.vit_depth = cfg->vit_depth; tmp.dec_depth = cfg->dec_depth; tmp.max_batch = cfg->max_batch;
+    layout_weights(&tmp);
+    layout_scratch(&tmp);
+    if (weight_bytes) *weight_bytes = tmp.wfloats * sizeof(float);
+    if (scratch_bytes) *scratch_bytes = tmp.sfloats * sizeof(float);
+    return 0;
+}
+
+int thmr_spec(const thmr_config* cfg, int32_t index, const char** name, int64_t* numel) {
+    if (int r = validate_cfg(cfg)) return r;
+    static thread_local std::vector<std::pair<std::string, int64_t>> spec;
+    spec.clear();
+    build_spec(cfg->vit_depth, cfg->dec_depth, spec);
+    if (index >= 0 && index < (int32_t)spec.size()) {
+        if (name) *name = spec[index].first.c_str();
+        if (numel) *numel = spec[index].second;
+    }
+    return (int)spec.size();
+}
+
+int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_arena_dev, thmr_engine** out) {
+    if (!out) return fail(nullptr, THMR_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (int r = validate_cfg(cfg)) return r;
+    thmr_engine* e = new thmr_engine();
+    e->cfg = *cfg;
+    e->vit_depth = cfg->vit_depth; e->dec_depth = cfg->dec_depth; e->max_batch = cfg->max_batch;
+    layout_weights(e);
+    layout_scratch(e);
+    auto bail = [&](int code, const std::string& m) { fail(nullptr, code, m); thmr_destroy(e); return code; };
+    if (hipSetDevice(cfg->device) != hipSuccess) return bail(THMR_ERR_HIP, "hipSetDevice failed");
+    if (weight_arena_dev) e->warena = static_cast<float*>(weight_arena_dev);
+    else {
+        if (hipMalloc(&e->warena, e->wfloats * sizeof(float)) != hipSuccess) return bail(THMR_ERR_NOMEM, "hipMalloc(weights) failed");
+        e->own_w = true;
+    }
+    if (scratch_arena_dev) e->sarena = static_cast<float*>(scratch_arena_dev);
+    else {
+        if (hipMalloc(&e->sarena, e->sfloats * sizeof(float)) != hipSuccess) return bail(THMR_ERR_NOMEM, "hipMalloc(scratch) failed");
+        e->own_s = true;
+    }
+    // nn.Upsample(size) nearest index tables, evaluated in fp32 exactly like ATen
+    // (nearest_neighbor_compute_source_index: min(floor(dst * (float)in / out), in - 1))
+    std::vector<int32_t> idx(4 * 160, 0);
+    for (int i = 0; i < 4; ++i) {
+        const int tin = e->vq_len[i], tout = e->vq_len[i + 1];
+        const float scale = (float)tin / (float)tout;
+        for (int t = 0; t < tout; ++t) {
+            int sidx = (int)floorf((float)t * scale);
+            idx[i * 160 + t] = sidx < tin - 1 ? sidx : tin - 1;
+        }
+    }
+    if (hipMemcpy(e->warena + e->o_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(THMR_ERR_HIP, "hipMemcpy(idx tables) failed");
+    // the padding row of the read-out matrix must be finite
+    if (hipMemset(e->warena + e->o_ro_w, 0, 32 * E * sizeof(float)) != hipSuccess) return bail(THMR_ERR_HIP, "hipMemset failed");
+    *out = e;
+    return 0;
+}
+
+void thmr_destroy(thmr_engine* e) {
+    if (!e) return;
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->own_w && e->warena) (void)hipFree(e->warena);
+    if (e->own_s && e->sarena) (void)hipFree(e->sarena);
+    delete e;
+}
+
+int thmr_load_weights(thmr_engine* e, const thmr_tensor_desc* t, size_t n, void* stream) {
+    if (!e || (!t && n)) return fail(e, THMR_ERR_INVALID, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (size_t i = 0; i < n; ++i) {
+        if (!t[i].name || !t[i].data) return fail(e, THMR_ERR_INVALID, "tensor desc with null name/data");
+        auto it = e->slots.find(t[i].name);
+        if (it == e->slots.end()) return fail(e, THMR_ERR_INVALID, std::string("unexpected tensor '") + t[i].name + "' (strict load)");
+        if (it->second.numel != t[i].numel)
+            return fail(e, THMR_ERR_INVALID, std::string("tensor '") + t[i].name + "': expected " + std::to_string(it->second.numel) +
+                                                 " elements, got " + std::to_string(t[i].numel));
+        HIP_OK(hipMemcpyAsync(e->warena + it->second.off, t[i].data, sizeof(float) * t[i].numel,
+                              t[i].on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        it->second.loaded = true;
+    }
+    e->finalized = false;
+    return 0;
+}
+
+int thmr_load_smpl(thmr_engine* e, const thmr_smpl_desc* s, void* stream) {
+    if (!e || !s) return fail(e, THMR_ERR_INVALID, "null argument");
+    if (!s->v_template || !s->shapedirs || !s->posedirs || !s->J_regressor || !s->lbs_weights || !s->J19_regressor ||
+        !s->parents || !s->extra_verts || !s->joint_map)
+        return fail(e, THMR_ERR_INVALID, "thmr_smpl_desc has a null field");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const hipMemcpyKind k = s->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    HIP_OK(hipMemcpyAsync(e->warena + e->o_smpl_vt, s->v_template, sizeof(float) * NV * 3, k, st));
+    HIP_OK(hipMemcpyAsync(e->warena + e->o_smpl_sd, s->shapedirs, sizeof(float) * NV * 30, k, st));
+    HIP_OK(hipMemcpyAsync(e->warena + e->o_smpl_pd, s->posedirs, sizeof(float) * (size_t)NP * NV * 3, k, st));
+    HIP_OK(hipMemcpyAsync(e->warena + e->o_smpl_jr, s->J_regressor, sizeof(float) * NJ * NV, k, st));
+    HIP_OK(hipMemcpyAsync(e->warena + e->o_smpl_w, s->lbs_weights, sizeof(float) * NV * NJ, k, st));
+    HIP_OK(hipMemcpyAsync(e->warena + e->o_smpl_j19, s->J19_regressor, sizeof(float) * 19 * NV, k, st));
+    int32_t* ints = reinterpret_cast<int32_t*>(e->warena + e->o_smpl_int);
+    HIP_OK(hipMemcpyAsync(ints, s->parents, sizeof(int32_t) * 24, k, st));
+    HIP_OK(hipMemcpyAsync(ints + 24, s->extra_verts, sizeof(int32_t) * 21, k, st));
+    HIP_OK(hipMemcpyAsync(ints + 48, s->joint_map, sizeof(int32_t) * 25, k, st));
+    e->smpl_loaded = true;
+    e->finalized = false;
+    return 0;
+}
+
+int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* stream) {
+    if (!e) return fail(e, THMR_ERR_INVALID, "null engine");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!assume_all_loaded) {
+        for (auto& n : e->required)
+            if (!e->slots[n].loaded) return fail(e, THMR_ERR_STATE, "missing tensor '" + n + "' (strict load)");
+        if (!e->smpl_loaded) return fail(e, THMR_ERR_STATE, "SMPL constants not loaded (thmr_load_smpl)");
+    }
+    for (int i = 0; i < 9; ++i)
+        LAUNCH_OK(launch_conv_repack(e->W(std::string(kConv3[i]) + ".weight"), e->warena + e->convp[i], kConv3Co[i], kConv3Ci[i], 3, st));
+    LAUNCH_OK(launch_transpose(e->W("quantizer.codebook"), e->warena + e->o_cbT, 1, NCLS, CODE, st));
+    LAUNCH_OK(launch_code_norm(e->W("quantizer.codebook"), e->warena + e->o_cnorm, NCLS, st));
+    LAUNCH_OK(launch_lbs_jreg(e->warena + e->o_smpl_jr, e->warena + e->o_smpl_vt, e->warena + e->o_smpl_sd,
+                              e->warena + e->o_smpl_jt, e->warena + e->o_smpl_jsd, st));
+    e->finalized = true;
+    return 0;
+}
+
+int thmr_weight_arena(thmr_engine* e, void** ptr_dev, size_t* bytes) {
+    if (!e) return fail(e, THMR_ERR_INVALID, "null engine");
+    if (ptr_dev) *ptr_dev = e->warena;
+    if (bytes) *bytes = e->wfloats * sizeof(float);
+    return 0;
+}
+
+int thmr_vit_forward(thmr_engine* e, const float* img_dev, int32_t B, float* feats_dev, void* stream) {
+    if (int r = check_ready(e, B)) return r;
+    if (!img_dev || !feats_dev) return fail(e, THMR_ERR_INVALID, "null buffer");
+    return vit_forward(e, img_dev, B, feats_dev, static_cast<hipStream_t>(stream));
+}
+
+int thmr_head_forward(thmr_engine* e, const float* ctx_dev, int32_t B, const thmr_outputs* out, void* stream) {
+    if (int r = check_ready(e, B)) return r;
+    if (!ctx_dev) return fail(e, THMR_ERR_INVALID, "null buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int r = head_forward(e, ctx_dev, B, out, st)) return r;
+    if (out && (out->pred_vertices || out->pred_keypoints_3d || out->pred_keypoints_2d)) {
+        const float* rot = out->rotmat ? out->rotmat : e->S(e->so.rot);
+        const float* betas = out->betas ? out->betas : e->S(e->so.betas);
+        const float* camt = out->pred_cam_t ? out->pred_cam_t : e->S(e->so.camt);
+        return lbs(e, rot, betas, camt, B, out->pred_vertices, out->pred_keypoints_3d, out->pred_keypoints_2d, st);
+    }
+    return 0;
+}
+
+int thmr_forward(thmr_engine* e, const float* img_dev, int32_t B, const thmr_outputs* out, void* stream) {
+    if (int r = check_ready(e, B)) return r;
+    if (!img_dev || !out) return fail(e, THMR_ERR_INVALID, "null buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* ctx = e->S(e->so.h);
+    if (int r = vit_forward(e, img_dev, B, nullptr, st)) return r;
+    if (out->vit_features)
+        HIP_OK(hipMemcpyAsync(out->vit_features, ctx, sizeof(float) * (size_t)B * TOK * DIM, hipMemcpyDeviceToDevice, st));
+    if (int r = head_forward(e, ctx, B, out, st)) return r;
+    const float* rot = out->rotmat ? out->rotmat : e->S(e->so.rot);
+    const float* betas = out->betas ? out->betas : e->S(e->so.betas);
+    const float* camt = out->pred_cam_t ? out->pred_cam_t : e->S(e->so.camt);
+    return lbs(e, rot, betas, camt, B, out->pred_vertices, out->pred_keypoints_3d, out->pred_keypoints_2d, st);
+}
+
+int thmr_lbs_forward(thmr_engine* e, const float* rotmat_dev, const float* betas_dev, const float* cam_dev, int32_t B,
+                     float* verts_dev, float* joints_dev, float* cam_t_dev, float* kp2d_dev, void* stream) {
+    if (int r = check_ready(e, B)) return r;
+    if (!rotmat_dev || !betas_dev) return fail(e, THMR_ERR_INVALID, "null buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float* camt = nullptr;
+    if (cam_dev) {
+        float* ct = cam_t_dev ? cam_t_dev : e->S(e->so.camt);
+        LAUNCH_OK(launch_cam_t(cam_dev, ct, FOCAL, IMG, B, st));
+        camt = ct;
+    }
+    return lbs(e, rotmat_dev, betas_dev, camt, B, verts_dev, joints_dev, camt ? kp2d_dev : nullptr, st);
+}
+
+int thmr_vq_argmin(thmr_engine* e, const float* x_dev, int32_t rows, int32_t* idx_dev, float* dist_dev, void* stream) {
+    if (!e) return fail(e, THMR_ERR_INVALID, "null engine");
+    if (!e->finalized) return fail(e, THMR_ERR_STATE, "weights not finalized");
+    if (!x_dev || !idx_dev || rows < 1) return fail(e, THMR_ERR_INVALID, "bad argument");
+    if ((size_t)rows * NCLS > (size_t)e->max_batch * TOK * 6144) return fail(e, THMR_ERR_INVALID, "rows exceed scratch capacity");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* dot = e->S(e->so.big);
+    GemmArgs a = mk(x_dev, CODE, e->W("quantizer.codebook"), CODE, nullptr, nullptr, 0, dot, NCLS, rows, NCLS, CODE);
+    LAUNCH_OK(launch_gemm(a, EPI_NONE, 0, st));
+    LAUNCH_OK(launch_vq_argmin_rows(x_dev, dot, e->warena + e->o_cnorm, idx_dev, dist_dev, rows, st));
+    return 0;
+}
+
+// ---- stateless operator entry points ----
+int thmr_op_gemm(const float* A, int64_t lda, const float* W, const float* bias, const float* resid, float* C, int64_t ldc,
+                 int32_t M, int32_t N, int32_t K, int32_t epi, float qscale, int32_t qcols, int32_t variant, void* stream) {
+    thmr_engine* e = nullptr;
+    if (!A || !W || !C) return fail(e, THMR_ERR_INVALID, "null buffer");
+    if (epi < 0 || epi >= EPI_NUM) return fail(e, THMR_ERR_INVALID, "bad epilogue id");
+    if (epi != EPI_NONE && !bias) return fail(e, THMR_ERR_INVALID, "epilogue needs bias");
+    if ((epi == EPI_BIAS_RESID || epi == EPI_BIAS_POS) && !resid) return fail(e, THMR_ERR_INVALID, "epilogue needs resid");
+    GemmArgs a = mk(A, lda, W, K, bias, resid, ldc, C, ldc, M, N, K);
+    a.qscale = qscale; a.qcols = qcols;
+    if (variant == 2) { LAUNCH_OK(launch_gemm_skinny(a, epi, static_cast<hipStream_t>(stream))); }
+    else { LAUNCH_OK(launch_gemm(a, epi, variant, static_cast<hipStream_t>(stream))); }
+    return 0;
+}
+
+int thmr_op_layernorm(const float* x, const float* g, const float* b, float* y, int32_t rows, int32_t D, float eps,
+                      int32_t relu, void* stream) {
+    thmr_engine* e = nullptr;
+    if (!x || !g || !b || !y) return fail(e, THMR_ERR_INVALID, "null buffer");
+    LAUNCH_OK(launch_layernorm(x, g, b, y, rows, D, eps, relu, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int thmr_op_vit_attention(const float* qkv, float* out, int32_t B, void* stream) {
+    thmr_engine* e = nullptr;
+    if (!qkv || !out) return fail(e, THMR_ERR_INVALID, "null buffer");
+    LAUNCH_OK(launch_vit_attention(qkv, out, B, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int thmr_op_rot6d(const float* x, float* R, int32_t n, void* stream) {
+    thmr_engine* e = nullptr;
+    if (!x || !R || n < 1) return fail(e, THMR_ERR_INVALID, "bad argument");
+    LAUNCH_OK(launch_rot6d(x, R, n, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+// ---- profiler ----
+int thmr_prof_enable(thmr_engine* e, int32_t on) {
+    if (!e) return fail(e, THMR_ERR_INVALID, "null engine");
+    e->prof_on = on != 0;
+    return 0;
+}
+
+int thmr_prof_collect(thmr_engine* e, thmr_prof_entry* entries, int32_t reset) {
+    if (!e || !entries) return fail(e, THMR_ERR_INVALID, "null argument");
+    for (int i = 0; i < THMR_PROF_NUM; ++i) entries[i] = thmr_prof_entry{0, 0, 0, 0};
+    for (auto& r : e->prof) {
+        HIP_OK(hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        entries[r.cls].ms += ms;
+        entries[r.cls].flops += r.flops;
+        entries[r.cls].bytes += r.bytes;
+        entries[r.cls].launches += 1;
+    }
+    if (reset) { e->prof.clear(); e->ev_next = 0; }
+    return 0;
+}
+
+}  // extern "C"

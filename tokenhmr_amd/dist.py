@@ -1,0 +1,106 @@
+"""Data-parallel inference across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The reference has no collective on this path (inference is single-device, eval.py:52-54); crops are
+independent units (no BatchNorm at inference), so the path shards with NO data-path collective:
+rank r takes crops [r*B/N, (r+1)*B/N).  Two collectives exist around it:
+  * start-up: ONE broadcast of the packed weight arena (≈2.6 GB fp32) from rank 0, so only rank 0
+    reads the checkpoint;
+  * per batch (optional): ONE all-gather of a packed per-crop record (≈85 KB/crop: verts, joints,
+    kp2d, rotmats, betas, cam, cam_t, token indices) instead of one collective per tensor — the
+    gather is latency-bound on xGMI, so a single fused message is the right shape.
+Works with backend 'nccl' (= RCCL on ROCm) on GPUs and 'gloo' on CPU tensors (tests).
+"""
+import torch
+import torch.distributed as dist
+
+# packed per-crop record layout (float32 words); token_idx is stored bit-exactly via view(int32)
+RECORD_FIELDS = [
+    ("pred_vertices", 6890 * 3), ("pred_keypoints_3d", 44 * 3), ("pred_keypoints_2d", 44 * 2),
+    ("rotmat", 24 * 9), ("betas", 10), ("pred_cam", 3), ("pred_cam_t", 3), ("token_idx", 160),
+]
+RECORD_WORDS = sum(n for _, n in RECORD_FIELDS)
+
+
+def shard_range(total: int, world: int, rank: int):
+    """Contiguous, balanced split: the first (total % world) ranks get one extra crop."""
+    base, rem = divmod(total, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def shard_sizes(total: int, world: int):
+    return [shard_range(total, world, r)[1] - shard_range(total, world, r)[0] for r in range(world)]
+
+
+def pack_records(o):
+    """dict of per-crop tensors (engine output) -> (B, RECORD_WORDS) float32."""
+    B = o["pred_cam"].shape[0]
+    parts = []
+    for name, n in RECORD_FIELDS:
+        t = o[name]
+        if name == "token_idx":
+            t = t.contiguous().view(torch.float32)
+        parts.append(t.reshape(B, n))
+    return torch.cat(parts, dim=1).contiguous()
+
+
+def unpack_records(rec):
+    B = rec.shape[0]
+    shapes = {"pred_vertices": (6890, 3), "pred_keypoints_3d": (44, 3), "pred_keypoints_2d": (44, 2),
+              "rotmat": (24, 3, 3), "betas": (10,), "pred_cam": (3,), "pred_cam_t": (3,), "token_idx": (160,)}
+    out, off = {}, 0
+    for name, n in RECORD_FIELDS:
+        t = rec[:, off:off + n]
+        off += n
+        if name == "token_idx":
+            t = t.contiguous().view(torch.int32)
+        out[name] = t.reshape(B, *shapes[name])
+    return out
+
+
+def broadcast_weights(engine, src: int = 0):
+    """ONE collective for the whole model: rank `src` has loaded the checkpoint; everyone else
+    receives the packed arena and only has to finalize."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(engine.weight_arena, src=src)
+
+
+def all_gather_records(local_rec, total: int):
+    """All-gather the packed records of every rank's shard; returns (total, RECORD_WORDS) in crop order.
+    Shards may differ by one crop, so each rank pads to the maximum shard size."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return local_rec
+    world = dist.get_world_size()
+    sizes = shard_sizes(total, world)
+    mx = max(sizes)
+    pad = local_rec
+    if local_rec.shape[0] < mx:
+        pad = torch.zeros(mx, local_rec.shape[1], dtype=local_rec.dtype, device=local_rec.device)
+        pad[: local_rec.shape[0]] = local_rec
+    buf = torch.empty(world * mx, local_rec.shape[1], dtype=local_rec.dtype, device=local_rec.device)
+    dist.all_gather_into_tensor(buf, pad.contiguous())
+    chunks = [buf[r * mx: r * mx + sizes[r]] for r in range(world)]
+    return torch.cat(chunks, dim=0)
+
+
+class ShardedRunner:
+    """Runs `forward_fn(img_shard) -> engine-output dict` on this rank's shard of a global batch and
+    (optionally) all-gathers the packed records so every rank sees all crops."""
+
+    def __init__(self, forward_fn, gather: bool = True):
+        self.forward_fn = forward_fn
+        self.gather = gather
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+
+    def local_slice(self, total):
+        return shard_range(total, self.world, self.rank)
+
+    def __call__(self, img_global):
+        total = img_global.shape[0]
+        s, e = self.local_slice(total)
+        o = self.forward_fn(img_global[s:e])
+        rec = pack_records(o)
+        if not self.gather:
+            return unpack_records(rec)
+        return unpack_records(all_gather_records(rec, total))

@@ -1,0 +1,196 @@
+"""Python handle on the C-ABI engine (include/tokenhmr_hip.h).  torch is used only for device
+memory (arenas, I/O tensors), the current stream and torch.distributed — never for compute."""
+import ctypes as C
+
+import torch
+
+from . import _cabi
+from .config import HMRConfig, RELEASE
+from . import weights as W
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+    """One engine per GPU.  The weight arena is a torch uint8 tensor so that
+    torch.distributed.broadcast (RCCL) can replicate it across ranks."""
+
+    def __init__(self, cfg: HMRConfig = RELEASE, max_batch: int = 64, device="cuda:0"):
+        self.lib = _cabi.load()
+        self.cfg = cfg
+        self.max_batch = int(max_batch)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _cabi.EngineError("tokenhmr_amd runs on a HIP device only (no CPU fallback)")
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        self._ccfg = _cabi.Config(abi_version=_cabi.ABI_VERSION, vit_depth=cfg.vit_depth, dec_depth=cfg.dec_depth,
+                                  max_batch=self.max_batch, device=idx)
+        wb, sb = C.c_size_t(0), C.c_size_t(0)
+        _cabi.check(self.lib.thmr_arena_bytes(C.byref(self._ccfg), C.byref(wb), C.byref(sb)))
+        self.weight_bytes, self.scratch_bytes = wb.value, sb.value
+        with torch.cuda.device(self.device):
+            self.weight_arena = torch.empty(self.weight_bytes, dtype=torch.uint8, device=self.device)
+            self.scratch_arena = torch.empty(self.scratch_bytes, dtype=torch.uint8, device=self.device)
+            h = C.c_void_p(0)
+            _cabi.check(self.lib.thmr_create(C.byref(self._ccfg), _ptr(self.weight_arena), _ptr(self.scratch_arena),
+                                             C.byref(h)))
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.thmr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_state(self, state, tokenizer=None):
+        """state: TokenHMR state_dict ('backbone.*','smpl_head.*'); tokenizer: tokenizer 'net' dict.
+        Host or device fp32 tensors in the reference layouts (strict: missing/unknown keys raise)."""
+        items = list(state.items()) + (list(tokenizer.items()) if tokenizer else [])
+        wanted = {n for n, *_ in W.spec(self.cfg)} | {n for n, *_ in W.tokenizer_spec(self.cfg)}
+        descs, keep = [], []
+        for name, t in items:
+            if name not in wanted:
+                if name.startswith(("encoder.", "body_model", "decoder.body_model")):
+                    continue   # filtered by the reference too (vanilla_pose_vqvae.py:24-40)
+                raise KeyError(f"unexpected tensor '{name}' (strict load)")
+            t = t.detach()
+            if t.dtype != torch.float32:
+                t = t.float()
+            t = t.contiguous()
+            keep.append(t)
+            descs.append(_cabi.TensorDesc(name=name.encode(), data=t.data_ptr(), numel=t.numel(),
+                                          on_device=1 if t.is_cuda else 0))
+        arr = (_cabi.TensorDesc * len(descs))(*descs)
+        with torch.cuda.device(self.device):
+            _cabi.check(self.lib.thmr_load_weights(self.h, arr, len(descs), _stream_ptr(self.device)), self.h)
+            torch.cuda.current_stream(self.device).synchronize()   # host staging tensors may now be freed
+
+    def load_smpl(self, smpl):
+        keys = ["v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "J19_regressor"]
+        ikeys = ["parents", "extra_verts", "joint_map"]
+        ts = {k: smpl[k].detach().float().contiguous().cpu() for k in keys}
+        ts.update({k: smpl[k].detach().to(torch.int32).contiguous().cpu() for k in ikeys})
+        shapes = {"v_template": (6890, 3), "shapedirs": (6890, 3, 10), "posedirs": (207, 20670),
+                  "J_regressor": (24, 6890), "lbs_weights": (6890, 24), "J19_regressor": (19, 6890),
+                  "parents": (24,), "extra_verts": (21,), "joint_map": (25,)}
+        for k, s in shapes.items():
+            if tuple(ts[k].shape) != s:
+                raise ValueError(f"SMPL '{k}': expected {s}, got {tuple(ts[k].shape)}")
+        d = _cabi.SmplDesc(**{k: ts[k].data_ptr() for k in keys + ikeys}, on_device=0)
+        with torch.cuda.device(self.device):
+            _cabi.check(self.lib.thmr_load_smpl(self.h, C.byref(d), _stream_ptr(self.device)), self.h)
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def finalize(self, assume_all_loaded=False):
+        with torch.cuda.device(self.device):
+            _cabi.check(self.lib.thmr_finalize_weights(self.h, 1 if assume_all_loaded else 0, _stream_ptr(self.device)), self.h)
+
+    # ------------------------------------------------------------------ forward
+    def _alloc_outputs(self, B, taps=False, want_probs=True):
+        dev, f32 = self.device, torch.float32
+        o = {
+            "pred_cam": torch.empty(B, 3, device=dev, dtype=f32),
+            "rotmat": torch.empty(B, 24, 3, 3, device=dev, dtype=f32),
+            "betas": torch.empty(B, 10, device=dev, dtype=f32),
+            "pred_cam_t": torch.empty(B, 3, device=dev, dtype=f32),
+            "focal_length": torch.empty(B, 2, device=dev, dtype=f32),
+            "pred_keypoints_3d": torch.empty(B, 44, 3, device=dev, dtype=f32),
+            "pred_vertices": torch.empty(B, 6890, 3, device=dev, dtype=f32),
+            "pred_keypoints_2d": torch.empty(B, 44, 2, device=dev, dtype=f32),
+            "token_idx": torch.empty(B, 160, device=dev, dtype=torch.int32),
+        }
+        if want_probs:
+            o["cls_logits_softmax"] = torch.empty(B, 160, 2048, device=dev, dtype=f32)
+        if taps:
+            o["vit_features"] = torch.empty(B, 192, 1280, device=dev, dtype=f32)
+            o["token_out"] = torch.empty(B, 1024, device=dev, dtype=f32)
+            o["cls_logits"] = torch.empty(B, 160, 2048, device=dev, dtype=f32)
+            o["pose6d"] = torch.empty(B, 144, device=dev, dtype=f32)
+        return o
+
+    def _outputs_struct(self, o):
+        return _cabi.Outputs(**{k: (o[k].data_ptr() if k in o else None) for k in _cabi.OUTPUT_FIELDS})
+
+    def _check_img(self, img):
+        if not (img.is_cuda and img.device == self.device):
+            raise ValueError(f"img must live on {self.device}")
+        if img.dtype != torch.float32 or img.dim() != 4 or tuple(img.shape[1:]) != (3, 256, 256):
+            raise ValueError(f"img must be float32 (B,3,256,256), got {img.dtype} {tuple(img.shape)}")
+        if img.shape[0] > self.max_batch:
+            raise ValueError(f"batch {img.shape[0]} > max_batch {self.max_batch}")
+        return img.contiguous()
+
+    def forward(self, img, taps=False, want_probs=True, outputs=None):
+        img = self._check_img(img)
+        B = img.shape[0]
+        o = outputs if outputs is not None else self._alloc_outputs(B, taps, want_probs)
+        st = self._outputs_struct(o)
+        with torch.cuda.device(self.device):
+            _cabi.check(self.lib.thmr_forward(self.h, _ptr(img), B, C.byref(st), _stream_ptr(self.device)), self.h)
+        return o
+
+    def vit_forward(self, img, out=None):
+        img = self._check_img(img)
+        B = img.shape[0]
+        if out is None:
+            out = torch.empty(B, 192, 1280, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _cabi.check(self.lib.thmr_vit_forward(self.h, _ptr(img), B, _ptr(out), _stream_ptr(self.device)), self.h)
+        return out
+
+    def head_forward(self, ctx, taps=False, want_probs=True):
+        ctx = ctx.contiguous()
+        B = ctx.shape[0]
+        o = self._alloc_outputs(B, taps, want_probs)
+        o.pop("vit_features", None)
+        st = self._outputs_struct(o)
+        with torch.cuda.device(self.device):
+            _cabi.check(self.lib.thmr_head_forward(self.h, _ptr(ctx), B, C.byref(st), _stream_ptr(self.device)), self.h)
+        return o
+
+    def lbs_forward(self, rotmat, betas, cam=None):
+        B = betas.shape[0]
+        dev, f32 = self.device, torch.float32
+        rotmat, betas = rotmat.contiguous(), betas.contiguous()
+        verts = torch.empty(B, 6890, 3, device=dev, dtype=f32)
+        joints = torch.empty(B, 44, 3, device=dev, dtype=f32)
+        cam_t = torch.empty(B, 3, device=dev, dtype=f32) if cam is not None else None
+        kp2d = torch.empty(B, 44, 2, device=dev, dtype=f32) if cam is not None else None
+        cam = cam.contiguous() if cam is not None else None
+        with torch.cuda.device(self.device):
+            _cabi.check(self.lib.thmr_lbs_forward(self.h, _ptr(rotmat), _ptr(betas), _ptr(cam), B, _ptr(verts), _ptr(joints),
+                                                  _ptr(cam_t), _ptr(kp2d), _stream_ptr(self.device)), self.h)
+        return verts, joints, cam_t, kp2d
+
+    def vq_argmin(self, x, want_dist=False):
+        x = x.contiguous()
+        rows = x.shape[0]
+        idx = torch.empty(rows, device=self.device, dtype=torch.int32)
+        dist = torch.empty(rows, 2048, device=self.device, dtype=torch.float32) if want_dist else None
+        with torch.cuda.device(self.device):
+            _cabi.check(self.lib.thmr_vq_argmin(self.h, _ptr(x), rows, _ptr(idx), _ptr(dist), _stream_ptr(self.device)), self.h)
+        return (idx, dist) if want_dist else idx
+
+    # ------------------------------------------------------------------ profiler
+    def prof_enable(self, on=True):
+        _cabi.check(self.lib.thmr_prof_enable(self.h, 1 if on else 0), self.h)
+
+    def prof_collect(self, reset=True):
+        arr = (_cabi.ProfEntry * len(_cabi.PROF_NAMES))()
+        _cabi.check(self.lib.thmr_prof_collect(self.h, arr, 1 if reset else 0), self.h)
+        return {n: dict(ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes, launches=arr[i].launches)
+                for i, n in enumerate(_cabi.PROF_NAMES)}

@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's model API for the inference hot path.
+
+    model, cfg = load_tokenhmr(checkpoint_path, model_cfg)        tokenhmr/lib/models/__init__.py:3-26
+    out = model(batch)                                            tokenhmr/lib/models/tokenhmr.py:330-338
+so that tokenhmr/eval.py:147, demo.py:78 and track.py:39 can call it unchanged: same ctor entry
+point, same `forward(batch) -> dict` keys / shapes / dtypes (tokenhmr.py:156-188), `.to()`,
+`.eval()`, `.cfg`, `.smpl.faces`.  All arithmetic happens in libtokenhmr_hip.so.
+"""
+import os
+import types
+
+import torch
+
+from .config import HMRConfig, RELEASE
+from .engine import Engine
+from . import weights as W
+from .smpl_assets import load_smpl_pkl
+
+
+class _SmplHandle:
+    """What callers read from `model.smpl` (demo.py:52 uses .faces)."""
+
+    def __init__(self, faces):
+        self.faces = faces.cpu().numpy() if torch.is_tensor(faces) else faces
+
+
+class TokenHMR:
+    def __init__(self, cfg: HMRConfig = RELEASE, max_batch: int = 64, device="cuda:0", model_cfg=None):
+        self.hmr_cfg = cfg
+        self.cfg = model_cfg if model_cfg is not None else types.SimpleNamespace(**cfg.to_dict())
+        self.max_batch = max_batch
+        self.device = torch.device(device)
+        self.engine = Engine(cfg, max_batch=max_batch, device=device)
+        self.smpl = _SmplHandle(torch.zeros(13776, 3, dtype=torch.int64))
+        self.training = False
+        self.return_taps = False
+
+    # ---- construction -------------------------------------------------------------------
+    @classmethod
+    def from_state(cls, cfg, state, tokenizer, smpl, max_batch=64, device="cuda:0", model_cfg=None):
+        W.validate_state(state, cfg, tokenizer)
+        m = cls(cfg, max_batch=max_batch, device=device, model_cfg=model_cfg)
+        m.engine.load_state(state, tokenizer)
+        m.engine.load_smpl(smpl)
+        m.engine.finalize()
+        m.smpl = _SmplHandle(smpl["faces"])
+        return m
+
+    # ---- nn.Module-like surface used by eval.py:52-54 / demo.py:35-37 ------------------------
+    def to(self, device):
+        if torch.device(device).type == "cuda" and torch.device(device) != self.engine.device and torch.device(device).index is not None:
+            raise RuntimeError("engine is pinned to %s; build it on the target device" % self.engine.device)
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("tokenhmr_amd implements the inference path only")
+        return self
+
+    def __call__(self, batch):
+        return self.forward(batch)
+
+    # ---- the hot path -------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, batch):
+        """tokenhmr.py:135-188: batch['img'] (B,3,256,256) fp32 -> output dict.  Batches larger
+        than max_batch are processed in max_batch chunks."""
+        img = batch["img"]
+        if not img.is_cuda:
+            raise RuntimeError("batch['img'] must be on the GPU (recursive_to(batch, device), eval.py:145)")
+        if img.dtype != torch.float32:
+            img = img.float()
+        B = img.shape[0]
+        if B <= self.max_batch:
+            return self._pack(self.engine.forward(img, taps=self.return_taps))
+        outs = [self._pack(self.engine.forward(img[i:i + self.max_batch], taps=self.return_taps))
+                for i in range(0, B, self.max_batch)]
+        return _cat_outputs(outs)
+
+    def forward_step(self, batch, train=False):
+        if train:
+            raise NotImplementedError("inference only")
+        return self.forward(batch)
+
+    def _pack(self, o):
+        R = o["rotmat"]
+        out = {
+            "cls_logits_softmax": o["cls_logits_softmax"],
+            "pred_cam": o["pred_cam"],
+            "pred_smpl_params": {"global_orient": R[:, :1], "body_pose": R[:, 1:], "betas": o["betas"]},
+            "pred_cam_t": o["pred_cam_t"],
+            "focal_length": o["focal_length"],
+            "pred_keypoints_3d": o["pred_keypoints_3d"],
+            "pred_vertices": o["pred_vertices"],
+            "pred_keypoints_2d": o["pred_keypoints_2d"],
+            "token_idx": o["token_idx"],          # build-defined extra
+        }
+        for k in ("vit_features", "token_out", "cls_logits", "pose6d"):
+            if k in o:
+                out[k] = o[k]
+        return out
+
+
+def _cat_outputs(outs):
+    res = {}
+    for k in outs[0]:
+        if isinstance(outs[0][k], dict):
+            res[k] = {kk: torch.cat([o[k][kk] for o in outs], 0) for kk in outs[0][k]}
+        else:
+            res[k] = torch.cat([o[k] for o in outs], 0)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+def _read_yaml_cfg(path):
+    """model_config.yaml reader without yacs (absent offline): nested dict -> attribute namespace."""
+    import yaml
+
+    def ns(d):
+        if isinstance(d, dict):
+            n = types.SimpleNamespace(**{k: ns(v) for k, v in d.items()})
+            n.get = lambda key, default=None, _d=d: ns(_d.get(key, default)) if isinstance(_d.get(key, default), dict) else _d.get(key, default)
+            return n
+        return d
+
+    with open(path) as f:
+        return ns(yaml.safe_load(f)), yaml
+
+
+def load_tokenhmr(checkpoint_path="", model_cfg="", dataset_dir="", is_train_state=False, is_demo=False,
+                  max_batch=64, device="cuda:0"):
+    """Drop-in for tokenhmr/lib/models/__init__.py:3-26 (eval branch of TokenHMR.__init__, tokenhmr.py:49-53,84-85).
+
+    Reads the Lightning checkpoint ['state_dict'] (misc.py:242-256), the tokenizer checkpoint named
+    by MODEL.TOKENIZER_CHECKPOINT_PATH ['net'] (vanilla_pose_vqvae.py:265,299-301) and the SMPL
+    pickles named by SMPL.MODEL_PATH / SMPL.JOINT_REGRESSOR_EXTRA, and returns (model, cfg).
+    """
+    if is_train_state:
+        raise NotImplementedError("tokenhmr_amd implements the inference path only")
+    cfg, _ = _read_yaml_cfg(model_cfg)
+    cfg.ckpt_path = checkpoint_path
+    if getattr(cfg.MODEL.BACKBONE, "TYPE", "vit") != "vit":
+        raise NotImplementedError("Backbone type is not implemented")
+    if getattr(cfg.MODEL.SMPL_HEAD, "TYPE", "token") != "token":
+        raise ValueError("Unknown SMPL head type for this engine: only 'token' (tokenhmr_release.yaml:65)")
+    assert cfg.MODEL.IMAGE_SIZE == 256, f"MODEL.IMAGE_SIZE ({cfg.MODEL.IMAGE_SIZE}) should be 256 for ViT backbone"
+    if not hasattr(cfg.MODEL, "BBOX_SHAPE"):
+        cfg.MODEL.BBOX_SHAPE = [192, 256]
+    if dataset_dir != "":
+        cfg.DATASETS.DATASET_DIR = dataset_dir
+    if not os.path.exists(checkpoint_path):
+        raise FileNotFoundError(f"Missing full pretrained model from {checkpoint_path}")   # reference: exit(1), misc.py:252-254
+    td = dict(cfg.MODEL.SMPL_HEAD.TRANSFORMER_DECODER.__dict__)
+    hcfg = HMRConfig(dec_depth=int(td.get("depth", 6)))
+    # torch>=2.6 defaults weights_only=True, but these checkpoints pickle config nodes
+    ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)["state_dict"]
+    state = {k: v for k, v in ckpt.items() if k.startswith(("backbone.", "smpl_head."))}
+    tok = torch.load(cfg.MODEL.TOKENIZER_CHECKPOINT_PATH, map_location="cpu", weights_only=False)["net"]
+    tok = {k: v for k, v in tok.items() if k.startswith("decoder.decoder.") or k == "quantizer.codebook"}
+    mean = __import__("numpy").load(cfg.SMPL.MEAN_PARAMS)
+    state.setdefault("smpl_head.init_body_pose", torch.from_numpy(mean["pose"].astype("float32")).unsqueeze(0))
+    state.setdefault("smpl_head.init_betas", torch.from_numpy(mean["shape"].astype("float32")).unsqueeze(0))
+    state.setdefault("smpl_head.init_cam", torch.from_numpy(mean["cam"].astype("float32")).unsqueeze(0))
+    gender = str(getattr(cfg.SMPL, "GENDER", "neutral")).upper()
+    smpl = load_smpl_pkl(os.path.join(cfg.SMPL.MODEL_PATH, f"SMPL_{gender}.pkl"), cfg.SMPL.JOINT_REGRESSOR_EXTRA, hcfg)
+    model = TokenHMR.from_state(hcfg, state, tok, smpl, max_batch=max_batch, device=device, model_cfg=cfg)
+    return model, cfg

@@ -1,0 +1,65 @@
+"""Stateless operator wrappers over the C ABI (thmr_op_*), used for per-kernel parity tests and
+micro-benchmarks.  Inputs/outputs are contiguous fp32 CUDA tensors; no CPU path exists."""
+import ctypes as C
+
+import torch
+
+from . import _cabi
+
+EPI = {"none": 0, "bias": 1, "bias_gelu": 2, "bias_relu": 3, "bias_resid": 4, "bias_qscale": 5, "bias_pos": 6}
+VARIANT = {"auto": -1, "128x128": 0, "128x160": 1, "skinny": 2}
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _s(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _req(*ts):
+    for t in ts:
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("ops need contiguous float32 CUDA tensors")
+
+
+def gemm(a, w, bias=None, resid=None, epi="none", qscale=1.0, qcols=0, variant="auto"):
+    """C = epilogue(a @ w.T);  a (M,K), w (N,K) — torch.nn.Linear layout."""
+    _req(a, w, bias, resid)
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    with torch.cuda.device(a.device):
+        _cabi.check(_cabi.load().thmr_op_gemm(_p(a), K, _p(w), _p(bias), _p(resid), _p(out), N, M, N, K, EPI[epi],
+                                             float(qscale), int(qcols), VARIANT[variant], _s(a)))
+    return out
+
+
+def layernorm(x, gamma, beta, eps, relu=False):
+    _req(x, gamma, beta)
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _cabi.check(_cabi.load().thmr_op_layernorm(_p(x), _p(gamma), _p(beta), _p(y), rows, D, float(eps), int(relu), _s(x)))
+    return y
+
+
+def vit_attention(qkv):
+    """qkv (B,192,3840) with q pre-scaled -> (B,192,1280)."""
+    _req(qkv)
+    B = qkv.shape[0]
+    out = torch.empty(B, 192, 1280, device=qkv.device, dtype=torch.float32)
+    with torch.cuda.device(qkv.device):
+        _cabi.check(_cabi.load().thmr_op_vit_attention(_p(qkv), _p(out), B, _s(qkv)))
+    return out
+
+
+def rot6d_to_rotmat(x):
+    _req(x)
+    x2 = x.reshape(-1, 6).contiguous()
+    n = x2.shape[0]
+    R = torch.empty(n, 3, 3, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _cabi.check(_cabi.load().thmr_op_rot6d(_p(x2), _p(R), n, _s(x)))
+    return R
