@@ -43,21 +43,43 @@ def parse():
 def cpu_baseline(cfg, sd, tok, smpl, workload, n_crops):
     """The oracle (CPU restatement pinned bit-exact to the reference's modules) on this host's cores."""
     from oracle import tokenhmr_oracle as O
-    cores = os.cpu_count()
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count()
     g = torch.Generator().manual_seed(4001)
     img = torch.randn(n_crops, 3, 256, 256, generator=g)
-    fn = (lambda: O.forward(img, sd, tok, smpl, cfg)) if workload == "full" else (lambda: O.vit_forward(img, sd, cfg))
+
+    def fn(x):
+        return O.forward(x, sd, tok, smpl, cfg) if workload == "full" else O.vit_forward(x, sd, cfg)
+
+    # Thread count matters a lot on big hosts (all 256 hardware threads of a 2-socket EPYC are ~50x SLOWER than
+    # 32-64 threads for these GEMM sizes), so probe a few counts on 2 crops and keep the fastest; the whole leg is
+    # bounded to ~40 s of wall time.
+    t_start = time.perf_counter()
+    cands = sorted({t for t in (16, 32, 64, 128, ncpu) if t <= ncpu})
+    probe = {}
     with torch.no_grad():
-        fn()                       # warm-up
+        for t in cands:
+            torch.set_num_threads(t)
+            fn(img[:1])                                    # warm-up at this thread count
+            t0 = time.perf_counter()
+            fn(img[:2])
+            probe[t] = time.perf_counter() - t0
+            if time.perf_counter() - t_start > 20 or probe[t] > 4 * min(probe.values()):
+                break
+        best_t = min(probe, key=probe.get)
+        torch.set_num_threads(best_t)
         ts = []
         for _ in range(2):
             t0 = time.perf_counter()
-            fn()
+            fn(img)
             ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > 40:
+                break
     best = min(ts)
-    return {"value": n_crops / best, "unit": "crops/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch CPU fp32, {cores} threads), {workload} path, best of 2 passes over {n_crops} crops after 1 warm-up"}
+    return {"value": round(n_crops / best, 3), "unit": "crops/s", "cores": best_t, "kind": "port",
+            "host_cpus": ncpu,
+            "sample": (f"oracle (torch CPU fp32, restatement pinned bit-exact to the reference modules), {workload} path, "
+                       f"best of {len(ts)} passes over {n_crops} crops with {best_t} threads "
+                       f"(fastest of probed thread counts {dict((k, round(2 / v, 2)) for k, v in probe.items())} crops/s)")}
 
 
 def main():

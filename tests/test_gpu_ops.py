@@ -39,7 +39,7 @@ SHAPES = [(128, 128, 32), (256, 320, 64), (384, 1280, 1280), (200, 72, 96), (130
           (384, 3840, 1280), (384, 1280, 5120), (1, 160, 64), (1344, 512, 512)]
 
 
-@pytest.mark.parametrize("variant", ["128x128", "128x160", "auto"])
+@pytest.mark.parametrize("variant", ["128x128", "128x160", "128x128s3", "128x160s3", "256x128s3", "256x128", "auto"])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_gemm_shapes(built_lib, cuda_dev, shape, variant):
     from tokenhmr_amd import ops
@@ -119,15 +119,21 @@ def test_vit_attention(built_lib, cuda_dev, B):
 
 
 def test_vit_attention_peaked(built_lib, cuda_dev):
-    """Large score spread (one dominant key per query) exercises the max-subtraction path."""
+    """Large score spread (|scores| ~ 100, one dominant key per query) exercises the max-subtraction path.
+    Judged against an fp64 statement: the HIP fp32 error must be of the same class as torch's own fp32 error
+    (both are dominated by the fp32 rounding of ~1e2-sized scores entering exp)."""
     from tokenhmr_amd import ops
     qkv = _rand(1, 192, 3840, seed=12)
     qkv[:, :, :2560] *= 6.0
     out = ops.vit_attention(qkv.to(cuda_dev)).cpu()
     t = qkv.reshape(1, 192, 3, 16, 80).permute(2, 0, 3, 1, 4)
-    ref = ((t[0] @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]).transpose(1, 2).reshape(1, 192, 1280)
+    ref32 = ((t[0] @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]).transpose(1, 2).reshape(1, 192, 1280)
+    t64 = t.double()
+    ref64 = ((t64[0] @ t64[1].transpose(-2, -1)).softmax(-1) @ t64[2]).transpose(1, 2).reshape(1, 192, 1280)
     assert torch.isfinite(out).all()
-    assert torch.allclose(out, ref, atol=2e-5, rtol=1e-4), (out - ref).abs().max()
+    err_hip = (out.double() - ref64).abs().max().item()
+    err_cpu = (ref32.double() - ref64).abs().max().item()
+    assert err_hip <= max(4 * err_cpu, 2e-5), (err_hip, err_cpu)
 
 
 def test_rot6d(built_lib, cuda_dev):

@@ -5,13 +5,15 @@
 // Input  qkv (B,192,3840) = [q(16x80) | k(16x80) | v(16x80)] per token, q already scaled by 80^-0.5 in the
 // QKV GEMM epilogue (vit.py:116).  Output (B,192,1280) with column h*80+d (vit.py:122 transpose+reshape).
 //
-// gfx950 design: one 256-thread workgroup per (b,h); K and V of the head live in LDS (129 KB, 1 WG/CU,
-// one wave per SIMD); each wave owns 48 query rows = 3 tiles of 16 and keeps the whole 48x192 score
-// tile in registers (144 accumulator VGPRs) — no KV loop and no online softmax is needed at N = 192.
+// gfx950 design: one 256-thread workgroup per (b,h), TWO workgroups per CU (2 waves per SIMD) so that one
+// workgroup's load / softmax phases run under the other's MFMAs.  K and V of the head time-share ONE 66 KB
+// LDS buffer: K is staged first; after S = QK^T the V rows are fetched into the (now dead) Q registers while
+// the softmax runs, then written over K.  Each wave owns 48 query rows = 3 tiles of 16 and keeps the whole
+// 48x192 score tile in registers (144 VGPRs) — no KV loop and no online softmax is needed at N = 192.
 //   S^T = K Q^T  with v_mfma_f32_16x16x4_f32 (A = K rows from LDS via ds_read_b128 + the k-permutation
 //                trick, B = Q fragments held in registers).  The swapped product leaves every query's
 //                192 scores in 4 lanes x 48 registers, so row max/sum are 47 in-lane ops + 2 xor-shuffles.
-//   P = softmax  exact expf and a true division, fp32.
+//   P = softmax  fp32; exp(x) = v_exp_f32(x * log2 e) (1 ulp) and one reciprocal per row.
 //   O = P V      P registers are directly the MFMA A operand (lane group g <-> key 16*kt + 4g + r);
 //                V rows come from LDS with conflict-free ds_read_b32 (row stride 84).
 // d = 80 = 5 tiles of 16 and 80 = 20 k-steps of 4: the 16x16x4 shape wastes no MFMA work.
@@ -22,27 +24,22 @@ namespace {
 constexpr int NTOK = 192, HD = 80, NH = 16, DIM = 1280, QKV_LD = 3840;
 constexpr int KS = 88;   // K row stride in LDS (floats): conflict-free for ds_read_b128 lane groups
 constexpr int VS = 84;   // V row stride in LDS (floats): conflict-free for ds_read_b32 (rows 4 apart)
+constexpr int F4_PER_THREAD = NTOK * (HD / 4) / 256;   // 15 float4 of a 192x80 tile per thread
 
-__global__ __launch_bounds__(256, 1) void vit_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float smem[NTOK * KS + NTOK * VS];
-    float* Ks = smem;
-    float* Vs = smem + NTOK * KS;
-
+__global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float smem[NTOK * KS];   // K, later overwritten by V
     const int b = blockIdx.x / NH, h = blockIdx.x % NH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const float* base = qkv + (int64_t)b * NTOK * QKV_LD + h * HD;
 
-    // ---- stage K and V of this head into LDS (coalesced: 20 consecutive threads read one 320 B row) ----
-    for (int idx = tid; idx < NTOK * (HD / 4); idx += 256) {
-        const int row = idx / (HD / 4), c4 = idx % (HD / 4);
-        const float* src = base + (int64_t)row * QKV_LD + c4 * 4;
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(src + DIM);
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(src + 2 * DIM);
-        *reinterpret_cast<f32x4*>(&Ks[row * KS + c4 * 4]) = kv;
-        *reinterpret_cast<f32x4*>(&Vs[row * VS + c4 * 4]) = vv;
+    // ---- stage K (coalesced: 20 consecutive threads read one 320 B row) ----
+    f32x4 stg[F4_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < F4_PER_THREAD; ++i) {
+        const int idx = tid + i * 256, row = idx / (HD / 4), c4 = idx % (HD / 4);
+        stg[i] = *reinterpret_cast<const f32x4*>(base + (int64_t)row * QKV_LD + DIM + c4 * 4);
     }
-
     // ---- Q fragments: B operand of S^T = K Q^T.  B[kslot g][j = query l15]; with the k-permutation,
     //      register qf[qt][j][t] = Q[q0 + 16 qt + l15][16 j + 4 g + t] ----
     const int q0 = wave * 48;
@@ -52,7 +49,11 @@ __global__ __launch_bounds__(256, 1) void vit_attention_kernel(const float* __re
 #pragma unroll
         for (int j = 0; j < 5; ++j)
             qf[qt][j] = *reinterpret_cast<const f32x4*>(base + (int64_t)(q0 + qt * 16 + l15) * QKV_LD + j * 16 + g * 4);
-
+#pragma unroll
+    for (int i = 0; i < F4_PER_THREAD; ++i) {
+        const int idx = tid + i * 256, row = idx / (HD / 4), c4 = idx % (HD / 4);
+        *reinterpret_cast<f32x4*>(&smem[row * KS + c4 * 4]) = stg[i];
+    }
     __syncthreads();
 
     // ---- S^T tiles: s[qt][kt][r] = S[q0 + 16 qt + l15][16 kt + 4 g + r] ----
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256, 1) void vit_attention_kernel(const float* __re
     for (int kt = 0; kt < 12; ++kt) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const f32x4 ka = *reinterpret_cast<const f32x4*>(&Ks[(kt * 16 + l15) * KS + j * 16 + g * 4]);
+            const f32x4 ka = *reinterpret_cast<const f32x4*>(&smem[(kt * 16 + l15) * KS + j * 16 + g * 4]);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -75,7 +76,15 @@ __global__ __launch_bounds__(256, 1) void vit_attention_kernel(const float* __re
         }
     }
 
+    // ---- fetch V into registers (in flight during the softmax) ----
+#pragma unroll
+    for (int i = 0; i < F4_PER_THREAD; ++i) {
+        const int idx = tid + i * 256, row = idx / (HD / 4), c4 = idx % (HD / 4);
+        stg[i] = *reinterpret_cast<const f32x4*>(base + (int64_t)row * QKV_LD + 2 * DIM + c4 * 4);
+    }
+
     // ---- softmax over the 192 keys of each query (4 lanes x 48 registers per query) ----
+    constexpr float LOG2E = 1.44269504088896340736f;
 #pragma unroll
     for (int qt = 0; qt < 3; ++qt) {
         float m = s[qt][0][0];
@@ -90,17 +99,27 @@ __global__ __launch_bounds__(256, 1) void vit_attention_kernel(const float* __re
         for (int kt = 0; kt < 12; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = expf(s[qt][kt][r] - m);
+                const float e = __builtin_amdgcn_exp2f((s[qt][kt][r] - m) * LOG2E);
                 s[qt][kt][r] = e;
                 sum += e;
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
 #pragma unroll
         for (int kt = 0; kt < 12; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[qt][kt][r] = s[qt][kt][r] / sum;
+            for (int r = 0; r < 4; ++r) s[qt][kt][r] *= inv;
     }
+
+    // ---- V over K in LDS: every wave must be done reading K first ----
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < F4_PER_THREAD; ++i) {
+        const int idx = tid + i * 256, row = idx / (HD / 4), c4 = idx % (HD / 4);
+        *reinterpret_cast<f32x4*>(&smem[row * VS + c4 * 4]) = stg[i];
+    }
+    __syncthreads();
 
     // ---- O = P V: A[i = query l15][kslot g] = P register, B[kslot g][j = d] = V[16 kt + 4 g + r][16 dt + l15] ----
     f32x4 o[3][5];
@@ -113,7 +132,7 @@ __global__ __launch_bounds__(256, 1) void vit_attention_kernel(const float* __re
     for (int kt = 0; kt < 12; ++kt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float* vrow = &Vs[(kt * 16 + g * 4 + r) * VS + l15];
+            const float* vrow = &smem[(kt * 16 + g * 4 + r) * VS + l15];
 #pragma unroll
             for (int dt = 0; dt < 5; ++dt) {
                 const float vb = vrow[dt * 16];

@@ -10,15 +10,21 @@
 //   * Both operands are K-contiguous (torch Linear layout), so A and W tiles are staged identically:
 //     global float4 -> registers -> LDS rows of 32 floats whose eight 16-B slots are XOR-swizzled with
 //     (row>>1)&7 (conflict-free for the four 16-lane groups of ds_read_b128 and for the 8-lane groups of
-//     ds_write_b128, no padding), double-buffered, ONE barrier per 32-deep K tile; the global loads
-//     of tile t+2 are issued before the MFMAs of tile t+1 so HBM/L2 latency hides under 64 MFMAs.
+//     ds_write_b128, no padding).
+//   * pipeline: ONE barrier per 32-deep K tile.  Inside iteration t the register-staged tile (global-loaded
+//     one iteration earlier) is written to LDS right after the first 16 MFMAs and the next global loads are
+//     issued after the second 16, so all staging traffic sits in the shadow of the 64-cycle MFMAs.
+//       STAGES = 2: two LDS buffers, 2 blocks/CU (the co-resident block covers the barrier bubble);
+//       STAGES = 3: three LDS buffers, the first fragments of tile t+1 are read BEFORE the barrier
+//                   (they were written two barriers ago), so a lone block per CU has no LDS-latency bubble.
 //   * k-permutation trick: one ds_read_b128 gives a lane 4 consecutive k of its row; lanes 0-31 take
 //     k0..k0+3 and lanes 32-63 take k0+4..k0+7, so MFMA step t multiplies k0+t (lower half) and
 //     k0+4+t (upper half).  A and W use the same permutation, hence the sum over k is unchanged.
 //   * wave tile = TM x TN blocks of 32x32 (16 accumulator VGPRs each); block = WM x WN waves.
 //   * XCD-aware tile order: block b runs on XCD b%8, so consecutive logical tiles (which share A
 //     row panels / W column panels) are given to the same XCD's L2.
-//   * fused epilogues: bias, exact-erf GELU, ReLU, residual add, q-scale, pos-embed add.
+//   * fused epilogues: bias, exact-erf GELU, ReLU, residual add, q-scale, pos-embed add.  The epilogue
+//     loads a whole 16-row fragment of residual/pos values BEFORE combining (no load->wait->store chains).
 #include "common.h"
 
 namespace {
@@ -26,18 +32,20 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDK = 32;   // LDS row (floats) = 8 slots of 16 B; slot' = slot ^ ((row >> 1) & 7)
 
-template <int WM, int WN, int TM, int TN, int EPI>
+template <int WM, int WN, int TM, int TN, int STAGES, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int tiles_m, int tiles_n) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     constexpr int A_F4 = BM * 8 / NT;   // float4 loads per thread per K tile
     constexpr int B_F4 = BN * 8 / NT;
+    constexpr int NJ = BK / 8;
     static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile/threads mismatch");
+    static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
-    float* As = smem;                    // [2][BM][LDK]
-    float* Bs = smem + 2 * BM * LDK;     // [2][BN][LDK]
+    __shared__ __attribute__((aligned(16))) float smem[STAGES * (BM + BN) * LDK];
+    float* As = smem;                         // [STAGES][BM][LDK]
+    float* Bs = smem + STAGES * BM * LDK;     // [STAGES][BN][LDK]
 
     // ---- XCD-aware logical tile id (bijective for any grid size) ----
     const int nwg = tiles_m * tiles_n;
@@ -63,12 +71,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
     const int lrow = lane & 31, lhalf = lane >> 5;
 
     // ---- global -> register staging ----
-    f32x4 ra[A_F4], rb[B_F4];
-    const float* Ag[A_F4];
-    const float* Wg[B_F4];
     // Rows past M / N are clamped to a valid row and NOT zeroed: an output element depends only on its own
     // A row and W row, and rows/cols past the edge are never stored, so their (duplicate) data is harmless.
     // Keeping the loaded registers untouched lets the loads stay in flight across the barrier.
+    f32x4 ra[A_F4], rb[B_F4];
+    const float* Ag[A_F4];
+    const float* Wg[B_F4];
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
         const int f = tid + i * NT, row = f >> 3, c4 = f & 7;
@@ -108,36 +116,44 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // swizzled float offset of logical slot (2j + lhalf) for this lane's rows (wm0, mi*32 are multiples of 16)
-    int koff[BK / 8];
+    int koff[NJ];
 #pragma unroll
-    for (int j = 0; j < BK / 8; ++j) koff[j] = (((2 * j + lhalf) ^ ((lrow >> 1) & 7)) << 2);
+    for (int j = 0; j < NJ; ++j) koff[j] = (((2 * j + lhalf) ^ ((lrow >> 1) & 7)) << 2);
+
+    f32x4 af[2][TM], bf[2][TN];
+    auto read_frags = [&](int buf, int j, int slot) {
+        const float* Ab = As + (buf * BM + wm0 + lrow) * LDK + koff[j];
+        const float* Bb = Bs + (buf * BN + wn0 + lrow) * LDK + koff[j];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) af[slot][mi] = *reinterpret_cast<const f32x4*>(Ab + mi * 32 * LDK);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) bf[slot][ni] = *reinterpret_cast<const f32x4*>(Bb + ni * 32 * LDK);
+    };
 
     const int nk = a.K / BK;
+    // ---- prologue: STAGES-1 tiles in LDS, one more in registers ----
     load_global(0);
     store_lds(0);
-    if (nk > 1) load_global(1);
+    if constexpr (STAGES == 3) {
+        load_global(min(1, nk - 1));
+        store_lds(1);
+        load_global(min(2, nk - 1));
+    } else {
+        load_global(min(1, nk - 1));
+    }
     __syncthreads();
+    if constexpr (STAGES == 3) read_frags(0, 0, 0);
 
+    int buf = 0;                       // LDS buffer of tile kt
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        const float* Ab = As + (buf * BM + wm0 + lrow) * LDK;
-        const float* Bb = Bs + (buf * BN + wn0 + lrow) * LDK;
-        // fragment double-buffer: the ds_read_b128s of k-group j+1 are issued before the 16 MFMAs of group j
-        f32x4 af[2][TM], bf[2][TN];
+        int wbuf = buf + (STAGES - 1);             // buffer receiving tile kt + STAGES - 1
+        if (wbuf >= STAGES) wbuf -= STAGES;
+        int nbuf = buf + 1;
+        if (nbuf >= STAGES) nbuf -= STAGES;
+        if constexpr (STAGES == 2) read_frags(buf, 0, 0);
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) af[0][mi] = *reinterpret_cast<const f32x4*>(Ab + mi * 32 * LDK + koff[0]);
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) bf[0][ni] = *reinterpret_cast<const f32x4*>(Bb + ni * 32 * LDK + koff[0]);
-#pragma unroll
-        for (int j = 0; j < BK / 8; ++j) {
-            if (j + 1 < BK / 8) {
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-                    af[(j + 1) & 1][mi] = *reinterpret_cast<const f32x4*>(Ab + mi * 32 * LDK + koff[j + 1]);
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-                    bf[(j + 1) & 1][ni] = *reinterpret_cast<const f32x4*>(Bb + ni * 32 * LDK + koff[j + 1]);
-            }
+        for (int j = 0; j < NJ; ++j) {
+            if (j + 1 < NJ) read_frags(buf, j + 1, (j + 1) & 1);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -146,38 +162,79 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
                     for (int ni = 0; ni < TN; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][mi][t], bf[j & 1][ni][t],
                                                                            acc[mi][ni], 0, 0, 0);
+            // staging in the MFMA shadow: registers -> LDS after the first k-group, next global loads after the second
+            // (unconditional: past the last tile the writes land in a buffer nobody reads again and the loads
+            //  re-read the last tile, which keeps the loop body branch-free)
+            if (j == 0) store_lds(wbuf);
+            if (j == 1) load_global(min(kt + STAGES, nk - 1));
         }
-        if (kt + 1 < nk) store_lds(buf ^ 1);      // tile kt+1 (loaded during the previous iteration)
-        if (kt + 2 < nk) load_global(kt + 2);     // in flight across the barrier and the next 64 MFMAs
+        if constexpr (STAGES == 3) {
+            // tile kt+1 was written during iteration kt-1, i.e. two barriers ago: safe to read before this barrier
+            if (kt + 1 < nk) read_frags(nbuf, 0, 0);
+        }
         __syncthreads();
+        buf = nbuf;
     }
 
-    // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             const int n = bn0 + wn0 + ni * 32 + lrow;
-            if (n < a.N) {
-                float bias = 0.f;
-                if constexpr (EPI != EPI_NONE) bias = a.bias[n];
+            const int nc = min(n, a.N - 1);
+            const int mbase = bm0 + wm0 + mi * 32 + 4 * lhalf;
+            float bias = 0.f;
+            if constexpr (EPI != EPI_NONE) bias = a.bias[nc];
+            float extra[16];
+            if constexpr (EPI == EPI_BIAS_RESID) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int m = bm0 + wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-                    if (m < a.M) a.C[(int64_t)m * a.ldc + n] = gemm_epilogue<EPI>(a, acc[mi][ni][e], bias, m, n);
+                    const int m = min(mbase + (e & 3) + 8 * (e >> 2), a.M - 1);
+                    extra[e] = a.resid[(int64_t)m * a.ldr + nc];
+                }
+            }
+            float pos0 = 0.f;
+            if constexpr (EPI == EPI_BIAS_POS) {
+                pos0 = a.resid[nc];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mbase + (e & 3) + 8 * (e >> 2);
+                    extra[e] = a.resid[(int64_t)(1 + m % 192) * a.N + nc];
+                }
+            }
+            float outv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[mi][ni][e];
+                if constexpr (EPI != EPI_NONE) v = v + bias;
+                if constexpr (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.0f);
+                if constexpr (EPI == EPI_BIAS_RESID) v = extra[e] + v;
+                if constexpr (EPI == EPI_BIAS_QSCALE) v = (n < a.qcols) ? v * a.qscale : v;
+                if constexpr (EPI == EPI_BIAS_POS) v = (v + extra[e]) + pos0;
+                outv[e] = v;
+            }
+            if (n < a.N) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mbase + (e & 3) + 8 * (e >> 2);
+                    if (m < a.M) a.C[(int64_t)m * a.ldc + n] = outv[e];
                 }
             }
         }
     }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int STAGES>
 int launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
-#define THMR_GEMM_CASE(E) \
-    case E: hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, E>), grid, block, 0, s, a, tiles_m, tiles_n); break;
+#define THMR_GEMM_CASE(E)                                                                                         \
+    case E:                                                                                                       \
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, STAGES, E>), grid, block, 0, s, a, tiles_m, tiles_n); \
+        break;
     switch (epi) {
         THMR_GEMM_CASE(EPI_NONE)
         THMR_GEMM_CASE(EPI_BIAS)
@@ -203,7 +260,10 @@ inline double tile_efficiency(int M, int N, int BM, int BN) {
 
 }  // namespace
 
-// variant: 0 = 128x128 (2x2 waves of 64x64), 1 = 128x160 (4x1 waves of 32x160), -1 = pick by tile quantisation
+// variant: 0 = 128x128 2-stage (2x2 waves of 64x64)      1 = 128x160 2-stage (4x1 waves of 32x160)
+//          3 = 128x128 3-stage                            4 = 128x160 3-stage
+//          5 = 256x128 3-stage (2x2 waves of 128x64)      6 = 256x128 2-stage
+//         -1 = pick by tile quantisation over 256 CUs     (2 is the skinny kernel, see thmr_op_gemm)
 int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % BK) != 0) return -1;
     if ((a.lda % 4) != 0 || (a.ldw % 4) != 0) return -1;
@@ -212,6 +272,12 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         const double e1 = tile_efficiency(a.M, a.N, 128, 160);
         variant = (e1 > e0 * 1.02) ? 1 : 0;
     }
-    if (variant == 1) return launch_cfg<4, 1, 1, 5>(a, epi, s);
-    return launch_cfg<2, 2, 2, 2>(a, epi, s);
+    switch (variant) {
+        case 1: return launch_cfg<4, 1, 1, 5, 2>(a, epi, s);
+        case 3: return launch_cfg<2, 2, 2, 2, 3>(a, epi, s);
+        case 4: return launch_cfg<4, 1, 1, 5, 3>(a, epi, s);
+        case 5: return launch_cfg<2, 2, 4, 2, 3>(a, epi, s);
+        case 6: return launch_cfg<2, 2, 4, 2, 2>(a, epi, s);
+        default: return launch_cfg<2, 2, 2, 2, 2>(a, epi, s);
+    }
 }
