@@ -9,17 +9,19 @@ dev = torch.device("cuda:0")
 M = 64 * 192
 SHAPES = {"qkv": (M, 3840, 1280, "bias_qscale"), "proj": (M, 1280, 1280, "bias_resid"),
           "fc1": (M, 5120, 1280, "bias_gelu"), "fc2": (M, 1280, 5120, "bias_resid")}
-VARIANTS = ["128x128", "128x160", "128x128s3", "128x160s3", "256x128s3", "256x128"]
+VARIANTS = ["128x128reg", "128x160reg", "128x128", "128x160"]
 only = os.environ.get("GEMM_VARIANTS")
 if only:
     VARIANTS = only.split(",")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+if os.environ.get("GEMM_EPI_NONE"):
+    SHAPES = {k: (m, n, kk, "none") for k, (m, n, kk, e) in SHAPES.items()}
 g = torch.Generator().manual_seed(0)
 res = {}
 for name, (m, n, k, epi) in SHAPES.items():
     a = torch.randn(m, k, generator=g).to(dev)
     w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev)
-    b = torch.randn(n, generator=g).to(dev)
+    b = torch.randn(n, generator=g).to(dev) if epi != "none" else None
     r = torch.randn(m, n, generator=g).to(dev) if epi == "bias_resid" else None
     kw = dict(qscale=0.1118, qcols=1280) if epi == "bias_qscale" else {}
     times = {v: [] for v in VARIANTS}

@@ -377,7 +377,7 @@ int conv3(thmr_engine* e, int conv_id, const float* in, int Tin, int Tout, const
     float* gat = e->S(e->so.gat);
     LAUNCH_OK(launch_conv3_gather(in, gat, src, B, Tin, Tout, ci, dil, prerelu, st));
     GemmArgs a = mk(gat, 3 * ci, e->warena + e->convp[conv_id], 3 * ci, bias, resid, co, outp, co, B * Tout, co, 3 * ci);
-    LAUNCH_OK(launch_gemm(a, epi, 0, st));
+    LAUNCH_OK(launch_gemm(a, epi, -1, st));
     return 0;
 }
 
@@ -454,28 +454,28 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
         LAUNCH_OK(launch_transpose(y1, tT, B, TN, HID, st));                                   // (B,160,64)->(B,64,160)
         {
             GemmArgs a = mk(tT, TN, e->W(p + "MLP_token.ff.0.weight"), TN, e->W(p + "MLP_token.ff.0.bias"), nullptr, 0, u, TOK_INTER, B * HID, TOK_INTER, TN);
-            LAUNCH_OK(launch_gemm(a, EPI_BIAS_GELU, 0, st));
+            LAUNCH_OK(launch_gemm(a, EPI_BIAS_GELU, -1, st));
         }
         {
             GemmArgs a = mk(u, TOK_INTER, e->W(p + "MLP_token.ff.3.weight"), TOK_INTER, e->W(p + "MLP_token.ff.3.bias"), nullptr, 0, yt, TN, B * HID, TN, TOK_INTER);
-            LAUNCH_OK(launch_gemm(a, EPI_BIAS, 0, st));
+            LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
         }
         LAUNCH_OK(launch_transpose(yt, y, B, HID, TN, st));                                    // (B,64,160)->(B,160,64)
         LAUNCH_OK(launch_add_ln64(cf, y, e->W(p + "layernorm2.weight"), e->W(p + "layernorm2.bias"), s, z0, R, LN_EPS, st));
         {
             GemmArgs a = mk(z0, HID, e->W(p + "MLP_channel.ff.0.weight"), HID, e->W(p + "MLP_channel.ff.0.bias"), nullptr, 0, zh, HID_INTER, R, HID_INTER, HID);
-            LAUNCH_OK(launch_gemm(a, EPI_BIAS_GELU, 0, st));
+            LAUNCH_OK(launch_gemm(a, EPI_BIAS_GELU, -1, st));
         }
         {   // out = (x + y) + z
             GemmArgs a = mk(zh, HID_INTER, e->W(p + "MLP_channel.ff.3.weight"), HID_INTER, e->W(p + "MLP_channel.ff.3.bias"), s, HID, cf2, HID, R, HID, HID_INTER);
-            LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, 0, st));
+            LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, -1, st));
         }
         std::swap(cf, cf2);
     }
     float *nl = e->S(so.nl), *nl2 = e->S(so.nl2);
     {
         GemmArgs a = mk(cf, HID, e->W(C + "mixer_norm_layer.ff.0.weight"), HID, e->W(C + "mixer_norm_layer.ff.0.bias"), nullptr, 0, nl, HID, R, HID, HID);
-        LAUNCH_OK(launch_gemm(a, EPI_BIAS, 0, st));
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
     }
     LAUNCH_OK(launch_layernorm(nl, e->W(C + "mixer_norm_layer.ff.1.weight"), e->W(C + "mixer_norm_layer.ff.1.bias"), nl2, R, HID, LN_EPS, 1, st));
     // logits / softmax / token index; KV in `big` is dead after the decoder, so logits+probs live there
@@ -484,14 +484,14 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
     int32_t* tokidx = (out && out->token_idx) ? out->token_idx : reinterpret_cast<int32_t*>(e->S(so.tokidx));
     {
         GemmArgs a = mk(nl2, HID, e->W(C + "class_pred_layer.weight"), HID, e->W(C + "class_pred_layer.bias"), nullptr, 0, logits, NCLS, R, NCLS, HID);
-        LAUNCH_OK(launch_gemm(a, EPI_BIAS, 0, st));
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
     }
     LAUNCH_OK(launch_softmax_argmax2048(logits, probs, tokidx, R, st));
     // soft codebook lookup: probs @ codebook (quantize_cnn.py:92-93) as a GEMM against codebook^T
     float* feat = e->S(so.feat);
     {
         GemmArgs a = mk(probs, NCLS, e->warena + e->o_cbT, NCLS, nullptr, nullptr, 0, feat, CODE, R, CODE, NCLS);
-        LAUNCH_OK(launch_gemm(a, EPI_NONE, 0, st));
+        LAUNCH_OK(launch_gemm(a, EPI_NONE, -1, st));
     }
     // VQ decoder (vanilla_pose_vqvae.py:135-154), channels-last (B,T,C)
     float *a0 = e->S(so.act0), *a1 = e->S(so.act1), *a2 = e->S(so.act2);
@@ -512,7 +512,7 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
         const int dil = blk == 0 ? 3 : 1;
         if (int r = conv3(e, 5 + blk, cur, Tq, Tq, nullptr, dil, 1, e->W(p + "conv1.bias"), EPI_BIAS_RELU, nullptr, a2, B, st)) return r;
         GemmArgs a = mk(a2, VQW, e->W(p + "conv2.weight"), VQW, e->W(p + "conv2.bias"), cur, VQW, nxt, VQW, B * Tq, VQW, VQW);
-        LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, 0, st));
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, -1, st));
         std::swap(cur, nxt);
     }
     if (int r = conv3(e, 7, cur, Tq, Tq, nullptr, 1, 0, e->W(d + "14.1.bias"), EPI_BIAS, nullptr, nxt, B, st)) return r;
@@ -761,7 +761,7 @@ int thmr_vq_argmin(thmr_engine* e, const float* x_dev, int32_t rows, int32_t* id
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* dot = e->S(e->so.big);
     GemmArgs a = mk(x_dev, CODE, e->W("quantizer.codebook"), CODE, nullptr, nullptr, 0, dot, NCLS, rows, NCLS, CODE);
-    LAUNCH_OK(launch_gemm(a, EPI_NONE, 0, st));
+    LAUNCH_OK(launch_gemm(a, EPI_NONE, -1, st));
     LAUNCH_OK(launch_vq_argmin_rows(x_dev, dot, e->warena + e->o_cnorm, idx_dev, dist_dev, rows, st));
     return 0;
 }

@@ -7,16 +7,19 @@
 //
 // Design (gfx950):
 //   * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 FLOP/clk/SIMD = 157 TF chip peak.
-//   * Both operands are K-contiguous (torch Linear layout), so A and W tiles are staged identically:
-//     global float4 -> registers -> LDS rows of 32 floats whose eight 16-B slots are XOR-swizzled with
-//     (row>>1)&7 (conflict-free for the four 16-lane groups of ds_read_b128 and for the 8-lane groups of
-//     ds_write_b128, no padding).
-//   * pipeline: ONE barrier per 32-deep K tile.  Inside iteration t the register-staged tile (global-loaded
-//     one iteration earlier) is written to LDS right after the first 16 MFMAs and the next global loads are
-//     issued after the second 16, so all staging traffic sits in the shadow of the 64-cycle MFMAs.
-//       STAGES = 2: two LDS buffers, 2 blocks/CU (the co-resident block covers the barrier bubble);
-//       STAGES = 3: three LDS buffers, the first fragments of tile t+1 are read BEFORE the barrier
-//                   (they were written two barriers ago), so a lone block per CU has no LDS-latency bubble.
+//   * Both operands are K-contiguous (torch Linear layout), so A and W tiles are staged identically into
+//     LDS rows of 32 floats whose eight 16-B slots are XOR-swizzled with (row>>1)&7: conflict-free for the
+//     four 16-lane groups of ds_read_b128, no padding (SQ_LDS_BANK_CONFLICT = 0 measured).
+//   * two staging paths, same LDS image:
+//       DMA  (product path): global_load_lds_dwordx4 — HBM/L2 -> LDS directly, no VGPR round trip and no
+//            ds_write.  The LDS destination of a wave instruction is lane-linear (base + 16*lane = 8 rows x
+//            8 slots), so the swizzle is applied to the per-lane SOURCE address: lane (r, p) fetches the
+//            logical slot p ^ ((r>>1)&7) of row r.  Every 8 lanes still read one whole 128-B line.
+//       REG  (kept for A/B): float4 global loads -> registers -> ds_write_b128 in the MFMA shadow.
+//     Ablation on MI355X (profiles/r1_gemm_ablation.md): the register staging traffic cost 10-13 % of the
+//     MFMA rate, the barrier 0-4 %, a pure-MFMA loop of this shape runs at 145-155 TF.
+//   * pipeline: two LDS buffers, ONE barrier per 32-deep K tile, 2 blocks per CU (the co-resident block
+//     covers the barrier / first-fragment bubble; 3-stage single-block variants measured 15 % slower).
 //   * k-permutation trick: one ds_read_b128 gives a lane 4 consecutive k of its row; lanes 0-31 take
 //     k0..k0+3 and lanes 32-63 take k0+4..k0+7, so MFMA step t multiplies k0+t (lower half) and
 //     k0+4+t (upper half).  A and W use the same permutation, hence the sum over k is unchanged.
@@ -31,159 +34,38 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int LDK = 32;   // LDS row (floats) = 8 slots of 16 B; slot' = slot ^ ((row >> 1) & 7)
+constexpr int NJ = BK / 8;
 
-template <int WM, int WN, int TM, int TN, int STAGES, int EPI>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int tiles_m, int tiles_n) {
-    constexpr int NT = WM * WN * 64;
-    constexpr int BM = WM * TM * 32;
-    constexpr int BN = WN * TN * 32;
-    constexpr int A_F4 = BM * 8 / NT;   // float4 loads per thread per K tile
-    constexpr int B_F4 = BN * 8 / NT;
-    constexpr int NJ = BK / 8;
-    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile/threads mismatch");
-    static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
 
-    __shared__ __attribute__((aligned(16))) float smem[STAGES * (BM + BN) * LDK];
-    float* As = smem;                         // [STAGES][BM][LDK]
-    float* Bs = smem + STAGES * BM * LDK;     // [STAGES][BN][LDK]
-
-    // ---- XCD-aware logical tile id (bijective for any grid size) ----
+// XCD-aware logical tile id (bijective for any grid size) -> (tile_m, tile_n), grouped GM tile-rows at a time
+__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, within = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-    // grouped order: GM tile-rows per group, tile_n slow, tile_m fast inside the group
     constexpr int GM = 8;
     const int per_group = GM * tiles_n;
     const int group = logical / per_group;
     const int first_m = group * GM;
     const int gsz = min(tiles_m - first_m, GM);
     const int in_group = logical - group * per_group;
-    const int tile_m = first_m + in_group % gsz;
-    const int tile_n = in_group / gsz;
-    const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+    tile_m = first_m + in_group % gsz;
+    tile_n = in_group / gsz;
+}
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave / WN) * TM * 32;
-    const int wn0 = (wave % WN) * TN * 32;
-    const int lrow = lane & 31, lhalf = lane >> 5;
-
-    // ---- global -> register staging ----
-    // Rows past M / N are clamped to a valid row and NOT zeroed: an output element depends only on its own
-    // A row and W row, and rows/cols past the edge are never stored, so their (duplicate) data is harmless.
-    // Keeping the loaded registers untouched lets the loads stay in flight across the barrier.
-    f32x4 ra[A_F4], rb[B_F4];
-    const float* Ag[A_F4];
-    const float* Wg[B_F4];
-#pragma unroll
-    for (int i = 0; i < A_F4; ++i) {
-        const int f = tid + i * NT, row = f >> 3, c4 = f & 7;
-        Ag[i] = a.A + (int64_t)min(bm0 + row, a.M - 1) * a.lda + c4 * 4;
-    }
-#pragma unroll
-    for (int i = 0; i < B_F4; ++i) {
-        const int f = tid + i * NT, row = f >> 3, c4 = f & 7;
-        Wg[i] = a.W + (int64_t)min(bn0 + row, a.N - 1) * a.ldw + c4 * 4;
-    }
-    auto load_global = [&](int kt) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(Ag[i] + k0);
-#pragma unroll
-        for (int i = 0; i < B_F4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(Wg[i] + k0);
-    };
-    auto store_lds = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            const int f = tid + i * NT, row = f >> 3, c4 = f & 7;
-            *reinterpret_cast<f32x4*>(&As[(buf * BM + row) * LDK + ((c4 ^ ((row >> 1) & 7)) << 2)]) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_F4; ++i) {
-            const int f = tid + i * NT, row = f >> 3, c4 = f & 7;
-            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + row) * LDK + ((c4 ^ ((row >> 1) & 7)) << 2)]) = rb[i];
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // swizzled float offset of logical slot (2j + lhalf) for this lane's rows (wm0, mi*32 are multiples of 16)
-    int koff[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) koff[j] = (((2 * j + lhalf) ^ ((lrow >> 1) & 7)) << 2);
-
-    f32x4 af[2][TM], bf[2][TN];
-    auto read_frags = [&](int buf, int j, int slot) {
-        const float* Ab = As + (buf * BM + wm0 + lrow) * LDK + koff[j];
-        const float* Bb = Bs + (buf * BN + wn0 + lrow) * LDK + koff[j];
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) af[slot][mi] = *reinterpret_cast<const f32x4*>(Ab + mi * 32 * LDK);
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) bf[slot][ni] = *reinterpret_cast<const f32x4*>(Bb + ni * 32 * LDK);
-    };
-
-    const int nk = a.K / BK;
-    // ---- prologue: STAGES-1 tiles in LDS, one more in registers ----
-    load_global(0);
-    store_lds(0);
-    if constexpr (STAGES == 3) {
-        load_global(min(1, nk - 1));
-        store_lds(1);
-        load_global(min(2, nk - 1));
-    } else {
-        load_global(min(1, nk - 1));
-    }
-    __syncthreads();
-    if constexpr (STAGES == 3) read_frags(0, 0, 0);
-
-    int buf = 0;                       // LDS buffer of tile kt
-    for (int kt = 0; kt < nk; ++kt) {
-        int wbuf = buf + (STAGES - 1);             // buffer receiving tile kt + STAGES - 1
-        if (wbuf >= STAGES) wbuf -= STAGES;
-        int nbuf = buf + 1;
-        if (nbuf >= STAGES) nbuf -= STAGES;
-        if constexpr (STAGES == 2) read_frags(buf, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if (j + 1 < NJ) read_frags(buf, j + 1, (j + 1) & 1);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][mi][t], bf[j & 1][ni][t],
-                                                                           acc[mi][ni], 0, 0, 0);
-            // staging in the MFMA shadow: registers -> LDS after the first k-group, next global loads after the second
-            // (unconditional: past the last tile the writes land in a buffer nobody reads again and the loads
-            //  re-read the last tile, which keeps the loop body branch-free)
-            if (j == 0) store_lds(wbuf);
-            if (j == 1) load_global(min(kt + STAGES, nk - 1));
-        }
-        if constexpr (STAGES == 3) {
-            // tile kt+1 was written during iteration kt-1, i.e. two barriers ago: safe to read before this barrier
-            if (kt + 1 < nk) read_frags(nbuf, 0, 0);
-        }
-        __syncthreads();
-        buf = nbuf;
-    }
-
-    // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
+// C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void store_tile(const GemmArgs& a, f32x16 (&acc)[TM][TN], int m0, int n0, int lrow, int lhalf) {
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
-            const int n = bn0 + wn0 + ni * 32 + lrow;
+            const int n = n0 + ni * 32 + lrow;
             const int nc = min(n, a.N - 1);
-            const int mbase = bm0 + wm0 + mi * 32 + 4 * lhalf;
+            const int mbase = m0 + mi * 32 + 4 * lhalf;
             float bias = 0.f;
             if constexpr (EPI != EPI_NONE) bias = a.bias[nc];
             float extra[16];
@@ -226,14 +108,182 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
     }
 }
 
-template <int WM, int WN, int TM, int TN, int STAGES>
+// DMA = true: global_load_lds staging; DMA = false: register staging
+template <int WM, int WN, int TM, int TN, bool DMA, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int tiles_m, int tiles_n) {
+    constexpr int NW = WM * WN;
+    constexpr int NT = NW * 64;
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int A_F4 = BM * 8 / NT;   // 16-byte pieces per thread per K tile (== wave instructions per wave)
+    constexpr int B_F4 = BN * 8 / NT;
+    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile/threads mismatch");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
+    float* As = smem;                    // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;     // [2][BN][LDK]
+
+    int tile_m, tile_n;
+    tile_coords(tiles_m, tiles_n, tile_m, tile_n);
+    const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / WN) * TM * 32;
+    const int wn0 = (wave % WN) * TN * 32;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+
+    // ---- staging addresses.  Piece i of this thread covers tile row `row`, physical slot `ps`.
+    // Rows past M / N are clamped to a valid row and NOT zeroed: an output element depends only on its own
+    // A row and W row, and rows/cols past the edge are never stored, so the duplicate data is harmless.
+    //   REG: thread f = tid + i*NT -> row f>>3, logical slot f&7, stored at slot (f&7) ^ swz(row)
+    //   DMA: wave instruction q = wave + i*NW covers rows 8q..8q+7; lane -> row 8q + (lane>>3), physical slot
+    //        lane&7, so it FETCHES logical slot (lane&7) ^ swz(row).
+    const float* Ag[A_F4];
+    const float* Wg[B_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+        int row, cs;
+        if constexpr (DMA) { row = (wave + i * NW) * 8 + (lane >> 3); cs = (lane & 7) ^ ((row >> 1) & 7); }
+        else { const int f = tid + i * NT; row = f >> 3; cs = f & 7; }
+        Ag[i] = a.A + (int64_t)min(bm0 + row, a.M - 1) * a.lda + cs * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+        int row, cs;
+        if constexpr (DMA) { row = (wave + i * NW) * 8 + (lane >> 3); cs = (lane & 7) ^ ((row >> 1) & 7); }
+        else { const int f = tid + i * NT; row = f >> 3; cs = f & 7; }
+        Wg[i] = a.W + (int64_t)min(bn0 + row, a.N - 1) * a.ldw + cs * 4;
+    }
+
+    // register staging path
+    f32x4 ra[DMA ? 1 : A_F4], rb[DMA ? 1 : B_F4];
+    auto load_global = [&](int kt) {
+        if constexpr (!DMA) {
+            const int k0 = kt * BK;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(Ag[i] + k0);
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(Wg[i] + k0);
+        }
+    };
+    auto store_lds = [&](int buf) {
+        if constexpr (!DMA) {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int f = tid + i * NT, row = f >> 3, c4 = f & 7;
+                *reinterpret_cast<f32x4*>(&As[(buf * BM + row) * LDK + ((c4 ^ ((row >> 1) & 7)) << 2)]) = ra[i];
+            }
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int f = tid + i * NT, row = f >> 3, c4 = f & 7;
+                *reinterpret_cast<f32x4*>(&Bs[(buf * BN + row) * LDK + ((c4 ^ ((row >> 1) & 7)) << 2)]) = rb[i];
+            }
+        }
+    };
+    // LDS-DMA path: one wave instruction moves 8 rows x 128 B = 1 KiB; LDS base is wave-uniform
+    auto dma_tile = [&](int kt, int buf) {
+        if constexpr (DMA) {
+            const int k0 = kt * BK;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(Ag[i] + k0),
+                                                 (lds_void*)(As + (buf * BM + (wave + i * NW) * 8) * LDK), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(Wg[i] + k0),
+                                                 (lds_void*)(Bs + (buf * BN + (wave + i * NW) * 8) * LDK), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // swizzled float offset of logical slot (2j + lhalf) for this lane's rows (wm0, mi*32 are multiples of 16)
+    int koff[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) koff[j] = (((2 * j + lhalf) ^ ((lrow >> 1) & 7)) << 2);
+
+    f32x4 af[2][TM], bf[2][TN];
+    auto read_frags = [&](int buf, int j, int slot) {
+        const float* Ab = As + (buf * BM + wm0 + lrow) * LDK + koff[j];
+        const float* Bb = Bs + (buf * BN + wn0 + lrow) * LDK + koff[j];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) af[slot][mi] = *reinterpret_cast<const f32x4*>(Ab + mi * 32 * LDK);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) bf[slot][ni] = *reinterpret_cast<const f32x4*>(Bb + ni * 32 * LDK);
+    };
+
+    const int nk = a.K / BK;
+    // ---- prologue: tile 0 in LDS (REG: tile 1 already in flight to registers) ----
+    if constexpr (DMA) {
+        dma_tile(0, 0);
+    } else {
+        load_global(0);
+        store_lds(0);
+        load_global(min(1, nk - 1));
+    }
+    __syncthreads();    // with LDS-DMA pending this is s_waitcnt vmcnt(0) + s_barrier
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        // DMA: tile kt+1 goes straight into the other buffer (last read in iteration kt-1, barrier passed);
+        // past the last tile the copy re-reads the last tile into a buffer nobody reads (keeps the body branch-free)
+        if constexpr (DMA) dma_tile(min(kt + 1, nk - 1), buf ^ 1);
+        read_frags(buf, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j + 1 < NJ) read_frags(buf, j + 1, (j + 1) & 1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][mi][t], bf[j & 1][ni][t],
+                                                                           acc[mi][ni], 0, 0, 0);
+            if constexpr (!DMA) {
+                // staging in the MFMA shadow: registers -> LDS after the first k-group, next loads after the second
+                if (j == 0) store_lds(buf ^ 1);
+                if (j == 1) load_global(min(kt + 2, nk - 1));
+            }
+        }
+        if constexpr (DMA) {
+            // Pin the issue order of this K tile (hipcc otherwise sinks the fragment prefetch below the MFMAs it
+            // should hide under):  DMA copies | frags(0) | 3 x { (MFMA, ds_read) x (TM+TN), rest of the MFMAs } | MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x010, A_F4 + B_F4, 0);        // VMEM: global_load_lds
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);            // DS read: fragments of k-group 0
+#pragma unroll
+            for (int j = 0; j + 1 < NJ; ++j) {
+#pragma unroll
+                for (int r = 0; r < TM + TN; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // DS read: one fragment of k-group j+1
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN - (TM + TN), 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+        }
+        __syncthreads();
+    }
+
+    store_tile<TM, TN, EPI>(a, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
+}
+
+template <int WM, int WN, int TM, int TN, bool DMA>
 int launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
-#define THMR_GEMM_CASE(E)                                                                                         \
-    case E:                                                                                                       \
-        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, STAGES, E>), grid, block, 0, s, a, tiles_m, tiles_n); \
+#define THMR_GEMM_CASE(E)                                                                                      \
+    case E:                                                                                                    \
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, DMA, E>), grid, block, 0, s, a, tiles_m, tiles_n); \
         break;
     switch (epi) {
         THMR_GEMM_CASE(EPI_NONE)
@@ -260,24 +310,21 @@ inline double tile_efficiency(int M, int N, int BM, int BN) {
 
 }  // namespace
 
-// variant: 0 = 128x128 2-stage (2x2 waves of 64x64)      1 = 128x160 2-stage (4x1 waves of 32x160)
-//          3 = 128x128 3-stage                            4 = 128x160 3-stage
-//          5 = 256x128 3-stage (2x2 waves of 128x64)      6 = 256x128 2-stage
-//         -1 = pick by tile quantisation over 256 CUs     (2 is the skinny kernel, see thmr_op_gemm)
+// variant: 0 = 128x128 REG (2x2 waves of 64x64)   1 = 128x160 REG (4x1 waves of 32x160)
+//          7 = 128x128 DMA                         8 = 128x160 DMA
+//         -1 = DMA, tile picked by quantisation over 256 CUs   (2 is the skinny kernel, see thmr_op_gemm)
 int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % BK) != 0) return -1;
     if ((a.lda % 4) != 0 || (a.ldw % 4) != 0) return -1;
     if (variant < 0) {
         const double e0 = tile_efficiency(a.M, a.N, 128, 128);
         const double e1 = tile_efficiency(a.M, a.N, 128, 160);
-        variant = (e1 > e0 * 1.02) ? 1 : 0;
+        variant = (e1 > e0 * 1.02) ? 8 : 7;
     }
     switch (variant) {
-        case 1: return launch_cfg<4, 1, 1, 5, 2>(a, epi, s);
-        case 3: return launch_cfg<2, 2, 2, 2, 3>(a, epi, s);
-        case 4: return launch_cfg<4, 1, 1, 5, 3>(a, epi, s);
-        case 5: return launch_cfg<2, 2, 4, 2, 3>(a, epi, s);
-        case 6: return launch_cfg<2, 2, 4, 2, 2>(a, epi, s);
-        default: return launch_cfg<2, 2, 2, 2, 2>(a, epi, s);
+        case 0: return launch_cfg<2, 2, 2, 2, false>(a, epi, s);
+        case 1: return launch_cfg<4, 1, 1, 5, false>(a, epi, s);
+        case 8: return launch_cfg<4, 1, 1, 5, true>(a, epi, s);
+        default: return launch_cfg<2, 2, 2, 2, true>(a, epi, s);
     }
 }
