@@ -178,6 +178,17 @@ def main():
                     "all_gemm_achieved": round(all_tf, 2), "all_gemm_frac": round(all_tf / PEAK_F32_MFMA_TFLOPS, 4),
                     "path_tflops": round(value / world * GFLOP_PER_CROP[a.workload] / 1e3, 2),
                     "classes_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in prof.items() if v["launches"]}}
+            # HBM traffic of that kernel from PMC counters (separate rocprofv3 --pmc passes, committed under profiles/;
+            # FETCH_SIZE doubled per the gfx950 correction) — cannot be collected live inside this process
+            try:
+                with open(os.path.join(ROOT, "profiles", "r1_pmc_gemm.json")) as f:
+                    pmc = json.load(f).get(dom.replace("gemm_", ""))
+                if pmc and a.batch == 64:
+                    roof["traffic"] = round(pmc["traffic_bytes"])
+                    roof["traffic_unit"] = "bytes/launch (FETCH_SIZE*2 + WRITE_SIZE, profiles/r1_pmc_gemm.json)"
+                    roof["algorithmic_bytes_per_launch"] = pmc["algorithmic_bytes"]
+            except (OSError, ValueError, KeyError):
+                pass
             lbs = prof.get("lbs")
             if lbs and lbs["launches"]:
                 gbs = lbs["bytes"] / (lbs["ms"] * 1e-3) / 1e9

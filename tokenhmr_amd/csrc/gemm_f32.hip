@@ -241,7 +241,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
         else
             bf[slot][f - TM] = *reinterpret_cast<const f32x4*>(Bs + (buf * BN + wn0 + lrow + (f - TM) * 32) * LDK + koff[j]);
     };
-    static_assert(!DMA || NP + TM + TN <= 4 * TM * TN, "k-group 0 too short for the staging interleave");
+    constexpr int G = 4 * TM * TN;                                   // MFMAs per k-group
+    constexpr int OFF0 = (NP < G - (TM + TN)) ? NP : G - (TM + TN);  // where the fragment prefetch starts in k-group 0
+    static_assert(TM + TN <= G && NP <= NJ * G, "tile too small for the staging interleave");
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -265,14 +267,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
                             const int idx = (t * TM + mi) * TN + ni;          // compile-time after unrolling
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][mi][t], bf[j & 1][ni][t],
                                                                                acc[mi][ni], 0, 0, 0);
-                            const int ridx = idx - (j == 0 ? NP : 0);         // slot in the fragment-prefetch run
-                            if (j == 0 && idx < NP) {
-                                dma_piece(ktn, buf ^ 1, idx);
-                                __builtin_amdgcn_sched_barrier(0);
-                            } else if (j + 1 < NJ && ridx >= 0 && ridx < TM + TN) {
-                                read_one(buf, j + 1, (j + 1) & 1, ridx);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
+                            const int g = j * G + idx;                        // MFMA index within the K tile
+                            const int ridx = idx - (j == 0 ? OFF0 : 0);       // slot in the fragment-prefetch run
+                            const bool do_dma = g < NP;
+                            const bool do_read = j + 1 < NJ && ridx >= 0 && ridx < TM + TN;
+                            if (do_dma) dma_piece(ktn, buf ^ 1, g);
+                            if (do_read) read_one(buf, j + 1, (j + 1) & 1, ridx);
+                            if (do_dma || do_read) __builtin_amdgcn_sched_barrier(0);
                         }
             }
         } else {
@@ -334,20 +335,26 @@ inline double tile_efficiency(int M, int N, int BM, int BN) {
 }  // namespace
 
 // variant: 0 = 128x128 REG (2x2 waves of 64x64)   1 = 128x160 REG (4x1 waves of 32x160)
-//          7 = 128x128 DMA                         8 = 128x160 DMA
-//         -1 = DMA, tile picked by quantisation over 256 CUs   (2 is the skinny kernel, see thmr_op_gemm)
+//          7 = 128x128 DMA                         8 = 128x160 DMA            9 = 64x64 DMA (2x2 waves of 32x32)
+//         -1 = DMA, tile picked by a cost model over 256 CUs   (2 is the skinny kernel, see thmr_op_gemm)
 int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % BK) != 0) return -1;
     if ((a.lda % 4) != 0 || (a.ldw % 4) != 0) return -1;
     if (variant < 0) {
-        const double e0 = tile_efficiency(a.M, a.N, 128, 128);
-        const double e1 = tile_efficiency(a.M, a.N, 128, 160);
-        variant = (e1 >= e0 * 0.98) ? 8 : 7;      // 128x160 is 2-5 % faster at equal quantisation (measured)
+        // relative time ~ (rounds over 256 CUs) x tile area / tile efficiency; small grids (the VQ decoder's
+        // M = B*21 convs) cannot fill 256 CUs with big tiles and are latency-bound -> 64x64 tiles
+        auto cost = [&](int BM, int BN, double eff) {
+            const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+            return (double)((tiles + 255) / 256) * BM * BN / eff;
+        };
+        const double c7 = cost(128, 128, 0.97), c8 = cost(128, 160, 1.0), c9 = cost(64, 64, 0.80);
+        variant = (c8 <= c7 && c8 <= c9) ? 8 : (c7 <= c9 ? 7 : 9);
     }
     switch (variant) {
         case 0: return launch_cfg<2, 2, 2, 2, false>(a, epi, s);
         case 1: return launch_cfg<4, 1, 1, 5, false>(a, epi, s);
         case 8: return launch_cfg<4, 1, 1, 5, true>(a, epi, s);
+        case 9: return launch_cfg<2, 2, 1, 1, true>(a, epi, s);
         default: return launch_cfg<2, 2, 2, 2, true>(a, epi, s);
     }
 }
