@@ -163,6 +163,30 @@ int thmr_op_vit_attention(const float* qkv_dev, float* out_dev /*(B,192,1280)*/,
 /* rot6d_to_rotmat (geometry.py:64-84): (n,6) -> (n,3,3) */
 int thmr_op_rot6d(const float* x_dev, float* R_dev, int32_t n, void* stream);
 
+/* Stand-alone SMPL model: the GT-side meshes the reference computes per sample on the CPU with
+ * smplx.SMPL(gender) inside dataset workers (tokenhmr/lib/datasets/image_dataset.py:151-164,254-270, emdb_dataset.py:184-199)
+ * reuse the LBS kernels with their own (male / female) constants.
+ *   pose2rot = 0: pose_dev is (B,24,3,3) rotation matrices; 1: (B,72) axis-angle, converted by smplx batch_rodrigues. */
+typedef struct thmr_smpl thmr_smpl;
+int  thmr_smpl_create(const thmr_smpl_desc* desc, int32_t max_batch, int32_t device, thmr_smpl** out);
+void thmr_smpl_destroy(thmr_smpl* m);
+int  thmr_smpl_forward(thmr_smpl* m, const float* pose_dev, int32_t pose2rot, const float* betas_dev, int32_t B,
+                       float* verts_dev /*(B,6890,3)*/, float* joints_dev /*(B,44,3) or NULL*/, void* stream);
+
+/* Evaluation metrics right after the hot path — stateless, all buffers device-side.
+ * Replaces compute_similarity_transform / eval_pose and the arithmetic of Evaluator.__call__
+ * (tokenhmr/lib/utils/pose_utils.py:61-143, :201-275): pelvis alignment, MPJPE, PA-MPJPE (3x3 SVD Procrustes), PVE, in mm.
+ *   pred_joints (B,n_joints,3); gt_joints (B,n_joints,gt_stride) (gt_stride = 4 for batch['keypoints_3d'] with its confidence column)
+ *   pelvis_mode 0: joint pelvis_ind; 1: (joint1 + joint2)/2 (EMDB branch).  verts may be NULL (no PVE).
+ *   pelvis_scratch (B,6) receives [pred_pelvis | gt_pelvis]. */
+int thmr_eval_pose(const float* pred_joints_dev, const float* gt_joints_dev, int32_t n_joints, int32_t gt_stride,
+                   const int32_t* kp_list_dev, int32_t n_kp, int32_t pelvis_ind, int32_t pelvis_mode,
+                   const float* pred_verts_dev, const float* gt_verts_dev, int32_t n_verts, int32_t B,
+                   float* mpjpe_mm_dev, float* re_mm_dev, float* pve_mm_dev, float* pelvis_scratch_dev, void* stream);
+/* joints = J (n_joints,n_verts) @ verts (B,n_verts,3): J_regressor_24_SMPL of the EMDB branch (pose_utils.py:212,219) */
+int thmr_regress_joints(const float* J_dev, const float* verts_dev, int32_t n_joints, int32_t n_verts, int32_t B,
+                        float* out_dev, void* stream);
+
 /* Built-in profiler: HIP events recorded on the launch stream around each kernel class. */
 int thmr_prof_enable(thmr_engine* e, int32_t on);
 int thmr_prof_collect(thmr_engine* e, thmr_prof_entry* entries /*[THMR_PROF_NUM]*/, int32_t reset);

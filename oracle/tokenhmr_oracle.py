@@ -251,6 +251,27 @@ def smpl_forward(global_orient, body_pose, betas, smpl):
     return verts, torch.cat([joints, extra], dim=1)
 
 
+def batch_rodrigues(rot_vecs, epsilon=1e-8):
+    """smplx.lbs.batch_rodrigues (smplx==0.1.28; un-vendored -> restated, UNPINNED): (N,3) axis-angle -> (N,3,3)."""
+    N = rot_vecs.shape[0]
+    angle = torch.norm(rot_vecs + epsilon, dim=1, keepdim=True)
+    rot_dir = rot_vecs / angle
+    cos, sin = torch.cos(angle).unsqueeze(1), torch.sin(angle).unsqueeze(1)
+    rx, ry, rz = torch.split(rot_dir, 1, dim=1)
+    zeros = torch.zeros(N, 1, dtype=rot_vecs.dtype)
+    K = torch.cat([zeros, -rz, ry, rz, zeros, -rx, -ry, rx, zeros], dim=1).view(N, 3, 3)
+    ident = torch.eye(3, dtype=rot_vecs.dtype).unsqueeze(0)
+    return ident + sin * K + (1 - cos) * torch.bmm(K, K)
+
+
+def smpl_forward_axis_angle(global_orient, body_pose, betas, smpl):
+    """smplx.SMPL.forward(pose2rot=True) as used for GT meshes (tokenhmr/lib/datasets/image_dataset.py:254-270)."""
+    B = betas.shape[0]
+    full = torch.cat([global_orient.reshape(B, 3), body_pose.reshape(B, 69)], dim=1)
+    R = batch_rodrigues(full.reshape(-1, 3)).view(B, 24, 3, 3)
+    return smpl_forward(R[:, :1], R[:, 1:], betas, smpl)
+
+
 # --------------------------------------------------------------------------- full path
 def head_forward(ctx, sd, tok, cfg: HMRConfig = RELEASE):
     """token_head.py:65-128 SMPLTokenDecoderHead.forward (IEF_ITERS=1, zero token)."""

@@ -260,3 +260,27 @@ def test_errors_are_loud(small):
         e.finalize()                                                                     # strict: missing tensor
     with pytest.raises(KeyError):
         e.load_state({"backbone.not_a_tensor": torch.zeros(1)})
+
+
+def test_standalone_smpl_gt_meshes(built_lib, cuda_dev):
+    """GT-side SMPL from axis-angle parameters (smplx.SMPL pose2rot=True path of the dataset code),
+    batched on the GPU with gendered constants, vs the restated smplx oracle (unpinned boundary).  Tolerance 1e-4 m."""
+    from oracle import tokenhmr_oracle as O
+    from tokenhmr_amd.smpl import SMPL
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    from tokenhmr_amd.config import RELEASE
+    g = torch.Generator().manual_seed(21)
+    for seed in (1, 2):                                      # "male" / "female" constants
+        consts = make_synthetic_smpl(RELEASE, seed)
+        m = SMPL(consts, max_batch=40, device=cuda_dev)
+        B = 37
+        go, bp, betas = 2.0 * torch.randn(B, 3, generator=g), 0.5 * torch.randn(B, 69, generator=g), torch.randn(B, 10, generator=g)
+        bp[0] = 0.0                                          # zero rotation: exercises the +1e-8 epsilon of batch_rodrigues
+        out = m(global_orient=go, body_pose=bp, betas=betas)
+        rv, rj = O.smpl_forward_axis_angle(go, bp, betas, consts)
+        assert (out.vertices.cpu() - rv).abs().max() < 1e-4
+        assert (out.joints.cpu() - rj).abs().max() < 1e-4
+        R = O.batch_rodrigues(torch.cat([go, bp], 1).reshape(-1, 3)).view(B, 24, 3, 3)
+        out2 = m(global_orient=R[:, :1], body_pose=R[:, 1:], betas=betas, pose2rot=False)
+        assert (out2.vertices.cpu() - rv).abs().max() < 1e-4
+        m.close()

@@ -92,11 +92,17 @@ def load():
     lib.thmr_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, i32, vp]
     lib.thmr_op_vit_attention.argtypes = [vp, vp, i32, vp]
     lib.thmr_op_rot6d.argtypes = [vp, vp, i32, vp]
+    lib.thmr_smpl_create.argtypes = [C.POINTER(SmplDesc), i32, i32, C.POINTER(vp)]
+    lib.thmr_smpl_destroy.argtypes = [vp]
+    lib.thmr_smpl_destroy.restype = None
+    lib.thmr_smpl_forward.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
+    lib.thmr_eval_pose.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.thmr_regress_joints.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.thmr_prof_enable.argtypes = [vp, i32]
     lib.thmr_prof_collect.argtypes = [vp, C.POINTER(ProfEntry), i32]
     for name in declared_symbols():
         fn = getattr(lib, name)
-        if name not in ("thmr_build_info", "thmr_last_error", "thmr_destroy"):
+        if name not in ("thmr_build_info", "thmr_last_error", "thmr_destroy", "thmr_smpl_destroy"):
             fn.restype = C.c_int
     if lib.thmr_abi_version() != ABI_VERSION:
         raise RuntimeError("libtokenhmr_hip.so ABI version mismatch")

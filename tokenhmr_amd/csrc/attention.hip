@@ -14,8 +14,9 @@
 //                trick, B = Q fragments held in registers).  The swapped product leaves every query's
 //                192 scores in 4 lanes x 48 registers, so row max/sum are 47 in-lane ops + 2 xor-shuffles.
 //   P = softmax  fp32; exp(x) = v_exp_f32(x * log2 e) (1 ulp) and one reciprocal per row.
-//   O = P V      P registers are directly the MFMA A operand (lane group g <-> key 16*kt + 4g + r);
-//                V rows come from LDS with conflict-free ds_read_b32 (row stride 84).
+//   O^T = V^T P^T  P registers are directly the MFMA B operand (lane group g <-> key 16*kt + 4g + r); V rows come
+//                from LDS with conflict-free ds_read_b32 (row stride 84); each lane ends with 4 consecutive d of one
+//                query, so the output goes out as 16-byte stores.
 // d = 80 = 5 tiles of 16 and 80 = 20 k-steps of 4: the 16x16x4 shape wastes no MFMA work.
 #include "common.h"
 
@@ -121,7 +122,8 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
     }
     __syncthreads();
 
-    // ---- O = P V: A[i = query l15][kslot g] = P register, B[kslot g][j = d] = V[16 kt + 4 g + r][16 dt + l15] ----
+    // ---- O^T = V^T P^T: A[i = d l15][kslot g] = V[16 kt + 4 g + r][16 dt + l15], B[kslot g][j = query l15] = P register.
+    //      The transposed product leaves each lane with 4 CONSECUTIVE d of one query -> 16-byte output stores. ----
     f32x4 o[3][5];
 #pragma unroll
     for (int qt = 0; qt < 3; ++qt)
@@ -138,20 +140,18 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
                 const float vb = vrow[dt * 16];
 #pragma unroll
                 for (int qt = 0; qt < 3; ++qt)
-                    o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(s[qt][kt][r], vb, o[qt][dt], 0, 0, 0);
+                    o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb, s[qt][kt][r], o[qt][dt], 0, 0, 0);
             }
         }
     }
 
-    // ---- store: D layout of 16x16: col = lane&15 -> d, row = 4*(lane>>4) + reg -> query ----
+    // ---- store: D layout of 16x16: col = lane&15 -> query, row = 4*(lane>>4) + reg -> d  (one float4 per tile) ----
     float* obase = out + (int64_t)b * NTOK * DIM + h * HD;
 #pragma unroll
     for (int qt = 0; qt < 3; ++qt)
 #pragma unroll
         for (int dt = 0; dt < 5; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                obase[(int64_t)(q0 + qt * 16 + g * 4 + r) * DIM + dt * 16 + l15] = o[qt][dt][r];
+            *reinterpret_cast<f32x4*>(obase + (int64_t)(q0 + qt * 16 + l15) * DIM + dt * 16 + g * 4) = o[qt][dt];
 }
 
 }  // namespace

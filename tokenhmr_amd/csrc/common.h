@@ -96,3 +96,9 @@ int launch_lbs(const float* rotmat, const float* betas, const float* cam_t, cons
                const int32_t* parents, const float* vt, const float* sd, const float* pd, const float* W,
                const float* J19, const int32_t* extra, const int32_t* jmap, float* A, float* pf, float* Jtr, float* verts,
                float* joints, float* kp2d, float focal_over_size, int B, hipStream_t s);
+int launch_rodrigues(const float* aa, float* R, int n, hipStream_t s);
+// eval.hip
+int launch_eval_pose(const float* pred, const float* gt, int nj, int gt_stride, const int32_t* kp, int nkp, int pelvis_ind,
+                     int pelvis_mode, float* mpjpe, float* re, float* pelv, int B, hipStream_t s);
+int launch_eval_pve(const float* pv, const float* gv, const float* pelv, int nv, float* pve, int B, hipStream_t s);
+int launch_regress_joints(const float* J, const float* verts, int nj, int nv, float* out, int B, hipStream_t s);

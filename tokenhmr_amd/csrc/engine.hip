@@ -803,6 +803,97 @@ int thmr_op_rot6d(const float* x, float* R, int32_t n, void* stream) {
     return 0;
 }
 
+// ---- stand-alone SMPL model ----
+struct thmr_smpl {
+    float* mem = nullptr;
+    int max_batch = 0;
+    size_t o_vt, o_sd, o_pd, o_jr, o_w, o_j19, o_int, o_jt, o_jsd, o_A, o_pf, o_Jtr, o_rot, o_joints, total;
+};
+
+int thmr_smpl_create(const thmr_smpl_desc* d, int32_t max_batch, int32_t device, thmr_smpl** out) {
+    thmr_engine* e = nullptr;
+    if (!d || !out || max_batch < 1) return fail(e, THMR_ERR_INVALID, "bad argument");
+    *out = nullptr;
+    if (!d->v_template || !d->shapedirs || !d->posedirs || !d->J_regressor || !d->lbs_weights || !d->J19_regressor ||
+        !d->parents || !d->extra_verts || !d->joint_map)
+        return fail(e, THMR_ERR_INVALID, "thmr_smpl_desc has a null field");
+    HIP_OK(hipSetDevice(device));
+    thmr_smpl* m = new thmr_smpl();
+    m->max_batch = max_batch;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off = align64(off + n); return o; };
+    m->o_vt = take((size_t)NV * 3); m->o_sd = take((size_t)NV * 30); m->o_pd = take((size_t)NP * NV * 3);
+    m->o_jr = take((size_t)NJ * NV); m->o_w = take((size_t)NV * NJ); m->o_j19 = take((size_t)19 * NV);
+    m->o_int = take(128); m->o_jt = take(NJ * 3); m->o_jsd = take(NJ * 30);
+    const size_t B = (size_t)max_batch;
+    m->o_A = take(B * NJ * 12); m->o_pf = take(B * NP + 1); m->o_Jtr = take(B * NJ * 3); m->o_rot = take(B * NJ * 9);
+    m->o_joints = take(B * 132);
+    m->total = off;
+    if (hipMalloc(&m->mem, off * sizeof(float)) != hipSuccess) { delete m; return fail(e, THMR_ERR_NOMEM, "hipMalloc(smpl) failed"); }
+    const hipMemcpyKind k = d->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    auto cp = [&](size_t o, const void* src, size_t bytes) { return hipMemcpy(m->mem + o, src, bytes, k) == hipSuccess; };
+    int32_t* ints = reinterpret_cast<int32_t*>(m->mem + m->o_int);
+    bool ok = cp(m->o_vt, d->v_template, sizeof(float) * NV * 3) && cp(m->o_sd, d->shapedirs, sizeof(float) * NV * 30) &&
+              cp(m->o_pd, d->posedirs, sizeof(float) * (size_t)NP * NV * 3) && cp(m->o_jr, d->J_regressor, sizeof(float) * NJ * NV) &&
+              cp(m->o_w, d->lbs_weights, sizeof(float) * NV * NJ) && cp(m->o_j19, d->J19_regressor, sizeof(float) * 19 * NV) &&
+              hipMemcpy(ints, d->parents, sizeof(int32_t) * 24, k) == hipSuccess &&
+              hipMemcpy(ints + 24, d->extra_verts, sizeof(int32_t) * 21, k) == hipSuccess &&
+              hipMemcpy(ints + 48, d->joint_map, sizeof(int32_t) * 25, k) == hipSuccess;
+    if (!ok || launch_lbs_jreg(m->mem + m->o_jr, m->mem + m->o_vt, m->mem + m->o_sd, m->mem + m->o_jt, m->mem + m->o_jsd, nullptr) != 0 ||
+        hipDeviceSynchronize() != hipSuccess) {
+        thmr_smpl_destroy(m);
+        return fail(e, THMR_ERR_HIP, "SMPL constant upload failed");
+    }
+    *out = m;
+    return 0;
+}
+
+void thmr_smpl_destroy(thmr_smpl* m) {
+    if (!m) return;
+    if (m->mem) (void)hipFree(m->mem);
+    delete m;
+}
+
+int thmr_smpl_forward(thmr_smpl* m, const float* pose, int32_t pose2rot, const float* betas, int32_t B, float* verts,
+                      float* joints, void* stream) {
+    thmr_engine* e = nullptr;
+    if (!m || !pose || !betas || !verts) return fail(e, THMR_ERR_INVALID, "null argument");
+    if (B < 1 || B > m->max_batch) return fail(e, THMR_ERR_INVALID, "batch outside [1, max_batch]");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float* rot = pose;
+    if (pose2rot) {
+        LAUNCH_OK(launch_rodrigues(pose, m->mem + m->o_rot, B * NJ, st));
+        rot = m->mem + m->o_rot;
+    }
+    const int32_t* ints = reinterpret_cast<const int32_t*>(m->mem + m->o_int);
+    LAUNCH_OK(launch_lbs(rot, betas, nullptr, m->mem + m->o_jt, m->mem + m->o_jsd, ints, m->mem + m->o_vt, m->mem + m->o_sd,
+                         m->mem + m->o_pd, m->mem + m->o_w, m->mem + m->o_j19, ints + 24, ints + 48, m->mem + m->o_A,
+                         m->mem + m->o_pf, m->mem + m->o_Jtr, verts, joints ? joints : m->mem + m->o_joints, nullptr,
+                         FOCAL / IMG, B, st));
+    return 0;
+}
+
+// ---- evaluation metrics (stateless) ----
+int thmr_eval_pose(const float* pred_j, const float* gt_j, int32_t nj, int32_t gt_stride, const int32_t* kp, int32_t nkp,
+                   int32_t pelvis_ind, int32_t pelvis_mode, const float* pred_v, const float* gt_v, int32_t nv, int32_t B,
+                   float* mpjpe, float* re, float* pve, float* pelv, void* stream) {
+    thmr_engine* e = nullptr;
+    if (!pred_j || !gt_j || !kp || !mpjpe || !re || !pelv) return fail(e, THMR_ERR_INVALID, "null buffer");
+    if (nkp < 1 || nkp > 64 || gt_stride < 3 || B < 1 || pelvis_ind < 0 || pelvis_ind >= nj || nj < 3)
+        return fail(e, THMR_ERR_INVALID, "bad evaluator arguments (1 <= n_kp <= 64, gt_stride >= 3)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    LAUNCH_OK(launch_eval_pose(pred_j, gt_j, nj, gt_stride, kp, nkp, pelvis_ind, pelvis_mode, mpjpe, re, pelv, B, st));
+    if (pred_v && gt_v && pve) LAUNCH_OK(launch_eval_pve(pred_v, gt_v, pelv, nv, pve, B, st));
+    return 0;
+}
+
+int thmr_regress_joints(const float* J, const float* verts, int32_t nj, int32_t nv, int32_t B, float* out, void* stream) {
+    thmr_engine* e = nullptr;
+    if (!J || !verts || !out || nj < 1 || nv < 1 || B < 1) return fail(e, THMR_ERR_INVALID, "bad argument");
+    LAUNCH_OK(launch_regress_joints(J, verts, nj, nv, out, B, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 // ---- profiler ----
 int thmr_prof_enable(thmr_engine* e, int32_t on) {
     if (!e) return fail(e, THMR_ERR_INVALID, "null engine");

@@ -228,7 +228,32 @@ __global__ __launch_bounds__(256) void lbs_joints_kernel(const float* __restrict
     }
 }
 
+// smplx.lbs.batch_rodrigues (smplx==0.1.28, pose2rot=True path used for GT meshes, image_dataset.py:254-270):
+//   angle = ||r + 1e-8||, dir = r / angle, R = I + sin(angle) K + (1 - cos(angle)) K^2,  K = [dir]_x
+__global__ void rodrigues_kernel(const float* __restrict__ aa, float* __restrict__ R, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = aa[i * 3 + 0], y = aa[i * 3 + 1], z = aa[i * 3 + 2];
+    const float ex = x + 1e-8f, ey = y + 1e-8f, ez = z + 1e-8f;
+    const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float rx = x / angle, ry = y / angle, rz = z / angle;
+    const float s = sinf(angle), c = cosf(angle), oc = 1.0f - c;
+    // K^2 = dir dir^T - I (|dir| = 1 up to the epsilon), written out as smplx's bmm(K, K)
+    const float k2[9] = {-(rz * rz) - ry * ry, rx * ry, rx * rz,
+                         rx * ry, -(rz * rz) - rx * rx, ry * rz,
+                         rx * rz, ry * rz, -(ry * ry) - rx * rx};
+    const float k1[9] = {0.f, -rz, ry, rz, 0.f, -rx, -ry, rx, 0.f};
+    float* o = R + (int64_t)i * 9;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) o[e] = ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f) + s * k1[e] + oc * k2[e];
+}
+
 }  // namespace
+
+int launch_rodrigues(const float* aa, float* R, int n, hipStream_t s) {
+    hipLaunchKernelGGL(rodrigues_kernel, dim3((n + 255) / 256), dim3(256), 0, s, aa, R, n);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 int launch_lbs_jreg(const float* Jreg, const float* vt, const float* sd, float* Jt, float* Jsd, hipStream_t s) {
     hipLaunchKernelGGL(lbs_jreg_kernel, dim3(NJ, 33), dim3(256), 0, s, Jreg, vt, sd, Jt, Jsd);

@@ -1,0 +1,116 @@
+"""GPU-side mirror of the reference's `Evaluator` (tokenhmr/lib/utils/pose_utils.py:145-275).
+
+Same constructor arguments, `__call__(output, batch)`, `log()`, `get_metrics_dict()`, `get_imgnames()` and the same
+metric arrays (`mode_mpjpe`, `mode_re`, `mode_pve`, millimetres) — but pelvis alignment, MPJPE, the batched 3x3-SVD
+Procrustes and PVE run in libtokenhmr_hip.so (thmr_eval_pose / thmr_regress_joints) on the tensors the hot path just
+produced, so only 3 floats per crop are copied to the host instead of (B,6890,3) vertices (pose_utils.py:139-143,246).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _cabi
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def eval_pose_gpu(pred_joints, gt_joints, keypoint_list, pelvis_ind, pelvis_mode=0, pred_vertices=None, gt_vertices=None):
+    """Returns (mpjpe_mm, re_mm, pve_mm or None) as CUDA float32 tensors of shape (B,)."""
+    dev = pred_joints.device
+    if dev.type != "cuda":
+        raise RuntimeError("evaluator kernels run on the GPU only (no CPU fallback)")
+    pj = pred_joints.detach().float().contiguous()
+    gj = gt_joints.detach().float().contiguous()
+    B, nj = pj.shape[0], pj.shape[1]
+    if gj.shape[:2] != (B, nj) or pj.shape[2] != 3 or gj.shape[2] not in (3, 4):
+        raise ValueError(f"bad joint shapes {tuple(pj.shape)} / {tuple(gj.shape)}")
+    kp = torch.as_tensor(list(keypoint_list), dtype=torch.int32, device=dev)
+    mp = torch.empty(B, device=dev, dtype=torch.float32)
+    re = torch.empty(B, device=dev, dtype=torch.float32)
+    pelv = torch.empty(B, 6, device=dev, dtype=torch.float32)
+    pv = gv = pve = None
+    nv = 0
+    if pred_vertices is not None and gt_vertices is not None:
+        pv = pred_vertices.detach().float().contiguous()
+        gv = gt_vertices.detach().float().contiguous()
+        nv = pv.shape[1]
+        pve = torch.empty(B, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _cabi.check(_cabi.load().thmr_eval_pose(_p(pj), _p(gj), nj, gj.shape[2], _p(kp), kp.numel(), int(pelvis_ind),
+                                               int(pelvis_mode), _p(pv), _p(gv), nv, B, _p(mp), _p(re), _p(pve), _p(pelv), st))
+    return mp, re, pve
+
+
+def regress_joints_gpu(J, verts):
+    """(nj,nv) @ (B,nv,3) -> (B,nj,3) on the GPU."""
+    J = J.detach().float().contiguous()
+    v = verts.detach().float().contiguous()
+    B, nv = v.shape[0], v.shape[1]
+    out = torch.empty(B, J.shape[0], 3, device=v.device, dtype=torch.float32)
+    with torch.cuda.device(v.device):
+        st = C.c_void_p(torch.cuda.current_stream(v.device).cuda_stream)
+        _cabi.check(_cabi.load().thmr_regress_joints(_p(J), _p(v), J.shape[0], nv, B, _p(out), st))
+    return out
+
+
+class Evaluator:
+    def __init__(self, dataset_length, keypoint_list, pelvis_ind, metrics=("mode_mpjpe", "mode_re", "model_pve"),
+                 J_regressor_24_SMPL=None, dataset=""):
+        self.dataset_length = dataset_length
+        self.keypoint_list = list(keypoint_list)
+        self.pelvis_ind = pelvis_ind
+        self.metrics = list(metrics)
+        self.J_regressor_24_SMPL = J_regressor_24_SMPL
+        self.dataset = dataset
+        for m in self.metrics:
+            setattr(self, m, np.zeros((dataset_length,)))
+        self.counter = 0
+        self.imgnames = []
+
+    def log(self):
+        if self.counter == 0:
+            print("Evaluation has not started")
+            return
+        print(f"{self.counter} / {self.dataset_length} samples")
+        for m in self.metrics:
+            unit = "mm" if m in ("mode_mpjpe", "mode_re", "mode_pve") else ""
+            print(f"{m}: {getattr(self, m)[:self.counter].mean(0)} {unit}")
+        print("***")
+
+    def get_metrics_dict(self):
+        return {m: getattr(self, m)[:self.counter].mean() for m in self.metrics}
+
+    def get_imgnames(self):
+        return self.imgnames
+
+    def __call__(self, output, batch):
+        self.imgnames += list(batch.get("imgname", []))
+        want_pve = hasattr(self, "mode_pve")
+        if "EMDB" in self.dataset:                                  # pose_utils.py:209-222
+            gt_v, pred_v = batch["vertices"], output["pred_vertices"]
+            gt_j = regress_joints_gpu(self.J_regressor_24_SMPL, gt_v)
+            pred_j = regress_joints_gpu(self.J_regressor_24_SMPL, pred_v)
+            mp, re, pve = eval_pose_gpu(pred_j, gt_j, self.keypoint_list, 0, 1, pred_v if want_pve else None,
+                                        gt_v if want_pve else None)
+        else:                                                        # pose_utils.py:223-243
+            mp, re, pve = eval_pose_gpu(output["pred_keypoints_3d"], batch["keypoints_3d"], self.keypoint_list,
+                                        self.pelvis_ind, 0, output["pred_vertices"] if want_pve else None,
+                                        batch["vertices"] if want_pve else None)
+        B = mp.shape[0]
+        host = torch.stack([mp, re, pve if pve is not None else torch.zeros_like(mp)], 0).cpu().numpy()
+        res = {}
+        if hasattr(self, "mode_mpjpe"):
+            self.mode_mpjpe[self.counter:self.counter + B] = host[0]
+            res["mode_mpjpe"] = host[0]
+        if hasattr(self, "mode_re"):
+            self.mode_re[self.counter:self.counter + B] = host[1]
+            res["mode_re"] = host[1]
+        if want_pve:
+            self.mode_pve[self.counter:self.counter + B] = host[2]
+            res["mode_pve"] = host[2]
+        self.counter += B
+        return res
