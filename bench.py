@@ -87,8 +87,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run (also valid at N=1)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
@@ -100,7 +102,7 @@ def main():
     if not os.path.exists(_cabi.LIB_PATH):
         if rank == 0:
             __graft_entry__.build()
-        if world > 1:
+        if use_dist:
             dist.barrier()
     from tokenhmr_amd.config import HMRConfig
     from tokenhmr_amd import weights as W, dist as D
@@ -116,7 +118,7 @@ def main():
         sd, tok, smpl = W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0), make_synthetic_smpl(cfg, 0)
         eng.load_state(sd, tok)
         eng.load_smpl(smpl)
-    if world > 1:
+    if use_dist:
         torch.cuda.synchronize()
         D.broadcast_weights(eng, src=0)        # ... and ONE RCCL broadcast replicates the packed arena
         torch.cuda.synchronize()
@@ -126,7 +128,7 @@ def main():
     img = torch.randn(B, 3, 256, 256, generator=g).to(dev)     # resident in HBM before timing
     outs = eng._alloc_outputs(B, taps=False, want_probs=True)
     feats = torch.empty(B, 192, 1280, device=dev)
-    gather = world > 1 and not a.no_gather and a.workload == "full"
+    gather = use_dist and not a.no_gather and a.workload == "full"
 
     def step():
         if a.workload == "vit":
@@ -141,20 +143,20 @@ def main():
         step()
     torch.cuda.synchronize()
     eng.prof_enable(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     eng.prof_enable(False)
     prof = eng.prof_collect()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -211,7 +213,7 @@ def main():
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

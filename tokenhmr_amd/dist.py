@@ -61,14 +61,14 @@ def unpack_records(rec):
 def broadcast_weights(engine, src: int = 0):
     """ONE collective for the whole model: rank `src` has loaded the checkpoint; everyone else
     receives the packed arena and only has to finalize."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.broadcast(engine.weight_arena, src=src)
 
 
 def all_gather_records(local_rec, total: int):
     """All-gather the packed records of every rank's shard; returns (total, RECORD_WORDS) in crop order.
     Shards may differ by one crop, so each rank pads to the maximum shard size."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized():
         return local_rec
     world = dist.get_world_size()
     sizes = shard_sizes(total, world)
