@@ -150,6 +150,15 @@ int thmr_lbs_forward(thmr_engine* e, const float* rotmat_dev /*(B,24,3,3)*/, con
  * reference's expanded form; x (rows,256) -> idx (rows) int32; optional dist (rows,2048). */
 int thmr_vq_argmin(thmr_engine* e, const float* x_dev, int32_t rows, int32_t* idx_dev, float* dist_dev, void* stream);
 
+/* Tokenizer encode path: EncodeTokens.forward (tokenization/models/vanilla_pose_vqvae.py:334-342)
+ * = PoseSPEncoderV1 (:66-111) -> QuantizeEMAReset.preprocess/quantize (quantize_cnn.py:74-86).
+ * Needs the optional 'encoder.encoder.*' tensors of tokenizer.pth (loaded through thmr_load_weights; all or none).
+ * pose_dev (B,21,6) rot6d body pose -> idx_dev (B,160) int32 code indices; latent_dev (B,160,256) optional. */
+int thmr_encode_tokens(thmr_engine* e, const float* pose_dev, int32_t B, int32_t* idx_dev, float* latent_dev, void* stream);
+/* DecodeTokens.forward (vanilla_pose_vqvae.py:294-297): probs (B,160,2048) @ codebook -> PoseSPDecoderV1 -> pose6d (B,21,6).
+ * One-hot probs give the hard decode of code indices (QuantizeEMAReset.dequantize, quantize_cnn.py:88-90). */
+int thmr_vq_decode(thmr_engine* e, const float* probs_dev, int32_t B, float* pose6d_dev, void* stream);
+
 /* Stateless operator entry points (unit parity of individual kernels; no engine needed). */
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T); epi: 0 none, 1 +bias, 2 +bias gelu(erf), 3 +bias relu,
  * 4 resid + (acc+bias), 5 (+bias)*qscale on cols < qcols.  K % 32 == 0. lda/ldc in elements. */

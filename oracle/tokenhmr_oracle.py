@@ -187,6 +187,30 @@ def vq_decode(softmax_probs, tok, cfg: HMRConfig = RELEASE):
     return x.permute(0, 2, 1)                                           # (B,21,6)
 
 
+def vq_encode(pose6d, enc, codebook):
+    """EncodeTokens.forward (vanilla_pose_vqvae.py:334-342): PoseSPEncoderV1.forward (:90-111, layers :66-88 with the
+    release ARCH) -> QuantizeEMAReset.preprocess (quantize_cnn.py:74-78) -> quantize (:80-86).
+    pose6d (B,21,6) -> (idx (B*160,), latent (B*160,256), dist)."""
+    e = "encoder.encoder."
+    x = pose6d.reshape(pose6d.shape[0], pose6d.shape[1], -1).permute(0, 2, 1)          # preprocess, :90-94
+    x = F.relu(F.conv1d(x, enc[e + "0.weight"], enc[e + "0.bias"], padding=1))
+    x = x[:, :, nearest_index(21, 40)]                                                  # nn.Upsample(size=40)
+    x = F.relu(F.conv1d(x, enc[e + "3.weight"], enc[e + "3.bias"], padding=1))
+    for li in (6, 9, 12):                                                               # nn.Upsample(scale_factor=2)
+        t = x.shape[-1]
+        x = x[:, :, torch.arange(2 * t) // 2]
+        x = F.relu(F.conv1d(x, enc[e + f"{li}.weight"], enc[e + f"{li}.bias"], padding=1))
+    x = F.conv1d(x, enc[e + "14.0.weight"], enc[e + "14.0.bias"], stride=2, padding=1)
+    for blk, dil in ((0, 3), (1, 1)):                                                   # Resnet1D reverse_dilation
+        p = e + f"14.1.model.{blk}."
+        h = F.conv1d(F.relu(x), enc[p + "conv1.weight"], enc[p + "conv1.bias"], padding=dil, dilation=dil)
+        x = F.conv1d(F.relu(h), enc[p + "conv2.weight"], enc[p + "conv2.bias"]) + x
+    x = F.conv1d(x, enc[e + "15.weight"], enc[e + "15.bias"], padding=1)                # (B,256,160)
+    lat = x.permute(0, 2, 1).contiguous().view(-1, x.shape[1])                          # quantize_cnn.py:74-78
+    idx, dist = vq_quantize(lat, codebook)
+    return idx, lat, dist
+
+
 def vq_quantize(x, codebook):
     """quantize_cnn.py:80-86 QuantizeEMAReset.quantize: argmin_k of the *expanded* distance
     sum(x^2) - 2 x.C^T + sum(C^2), evaluated in that order in fp32."""

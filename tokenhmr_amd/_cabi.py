@@ -88,6 +88,8 @@ def load():
     lib.thmr_head_forward.argtypes = [vp, vp, i32, C.POINTER(Outputs), vp]
     lib.thmr_lbs_forward.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.thmr_vq_argmin.argtypes = [vp, vp, i32, vp, vp, vp]
+    lib.thmr_encode_tokens.argtypes = [vp, vp, i32, vp, vp, vp]
+    lib.thmr_vq_decode.argtypes = [vp, vp, i32, vp, vp]
     lib.thmr_op_gemm.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, i32, i32, vp]
     lib.thmr_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, i32, vp]
     lib.thmr_op_vit_attention.argtypes = [vp, vp, i32, vp]

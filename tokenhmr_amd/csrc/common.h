@@ -79,6 +79,9 @@ int launch_softmax_argmax2048(const float* logits, float* probs, int32_t* idx, i
 int launch_conv3_gather(const float* in, float* out, const int32_t* src, int Bn, int Tin, int Tout, int C, int dil,
                         int prerelu, hipStream_t s);
 int launch_conv_repack(const float* w, float* wp, int co, int ci, int kk, hipStream_t s);
+int launch_conv_gather_general(const float* in, float* out, const int32_t* src, int Bn, int Tin, int Tsrc, int Tout, int C,
+                               int Cp, int ks, int stride, int pad, hipStream_t s);
+int launch_conv_repack_pad(const float* w, float* wp, int co, int ci, int cp, int kk, hipStream_t s);
 // head.hip
 int launch_decoder_init(const float* bias, const float* pos, float* x, int B, int E, hipStream_t s);
 int launch_cross_attn(const float* q, const float* kv, int64_t ldkv, int koff, float* out, int B, hipStream_t s);

@@ -65,6 +65,11 @@ struct thmr_engine {
     size_t o_smpl_vt = 0, o_smpl_sd = 0, o_smpl_pd = 0, o_smpl_jr = 0, o_smpl_w = 0, o_smpl_j19 = 0, o_smpl_int = 0,
            o_smpl_jt = 0, o_smpl_jsd = 0;
     std::vector<size_t> convp;    // repacked conv offsets, index by conv id
+    // optional tokenizer ENCODER (EncodeTokens, vanilla_pose_vqvae.py:304-346): 'encoder.encoder.*' tensors
+    std::vector<std::string> enc_names;
+    std::vector<size_t> enc_convp;   // repacked encoder convs, index by kEnc id
+    size_t o_idx_enc = 0;
+    bool enc_ready = false;
     int vq_len[5] = {160, 125, 90, 55, 21};
     // scratch offsets (floats)
     struct {
@@ -195,6 +200,24 @@ const char* const kConv3[] = {"decoder.decoder.0", "decoder.decoder.3", "decoder
 const int kConv3Ci[] = {CODE, VQW, VQW, VQW, VQW, VQW, VQW, VQW, VQW};
 const int kConv3Co[] = {VQW, VQW, VQW, VQW, VQW, VQW, VQW, VQW, 6};
 
+// tokenizer encoder convs in execution order (PoseSPEncoderV1, vanilla_pose_vqvae.py:66-88 with the release ARCH:
+// input_dim 6, width 512, token_size_mul 4, down_t 1, stride_t 2, depth 2, dilation 3, code_dim 256)
+struct EncConv { const char* name; int ci, cp, co, ks; };
+const EncConv kEnc[] = {
+    {"encoder.encoder.0", 6, 32, VQW, 3},                      // T=21, +ReLU
+    {"encoder.encoder.3", VQW, VQW, VQW, 3},                   // nearest 21->40, +ReLU
+    {"encoder.encoder.6", VQW, VQW, VQW, 3},                   // x2 -> 80
+    {"encoder.encoder.9", VQW, VQW, VQW, 3},                   // x2 -> 160
+    {"encoder.encoder.12", VQW, VQW, VQW, 3},                  // x2 -> 320
+    {"encoder.encoder.14.0", VQW, VQW, VQW, 4},                // k4 s2 p1: 320 -> 160 (no activation)
+    {"encoder.encoder.14.1.model.0.conv1", VQW, VQW, VQW, 3},  // ResConv1DBlock dil 3
+    {"encoder.encoder.14.1.model.0.conv2", VQW, VQW, VQW, 1},
+    {"encoder.encoder.14.1.model.1.conv1", VQW, VQW, VQW, 3},  // dil 1
+    {"encoder.encoder.14.1.model.1.conv2", VQW, VQW, VQW, 1},
+    {"encoder.encoder.15", VQW, VQW, CODE, 3},                 // -> (B,160,256)
+};
+constexpr int kEncN = 11;
+
 void layout_weights(thmr_engine* e) {
     std::vector<std::pair<std::string, int64_t>> spec;
     build_spec(e->vit_depth, e->dec_depth, spec);
@@ -247,6 +270,22 @@ void layout_weights(thmr_engine* e) {
     e->o_smpl_int = off; off = align64(off + 128);       // parents(24) | extra(21) | jmap(25) as int32
     e->o_smpl_jt = off;  off = align64(off + NJ * 3);
     e->o_smpl_jsd = off; off = align64(off + NJ * 30);
+    // optional tokenizer encoder (tokenizer.pth 'encoder.encoder.*'): raw tensors, repacked convs, resample tables
+    for (int i = 0; i < kEncN; ++i) {
+        const std::string n = kEnc[i].name;
+        e->enc_names.push_back(n + ".weight");
+        e->enc_names.push_back(n + ".bias");
+        e->slots[n + ".weight"] = Slot{off, (int64_t)kEnc[i].co * kEnc[i].ci * kEnc[i].ks, false};
+        off = align64(off + (size_t)kEnc[i].co * kEnc[i].ci * kEnc[i].ks);
+        e->slots[n + ".bias"] = Slot{off, kEnc[i].co, false};
+        off = align64(off + kEnc[i].co);
+    }
+    e->enc_convp.resize(kEncN);
+    for (int i = 0; i < kEncN; ++i) {
+        e->enc_convp[i] = off;
+        if (kEnc[i].ks > 1) off = align64(off + (size_t)kEnc[i].co * kEnc[i].cp * kEnc[i].ks);
+    }
+    e->o_idx_enc = off; off = align64(off + 640);
     e->wfloats = off;
 }
 
@@ -381,6 +420,44 @@ int conv3(thmr_engine* e, int conv_id, const float* in, int Tin, int Tout, const
     return 0;
 }
 
+// DecodeTokens.forward (tokenization/models/vanilla_pose_vqvae.py:294-297): soft codebook lookup
+// (quantize_cnn.py:92-93 dequantize_logits) + PoseSPDecoderV1 (:135-154).  probs (B,160,2048) -> bpose (B,21,6).
+int vq_decode(thmr_engine* e, const float* probs, int B, float* bpose, hipStream_t st) {
+    auto& so = e->so;
+    const int R = B * TN;
+    // soft codebook lookup: probs @ codebook (quantize_cnn.py:92-93) as a GEMM against codebook^T
+    float* feat = e->S(so.feat);
+    {
+        GemmArgs a = mk(probs, NCLS, e->warena + e->o_cbT, NCLS, nullptr, nullptr, 0, feat, CODE, R, CODE, NCLS);
+        LAUNCH_OK(launch_gemm(a, EPI_NONE, -1, st));
+    }
+    // VQ decoder (vanilla_pose_vqvae.py:135-154), channels-last (B,T,C)
+    float *a0 = e->S(so.act0), *a1 = e->S(so.act1), *a2 = e->S(so.act2);
+    const int32_t* idxt = reinterpret_cast<const int32_t*>(e->warena + e->o_idx);
+    const std::string d = "decoder.decoder.";
+    if (int r = conv3(e, 0, feat, 160, 160, nullptr, 1, 0, e->W(d + "0.bias"), EPI_BIAS_RELU, nullptr, a0, B, st)) return r;
+    const char* up_bias[] = {"3.bias", "6.bias", "9.bias", "12.bias"};
+    float* cur = a0;
+    float* nxt = a1;
+    for (int i = 0; i < 4; ++i) {
+        if (int r = conv3(e, 1 + i, cur, e->vq_len[i], e->vq_len[i + 1], idxt + i * 160, 1, 0, e->W(d + up_bias[i]),
+                          EPI_BIAS_RELU, nullptr, nxt, B, st)) return r;
+        std::swap(cur, nxt);
+    }
+    const int Tq = VQJ;
+    for (int blk = 0; blk < 2; ++blk) {   // ResConv1DBlock, resnet.py:49-69 (dilation 3 then 1)
+        const std::string p = d + "14.0.model." + std::to_string(blk) + ".";
+        const int dil = blk == 0 ? 3 : 1;
+        if (int r = conv3(e, 5 + blk, cur, Tq, Tq, nullptr, dil, 1, e->W(p + "conv1.bias"), EPI_BIAS_RELU, nullptr, a2, B, st)) return r;
+        GemmArgs a = mk(a2, VQW, e->W(p + "conv2.weight"), VQW, e->W(p + "conv2.bias"), cur, VQW, nxt, VQW, B * Tq, VQW, VQW);
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, -1, st));
+        std::swap(cur, nxt);
+    }
+    if (int r = conv3(e, 7, cur, Tq, Tq, nullptr, 1, 0, e->W(d + "14.1.bias"), EPI_BIAS, nullptr, nxt, B, st)) return r;
+    if (int r = conv3(e, 8, nxt, Tq, Tq, nullptr, 1, 0, e->W(d + "15.bias"), EPI_BIAS, nullptr, bpose, B, st)) return r;
+    return 0;
+}
+
 int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* out, hipStream_t st) {
     auto& so = e->so;
     const int M = B * TOK;
@@ -487,37 +564,8 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
         LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
     }
     LAUNCH_OK(launch_softmax_argmax2048(logits, probs, tokidx, R, st));
-    // soft codebook lookup: probs @ codebook (quantize_cnn.py:92-93) as a GEMM against codebook^T
-    float* feat = e->S(so.feat);
-    {
-        GemmArgs a = mk(probs, NCLS, e->warena + e->o_cbT, NCLS, nullptr, nullptr, 0, feat, CODE, R, CODE, NCLS);
-        LAUNCH_OK(launch_gemm(a, EPI_NONE, -1, st));
-    }
-    // VQ decoder (vanilla_pose_vqvae.py:135-154), channels-last (B,T,C)
-    float *a0 = e->S(so.act0), *a1 = e->S(so.act1), *a2 = e->S(so.act2);
-    const int32_t* idxt = reinterpret_cast<const int32_t*>(e->warena + e->o_idx);
-    const std::string d = "decoder.decoder.";
-    if (int r = conv3(e, 0, feat, 160, 160, nullptr, 1, 0, e->W(d + "0.bias"), EPI_BIAS_RELU, nullptr, a0, B, st)) return r;
-    const char* up_bias[] = {"3.bias", "6.bias", "9.bias", "12.bias"};
-    float* cur = a0;
-    float* nxt = a1;
-    for (int i = 0; i < 4; ++i) {
-        if (int r = conv3(e, 1 + i, cur, e->vq_len[i], e->vq_len[i + 1], idxt + i * 160, 1, 0, e->W(d + up_bias[i]),
-                          EPI_BIAS_RELU, nullptr, nxt, B, st)) return r;
-        std::swap(cur, nxt);
-    }
-    const int Tq = VQJ;
-    for (int blk = 0; blk < 2; ++blk) {   // ResConv1DBlock, resnet.py:49-69 (dilation 3 then 1)
-        const std::string p = d + "14.0.model." + std::to_string(blk) + ".";
-        const int dil = blk == 0 ? 3 : 1;
-        if (int r = conv3(e, 5 + blk, cur, Tq, Tq, nullptr, dil, 1, e->W(p + "conv1.bias"), EPI_BIAS_RELU, nullptr, a2, B, st)) return r;
-        GemmArgs a = mk(a2, VQW, e->W(p + "conv2.weight"), VQW, e->W(p + "conv2.bias"), cur, VQW, nxt, VQW, B * Tq, VQW, VQW);
-        LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, -1, st));
-        std::swap(cur, nxt);
-    }
-    if (int r = conv3(e, 7, cur, Tq, Tq, nullptr, 1, 0, e->W(d + "14.1.bias"), EPI_BIAS, nullptr, nxt, B, st)) return r;
     float* bpose = e->S(so.bpose);
-    if (int r = conv3(e, 8, nxt, Tq, Tq, nullptr, 1, 0, e->W(d + "15.bias"), EPI_BIAS, nullptr, bpose, B, st)) return r;
+    if (int r = vq_decode(e, probs, B, bpose, st)) return r;
     // assemble + rot6d + camera (token_head.py:103-127, tokenhmr.py:165-169)
     float* rot = (out && out->rotmat) ? out->rotmat : e->S(so.rot);
     float* betas = (out && out->betas) ? out->betas : e->S(so.betas);
@@ -625,6 +673,20 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     }
     if (hipMemcpy(e->warena + e->o_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
         return bail(THMR_ERR_HIP, "hipMemcpy(idx tables) failed");
+    // encoder resample tables: nn.Upsample(size=40) from 21 (offset 0), then three nn.Upsample(scale_factor=2)
+    // (ATen uses scale 1/scale_factor = 0.5: src = floor(dst*0.5)): 40->80 (offset 40), 80->160 (120), 160->320 (280)
+    std::vector<int32_t> eidx(640, 0);
+    {
+        const float sc = 21.0f / 40.0f;
+        for (int t = 0; t < 40; ++t) { int s0 = (int)floorf((float)t * sc); eidx[t] = s0 < 20 ? s0 : 20; }
+        int o = 40;
+        for (int tin = 40; tin <= 160; tin *= 2) {
+            for (int t = 0; t < 2 * tin; ++t) { int s0 = (int)floorf((float)t * 0.5f); eidx[o + t] = s0 < tin - 1 ? s0 : tin - 1; }
+            o += 2 * tin;
+        }
+    }
+    if (hipMemcpy(e->warena + e->o_idx_enc, eidx.data(), eidx.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(THMR_ERR_HIP, "hipMemcpy(encoder idx tables) failed");
     // the padding row of the read-out matrix must be finite
     if (hipMemset(e->warena + e->o_ro_w, 0, 32 * E * sizeof(float)) != hipSuccess) return bail(THMR_ERR_HIP, "hipMemset failed");
     *out = e;
@@ -693,7 +755,87 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
     LAUNCH_OK(launch_code_norm(e->W("quantizer.codebook"), e->warena + e->o_cnorm, NCLS, st));
     LAUNCH_OK(launch_lbs_jreg(e->warena + e->o_smpl_jr, e->warena + e->o_smpl_vt, e->warena + e->o_smpl_sd,
                               e->warena + e->o_smpl_jt, e->warena + e->o_smpl_jsd, st));
+    // optional encoder: ready only when every 'encoder.encoder.*' tensor arrived (all-or-nothing)
+    size_t enc_loaded = 0;
+    for (auto& n : e->enc_names) enc_loaded += e->slots[n].loaded ? 1 : 0;
+    if (enc_loaded != 0 && enc_loaded != e->enc_names.size())
+        return fail(e, THMR_ERR_STATE, "tokenizer encoder partially loaded: " + std::to_string(enc_loaded) + " of " +
+                                           std::to_string(e->enc_names.size()) + " tensors");
+    e->enc_ready = enc_loaded == e->enc_names.size();
+    if (e->enc_ready)
+        for (int i = 0; i < kEncN; ++i)
+            if (kEnc[i].ks > 1)
+                LAUNCH_OK(launch_conv_repack_pad(e->W(std::string(kEnc[i].name) + ".weight"), e->warena + e->enc_convp[i],
+                                                 kEnc[i].co, kEnc[i].ci, kEnc[i].cp, kEnc[i].ks, st));
     e->finalized = true;
+    return 0;
+}
+
+int thmr_vq_decode(thmr_engine* e, const float* probs_dev, int32_t B, float* pose6d_dev, void* stream) {
+    if (int r = check_ready(e, B)) return r;
+    if (!probs_dev || !pose6d_dev) return fail(e, THMR_ERR_INVALID, "null buffer");
+    return vq_decode(e, probs_dev, B, pose6d_dev, static_cast<hipStream_t>(stream));
+}
+
+// EncodeTokens.forward (tokenization/models/vanilla_pose_vqvae.py:334-342): PoseSPEncoderV1 (:66-111) -> preprocess
+// (quantize_cnn.py:74-78) -> QuantizeEMAReset.quantize (:80-86).  pose (B,21,6) rot6d body pose -> idx (B,160).
+int thmr_encode_tokens(thmr_engine* e, const float* pose_dev, int32_t B, int32_t* idx_dev, float* latent_dev, void* stream) {
+    if (int r = check_ready(e, B)) return r;
+    if (!e->enc_ready) return fail(e, THMR_ERR_STATE, "tokenizer encoder weights ('encoder.encoder.*') were not loaded");
+    if (!pose_dev || !idx_dev) return fail(e, THMR_ERR_INVALID, "null buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // all scratch comes out of the big time-shared buffer (the encode path never overlaps a forward on one engine)
+    float* gat = e->S(e->so.big);
+    float* a0 = gat + (size_t)B * 320 * 1536;
+    float* a1 = a0 + (size_t)B * 320 * VQW;
+    float* a2 = a1 + (size_t)B * 320 * VQW;
+    const int32_t* tab = reinterpret_cast<const int32_t*>(e->warena + e->o_idx_enc);
+    auto W = [&](int i) { return kEnc[i].ks > 1 ? e->warena + e->enc_convp[i] : e->W(std::string(kEnc[i].name) + ".weight"); };
+    auto Bv = [&](int i) { return e->W(std::string(kEnc[i].name) + ".bias"); };
+    // 0: Conv1d(6->512,k3,p1)+ReLU at T=21 (channels zero-padded 6->32 so that K = 96)
+    LAUNCH_OK(launch_conv_gather_general(pose_dev, gat, nullptr, B, 21, 21, 21, 6, 32, 3, 1, 1, st));
+    {
+        GemmArgs a = mk(gat, 96, W(0), 96, Bv(0), nullptr, 0, a0, VQW, B * 21, VQW, 96);
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS_RELU, -1, st));
+    }
+    // 1-4: nearest resample (21->40, then x2 three times) + Conv1d(512,k3,p1) + ReLU
+    const int tin[4] = {21, 40, 80, 160}, tout[4] = {40, 80, 160, 320}, toff[4] = {0, 40, 120, 280};
+    float* cur = a0;
+    float* nxt = a1;
+    for (int i = 0; i < 4; ++i) {
+        LAUNCH_OK(launch_conv3_gather(cur, gat, tab + toff[i], B, tin[i], tout[i], VQW, 1, 0, st));
+        GemmArgs a = mk(gat, 3 * VQW, W(1 + i), 3 * VQW, Bv(1 + i), nullptr, 0, nxt, VQW, B * tout[i], VQW, 3 * VQW);
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS_RELU, -1, st));
+        std::swap(cur, nxt);
+    }
+    // 5: Conv1d(512,512,k4,s2,p1): 320 -> 160, no activation
+    LAUNCH_OK(launch_conv_gather_general(cur, gat, nullptr, B, 320, 320, 160, VQW, VQW, 4, 2, 1, st));
+    {
+        GemmArgs a = mk(gat, 4 * VQW, W(5), 4 * VQW, Bv(5), nullptr, 0, nxt, VQW, B * 160, VQW, 4 * VQW);
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
+        std::swap(cur, nxt);
+    }
+    // 6-9: Resnet1D (dilation 3 then 1): x + conv2(relu(conv1(relu(x))))   (resnet.py:49-69)
+    for (int blk = 0; blk < 2; ++blk) {
+        const int c1 = 6 + 2 * blk, c2 = 7 + 2 * blk, dil = blk == 0 ? 3 : 1;
+        LAUNCH_OK(launch_conv3_gather(cur, gat, nullptr, B, 160, 160, VQW, dil, 1, st));
+        GemmArgs g1 = mk(gat, 3 * VQW, W(c1), 3 * VQW, Bv(c1), nullptr, 0, a2, VQW, B * 160, VQW, 3 * VQW);
+        LAUNCH_OK(launch_gemm(g1, EPI_BIAS_RELU, -1, st));
+        GemmArgs g2 = mk(a2, VQW, W(c2), VQW, Bv(c2), cur, VQW, nxt, VQW, B * 160, VQW, VQW);
+        LAUNCH_OK(launch_gemm(g2, EPI_BIAS_RESID, -1, st));
+        std::swap(cur, nxt);
+    }
+    // 10: Conv1d(512->256,k3,p1): the latent, already in the (N*T, C) layout QuantizeEMAReset.preprocess produces
+    float* lat = latent_dev ? latent_dev : a2;
+    LAUNCH_OK(launch_conv3_gather(cur, gat, nullptr, B, 160, 160, VQW, 1, 0, st));
+    {
+        GemmArgs a = mk(gat, 3 * VQW, W(10), 3 * VQW, Bv(10), nullptr, 0, lat, CODE, B * 160, CODE, 3 * VQW);
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
+    }
+    // argmin-L2 against the codebook; the x.C^T scores go to the gather region (B*160*2048 <= B*320*1536)
+    GemmArgs d = mk(lat, CODE, e->W("quantizer.codebook"), CODE, nullptr, nullptr, 0, gat, NCLS, B * 160, NCLS, CODE);
+    LAUNCH_OK(launch_gemm(d, EPI_NONE, -1, st));
+    LAUNCH_OK(launch_vq_argmin_rows(lat, gat, e->warena + e->o_cnorm, idx_dev, nullptr, B * 160, st));
     return 0;
 }
 

@@ -231,9 +231,38 @@ __global__ void conv_repack_kernel(const float* __restrict__ w, float* __restric
     wp[((int64_t)co * kk + k) * ci_n + ci] = w[idx];
 }
 
-__global__ void relu_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) y[i] = fmaxf(x[i], 0.f);
+// General Conv1d gather for the tokenizer ENCODER (vanilla_pose_vqvae.py:66-88): kernel size ks, stride, padding,
+// optional nearest-resample table, input channels C zero-padded to Cp (so that K = ks*Cp is a multiple of 32):
+//   out[b][t][kk*Cp + c] = in[b][src[tp]][c]   with tp = t*stride - pad + kk, valid if 0 <= tp < Tsrc and c < C
+__global__ __launch_bounds__(256) void conv_gather_general_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                  const int32_t* __restrict__ src, int Bn, int Tin, int Tsrc,
+                                                                  int Tout, int C, int Cp, int ks, int stride, int pad) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)Bn * Tout * ks * Cp;
+    if (idx >= total) return;
+    const int c = (int)(idx % Cp);
+    int64_t rest = idx / Cp;
+    const int kk = (int)(rest % ks);
+    rest /= ks;
+    const int t = (int)(rest % Tout), b = (int)(rest / Tout);
+    const int tp = t * stride - pad + kk;
+    float v = 0.f;
+    if (c < C && tp >= 0 && tp < Tsrc) {
+        const int ts = src ? src[tp] : tp;
+        v = in[((int64_t)b * Tin + ts) * C + c];
+    }
+    out[idx] = v;
+}
+
+// Conv1d weight [co][ci][k] -> [co][k*cp + ci], ci zero-padded to cp
+__global__ void conv_repack_pad_kernel(const float* __restrict__ w, float* __restrict__ wp, int co_n, int ci_n, int cp, int kk) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)co_n * kk * cp;
+    if (idx >= total) return;
+    const int ci = (int)(idx % cp);
+    const int k = (int)((idx / cp) % kk);
+    const int co = (int)(idx / ((int64_t)cp * kk));
+    wp[idx] = ci < ci_n ? w[((int64_t)co * ci_n + ci) * kk + k] : 0.f;
 }
 
 }  // namespace
@@ -284,5 +313,19 @@ int launch_conv3_gather(const float* in, float* out, const int32_t* src, int Bn,
 int launch_conv_repack(const float* w, float* wp, int co, int ci, int kk, hipStream_t s) {
     const int64_t total = (int64_t)co * ci * kk;
     hipLaunchKernelGGL(conv_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wp, co, ci, kk);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_conv_gather_general(const float* in, float* out, const int32_t* src, int Bn, int Tin, int Tsrc, int Tout, int C,
+                               int Cp, int ks, int stride, int pad, hipStream_t s) {
+    const int64_t total = (int64_t)Bn * Tout * ks * Cp;
+    hipLaunchKernelGGL(conv_gather_general_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, src, Bn, Tin,
+                       Tsrc, Tout, C, Cp, ks, stride, pad);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_conv_repack_pad(const float* w, float* wp, int co, int ci, int cp, int kk, hipStream_t s) {
+    const int64_t total = (int64_t)co * kk * cp;
+    hipLaunchKernelGGL(conv_repack_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wp, co, ci, cp, kk);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

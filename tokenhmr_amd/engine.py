@@ -61,10 +61,11 @@ class Engine:
         Host or device fp32 tensors in the reference layouts (strict: missing/unknown keys raise)."""
         items = list(state.items()) + (list(tokenizer.items()) if tokenizer else [])
         wanted = {n for n, *_ in W.spec(self.cfg)} | {n for n, *_ in W.tokenizer_spec(self.cfg)}
+        wanted |= {n for n, *_ in W.tokenizer_encoder_spec(self.cfg)}      # optional: enables encode_tokens()
         descs, keep = [], []
         for name, t in items:
             if name not in wanted:
-                if name.startswith(("encoder.", "body_model", "decoder.body_model")):
+                if name.startswith(("encoder.", "body_model", "decoder.body_model", "quantizer.")):
                     continue   # filtered by the reference too (vanilla_pose_vqvae.py:24-40)
                 raise KeyError(f"unexpected tensor '{name}' (strict load)")
             t = t.detach()
@@ -175,6 +176,29 @@ class Engine:
             _cabi.check(self.lib.thmr_lbs_forward(self.h, _ptr(rotmat), _ptr(betas), _ptr(cam), B, _ptr(verts), _ptr(joints),
                                                   _ptr(cam_t), _ptr(kp2d), _stream_ptr(self.device)), self.h)
         return verts, joints, cam_t, kp2d
+
+    def encode_tokens(self, pose6d, want_latent=False):
+        """EncodeTokens.forward (vanilla_pose_vqvae.py:334-342): (B,21,6) rot6d body pose -> (B,160) int32 code indices."""
+        pose6d = pose6d.to(self.device, torch.float32).contiguous()
+        B = pose6d.shape[0]
+        if tuple(pose6d.shape[1:]) != (21, 6):
+            raise ValueError(f"pose must be (B,21,6), got {tuple(pose6d.shape)}")
+        idx = torch.empty(B, 160, device=self.device, dtype=torch.int32)
+        lat = torch.empty(B, 160, 256, device=self.device, dtype=torch.float32) if want_latent else None
+        with torch.cuda.device(self.device):
+            _cabi.check(self.lib.thmr_encode_tokens(self.h, _ptr(pose6d), B, _ptr(idx), _ptr(lat), _stream_ptr(self.device)), self.h)
+        return (idx, lat) if want_latent else idx
+
+    def vq_decode(self, probs):
+        """DecodeTokens.forward (vanilla_pose_vqvae.py:294-297): (B,160,2048) token probabilities -> (B,21,6) rot6d pose."""
+        probs = probs.to(self.device, torch.float32).contiguous()
+        B = probs.shape[0]
+        if tuple(probs.shape[1:]) != (160, 2048):
+            raise ValueError(f"probs must be (B,160,2048), got {tuple(probs.shape)}")
+        pose = torch.empty(B, 21, 6, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _cabi.check(self.lib.thmr_vq_decode(self.h, _ptr(probs), B, _ptr(pose), _stream_ptr(self.device)), self.h)
+        return pose
 
     def vq_argmin(self, x, want_dist=False):
         x = x.contiguous()

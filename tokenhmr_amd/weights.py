@@ -117,6 +117,35 @@ def tokenizer_spec(cfg: HMRConfig = RELEASE):
     return S
 
 
+def tokenizer_encoder_spec(cfg: HMRConfig = RELEASE):
+    """OPTIONAL tokenizer.pth ['net'] 'encoder.encoder.*' entries (PoseSPEncoderV1, vanilla_pose_vqvae.py:66-88 with the
+    release ARCH: input_dim 6, token_size_mul 4, down_t 1) — only needed for the encode path (EncodeTokens)."""
+    W, C = cfg.vq_width, cfg.code_dim
+    S = []
+
+    def conv(name, co, ci, k):
+        S.append((name + ".weight", (co, ci, k), "w", ci * k))
+        S.append((name + ".bias", (co,), "b", ci * k))
+
+    conv("encoder.encoder.0", W, 6, 3)
+    for i in (3, 6, 9, 12):
+        conv(f"encoder.encoder.{i}", W, W, 3)
+    conv("encoder.encoder.14.0", W, W, 4)
+    for blk in (0, 1):
+        conv(f"encoder.encoder.14.1.model.{blk}.conv1", W, W, 3)
+        conv(f"encoder.encoder.14.1.model.{blk}.conv2", W, W, 1)
+    conv("encoder.encoder.15", C, W, 3)
+    return S
+
+
+def make_synthetic_encoder(cfg: HMRConfig = RELEASE, seed: int = 0):
+    g = torch.Generator(device="cpu").manual_seed(2500 + seed)
+    sd = OrderedDict()
+    for name, shape, kind, fan_in in tokenizer_encoder_spec(cfg):
+        sd[name] = _fill(shape, kind, fan_in, g)
+    return sd
+
+
 def _fill(shape, kind, fan_in, g):
     if kind in ("w", "b"):
         bound = 1.0 / math.sqrt(max(fan_in, 1))
