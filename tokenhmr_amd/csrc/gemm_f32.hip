@@ -109,7 +109,11 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, f32x16 (&acc)[TM][
 }
 
 // DMA = true: global_load_lds staging; DMA = false: register staging
-template <int WM, int WN, int TM, int TN, bool DMA, int EPI>
+// ABL (timing-only experiments, results are garbage): bit0 no DMA copies in the loop, bit1 no per-tile barrier,
+// bit2 no LDS fragment reads.  ABL = 0 is the product kernel.
+// DS: one DMA piece every DS-th MFMA (0 = auto).  BARPOS: 0 = barrier after the last MFMA in program order (hipcc hoists it
+// above the register-only MFMA tail), k > 0 = barrier pinned k MFMAs before the end of the tile.
+template <int WM, int WN, int TM, int TN, bool DMA, int EPI, int ABL = 0, int DSP = 0, int BARPOS = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int tiles_m, int tiles_n) {
     constexpr int NW = WM * WN;
     constexpr int NT = NW * 64;
@@ -242,8 +246,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
             bf[slot][f - TM] = *reinterpret_cast<const f32x4*>(Bs + (buf * BN + wn0 + lrow + (f - TM) * 32) * LDK + koff[j]);
     };
     constexpr int G = 4 * TM * TN;                                   // MFMAs per k-group
+    constexpr int DS_AUTO = (NJ * G / 2) / NP >= 4 ? 4 : ((NJ * G / 2) / NP >= 1 ? (NJ * G / 2) / NP : 1);
+    constexpr int DS = DSP > 0 ? DSP : DS_AUTO;                     // measured: spreading the copies 4 MFMAs apart +2-5 %
     constexpr int OFF0 = (NP < G - (TM + TN)) ? NP : G - (TM + TN);  // where the fragment prefetch starts in k-group 0
-    static_assert(TM + TN <= G && NP <= NJ * G, "tile too small for the staging interleave");
+    static_assert(TM + TN <= G && NP * DS <= NJ * G, "tile too small for the staging interleave");
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
             // Tile kt+1 goes straight into the other buffer (last read in iteration kt-1, barrier passed); past the
             // last tile the copy re-reads the last tile into a buffer nobody reads (keeps the body branch-free).
             const int ktn = min(kt + 1, nk - 1);
-            read_frags(buf, 0, 0);
+            if constexpr (!(ABL & 4)) read_frags(buf, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -269,11 +275,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
                                                                                acc[mi][ni], 0, 0, 0);
                             const int g = j * G + idx;                        // MFMA index within the K tile
                             const int ridx = idx - (j == 0 ? OFF0 : 0);       // slot in the fragment-prefetch run
-                            const bool do_dma = g < NP;
+                            const bool do_dma = (g % DS == 0) && (g / DS < NP);     // one DMA piece every DS-th MFMA
                             const bool do_read = j + 1 < NJ && ridx >= 0 && ridx < TM + TN;
-                            if (do_dma) dma_piece(ktn, buf ^ 1, g);
-                            if (do_read) read_one(buf, j + 1, (j + 1) & 1, ridx);
+                            if constexpr (!(ABL & 1)) { if (do_dma) dma_piece(ktn, buf ^ 1, g / DS); }
+                            if constexpr (!(ABL & 4)) { if (do_read) read_one(buf, j + 1, (j + 1) & 1, ridx); }
                             if (do_dma || do_read) __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (BARPOS > 0 && !(ABL & 2)) {
+                                if (g == NJ * G - 1 - BARPOS) {
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    __syncthreads();
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            }
                         }
             }
         } else {
@@ -294,7 +307,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
                 if (j == 1) load_global(min(kt + 2, nk - 1));
             }
         }
-        __syncthreads();
+        if constexpr (!(ABL & 2) && !(DMA && BARPOS > 0)) __syncthreads();
+        if constexpr ((ABL & 4) != 0) {
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) asm volatile("" : "+v"(af[0][mi]), "+v"(af[1][mi]));
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) asm volatile("" : "+v"(bf[0][ni]), "+v"(bf[1][ni]));
+        }
     }
 
     store_tile<TM, TN, EPI>(a, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
@@ -323,6 +342,15 @@ int launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+#ifdef THMR_GEMM_ABLATION   // timing-only experiment kernels (garbage results); not built into the product library
+template <int ABL, int DS = 0, int BARPOS = 0>
+int launch_abl(const GemmArgs& a, hipStream_t s) {
+    const int tiles_m = (a.M + 127) / 128, tiles_n = (a.N + 159) / 160;
+    hipLaunchKernelGGL((gemm_f32_kernel<4, 1, 1, 5, true, EPI_NONE, ABL, DS, BARPOS>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+#endif
+
 inline double tile_efficiency(int M, int N, int BM, int BN) {
     // useful fraction of the MFMA work issued, including the partial last wave over 256 CUs
     const long tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
@@ -350,6 +378,22 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         const double c7 = cost(128, 128, 0.97), c8 = cost(128, 160, 1.0), c9 = cost(64, 64, 0.80);
         variant = (c8 <= c7 && c8 <= c9) ? 8 : (c7 <= c9 ? 7 : 9);
     }
+#ifdef THMR_GEMM_ABLATION
+    switch (variant) {     // 30 + ABL: timing-only ablations of the 128x160 DMA kernel (EPI_NONE)
+        case 31: return launch_abl<1>(a, s);
+        case 32: return launch_abl<2>(a, s);
+        case 33: return launch_abl<3>(a, s);
+        case 34: return launch_abl<4>(a, s);
+        case 37: return launch_abl<7>(a, s);
+        case 41: return launch_abl<0, 1>(a, s);    // DMA piece every MFMA / 2nd / 4th MFMA
+        case 42: return launch_abl<0, 2>(a, s);
+        case 44: return launch_abl<0, 4>(a, s);
+        case 51: return launch_abl<0, 4, 10>(a, s);   // barrier pinned 10 / 20 / 2 MFMAs before the end of the tile
+        case 52: return launch_abl<0, 4, 20>(a, s);
+        case 53: return launch_abl<0, 4, 2>(a, s);
+        default: break;
+    }
+#endif
     switch (variant) {
         case 0: return launch_cfg<2, 2, 2, 2, false>(a, epi, s);
         case 1: return launch_cfg<4, 1, 1, 5, false>(a, epi, s);

@@ -8,6 +8,7 @@ from . import _cabi
 
 EPI = {"none": 0, "bias": 1, "bias_gelu": 2, "bias_relu": 3, "bias_resid": 4, "bias_qscale": 5, "bias_pos": 6}
 VARIANT = {"auto": -1, "128x128reg": 0, "128x160reg": 1, "skinny": 2, "128x128": 7, "128x160": 8, "64x64": 9}
+# (timing-only ablation kernels 31-53 exist only in builds with -DTHMR_GEMM_ABLATION, see gemm_f32.hip)
 
 
 def _p(t):
