@@ -284,3 +284,26 @@ def test_standalone_smpl_gt_meshes(built_lib, cuda_dev):
         out2 = m(global_orient=R[:, :1], body_pose=R[:, 1:], betas=betas, pose2rot=False)
         assert (out2.vertices.cpu() - rv).abs().max() < 1e-4
         m.close()
+
+
+@pytest.mark.parametrize("B", [1, 7])
+def test_odd_batch_sizes_vs_oracle(built_lib, cuda_dev, B):
+    """Ragged everything: B=1 and B=7 (M = 192 and 1344 rows: partial GEMM tiles, partial LBS crop groups, skinny-GEMM
+    row tails) against the oracle at depth 1."""
+    from oracle import tokenhmr_oracle as O
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd.model import TokenHMR
+    cfg = HMRConfig(vit_depth=1, dec_depth=1)
+    sd, tok, smpl = _assets(cfg, seed=2)
+    model = TokenHMR.from_state(cfg, sd, tok, smpl, max_batch=8, device=cuda_dev)
+    img = _inputs(B, seed=9)
+    out = _to_cpu(model({"img": img.to(cuda_dev)}))
+    with torch.no_grad():
+        orc = O.forward(img, sd, tok, smpl, cfg)
+    assert (out["pred_vertices"] - orc["pred_vertices"]).abs().max() < 1e-4
+    assert (out["pred_keypoints_3d"] - orc["pred_keypoints_3d"]).abs().max() < 1e-4
+    assert (out["pred_cam"] - orc["pred_cam"]).abs().max() < 1e-4
+    assert (out["cls_logits_softmax"] - orc["cls_logits_softmax"]).abs().max() < 1e-5
+    top2 = orc["cls_logits"].topk(2, dim=-1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-2
+    assert (out["token_idx"] == orc["token_idx"])[safe].all()
