@@ -191,6 +191,12 @@ def main():
                     roof["algorithmic_bytes_per_launch"] = pmc["algorithmic_bytes"]
             except (OSError, ValueError, KeyError):
                 pass
+            pe = prof.get("patch_embed")
+            if pe and pe["launches"]:       # north_star asks for the patch-embed HBM rate too (it is MFMA/latency-bound: AI 240 flop/B)
+                gbs = pe["bytes"] / (pe["ms"] * 1e-3) / 1e9
+                roof["patch_embed_hbm"] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                           "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_ms": round(pe["ms"] / pe["launches"], 4),
+                                           "tflops": round(pe["flops"] / (pe["ms"] * 1e-3) / 1e12, 1)}
             lbs = prof.get("lbs")
             if lbs and lbs["launches"]:
                 gbs = lbs["bytes"] / (lbs["ms"] * 1e-3) / 1e9

@@ -351,15 +351,6 @@ int launch_abl(const GemmArgs& a, hipStream_t s) {
 }
 #endif
 
-inline double tile_efficiency(int M, int N, int BM, int BN) {
-    // useful fraction of the MFMA work issued, including the partial last wave over 256 CUs
-    const long tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
-    const double useful = (double)M * N;
-    const long tiles = tm * tn;
-    const long rounds = (tiles + 255) / 256;          // per-CU tile count of the busiest CU
-    return useful / ((double)rounds * 256 * BM * BN);
-}
-
 }  // namespace
 
 // variant: 0 = 128x128 REG (2x2 waves of 64x64)   1 = 128x160 REG (4x1 waves of 32x160)

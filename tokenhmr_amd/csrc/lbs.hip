@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void lbs_jreg_kernel(const float* __restrict__
     }
     red[threadIdx.x] = acc;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (unsigned s = 128; s > 0; s >>= 1) {
         if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
