@@ -64,6 +64,30 @@ def test_gemm_epilogues(built_lib, cuda_dev, epi):
     assert torch.allclose(out, ref, atol=2e-5, rtol=1e-5), (out - ref).abs().max()
 
 
+def test_gelu_epilogue_ulp(built_lib, cuda_dev):
+    """The epilogue's branch-free erf (csrc/common.h erf_fast) against fp64 GELU on a dense grid.  A has x in column 0 and
+    W a single 1, so C[m, n] = gelu(x_m) with no accumulation error.  fp32 GELU itself loses bits to the 1+erf cancellation
+    for x << 0 (torch's fp32 kernel does too), hence the |x|-scaled absolute term: 2 ulp of (1+erf) * |x|/2."""
+    from tokenhmr_amd import ops
+    M, N, K = 8192, 32, 32
+    x = torch.cat([torch.linspace(-9, 9, M - 512, dtype=torch.float64),
+                   torch.linspace(-1.4, -1.2, 256, dtype=torch.float64),      # around the piece boundary |x|/sqrt2 = 0.921875
+                   torch.linspace(1.2, 1.4, 256, dtype=torch.float64)]).float()
+    a = torch.zeros(M, K)
+    a[:, 0] = x
+    w = torch.zeros(N, K)
+    w[:, 0] = 1.0
+    out = ops.gemm(a.to(cuda_dev), w.to(cuda_dev), torch.zeros(N).to(cuda_dev), epi="bias_gelu", variant="128x160").cpu()
+    ref = F.gelu(x.double())
+    err = (out[:, 0].double() - ref).abs()
+    tol = 1.2e-7 * x.abs().clamp(min=1.0).double() + 2e-7 * ref.abs()
+    assert bool((err <= tol).all()), (err / tol).max()
+    assert torch.equal(out[:, 0], out[:, N - 1])
+    # and it is no worse than torch's own fp32 GELU (ocml/MKL erff) by more than 1 ulp-class
+    t32 = (F.gelu(x).double() - ref).abs().max()
+    assert err.max() <= t32 + 2.5e-7, (err.max(), t32)
+
+
 def test_gemm_asymmetric_identity(built_lib, cuda_dev):
     """A = I with an asymmetric W catches a transposed C write (guide rule: always A=I with asymmetric B)."""
     from tokenhmr_amd import ops

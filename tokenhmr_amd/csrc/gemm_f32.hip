@@ -59,6 +59,57 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tile_
 // C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 template <int TM, int TN, int EPI>
 __device__ __forceinline__ void store_tile(const GemmArgs& a, f32x16 (&acc)[TM][TN], int m0, int n0, int lrow, int lhalf) {
+#if !defined(THMR_NO_FAST_EPILOGUE)
+    // Interior wave tiles (every ViT GEMM at batch sizes that are multiples of 2 has only these): no bounds checks, and the
+    // address of element (mi, ni, e) is a wave-uniform pointer (SALU) plus ONE per-lane 32-bit offset computed once, so each
+    // store / residual load is a single saddr-form global instruction instead of ~12 VALU of 64-bit address arithmetic.
+    if constexpr (EPI != EPI_BIAS_POS) {
+        if (m0 + TM * 32 <= a.M && n0 + TN * 32 <= a.N && a.ldc < (1 << 24) && a.ldr < (1 << 24)) {   // wave-uniform
+            const uint32_t coff = (uint32_t)(4 * lhalf) * (uint32_t)a.ldc + (uint32_t)lrow;
+            const uint32_t roff = (uint32_t)(4 * lhalf) * (uint32_t)a.ldr + (uint32_t)lrow;
+            float* Cw = a.C + (int64_t)m0 * a.ldc + n0;
+            const float* Rw = nullptr;
+            if constexpr (EPI == EPI_BIAS_RESID) Rw = a.resid + (int64_t)m0 * a.ldr + n0;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    float bias = 0.f;
+                    if constexpr (EPI != EPI_NONE) bias = (a.bias + n0 + ni * 32)[lrow];
+                    float extra[16];
+                    if constexpr (EPI == EPI_BIAS_RESID) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            extra[e] = (Rw + (int64_t)(mi * 32 + (e & 3) + 8 * (e >> 2)) * a.ldr + ni * 32)[roff];
+                    }
+                    float outv[16];
+                    if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 16; e += 2) {
+                            const f32x2 g = gelu_erf2(f32x2{acc[mi][ni][e] + bias, acc[mi][ni][e + 1] + bias});
+                            outv[e] = g.x;
+                            outv[e + 1] = g.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            float v = acc[mi][ni][e];
+                            if constexpr (EPI != EPI_NONE) v = v + bias;
+                            if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.0f);
+                            if constexpr (EPI == EPI_BIAS_RESID) v = extra[e] + v;
+                            if constexpr (EPI == EPI_BIAS_QSCALE) v = (n0 + ni * 32 + lrow < a.qcols) ? v * a.qscale : v;
+                            outv[e] = v;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        (Cw + (int64_t)(mi * 32 + (e & 3) + 8 * (e >> 2)) * a.ldc + ni * 32)[coff] = outv[e];
+                }
+            }
+            return;
+        }
+    }
+#endif
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
@@ -86,11 +137,19 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, f32x16 (&acc)[TM][
                 }
             }
             float outv[16];
+            if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 g = gelu_erf2(f32x2{acc[mi][ni][e] + bias, acc[mi][ni][e + 1] + bias});
+                    outv[e] = g.x;
+                    outv[e + 1] = g.y;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
+                if constexpr (EPI == EPI_BIAS_GELU) break;
                 float v = acc[mi][ni][e];
                 if constexpr (EPI != EPI_NONE) v = v + bias;
-                if constexpr (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
                 if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.0f);
                 if constexpr (EPI == EPI_BIAS_RESID) v = extra[e] + v;
                 if constexpr (EPI == EPI_BIAS_QSCALE) v = (n < a.qcols) ? v * a.qscale : v;
