@@ -64,6 +64,50 @@ def test_gemm_epilogues(built_lib, cuda_dev, epi):
     assert torch.allclose(out, ref, atol=2e-5, rtol=1e-5), (out - ref).abs().max()
 
 
+RING_SHAPES = [(192, 1280, 1280), (192, 3840, 1280), (384, 1280, 5120), (64, 64, 32), (64, 64, 256), (200, 72, 512), (37, 31, 1024),
+               (576, 5120, 1280)]
+
+
+@pytest.mark.parametrize("variant", ["ring4", "ring8", "ring4/k2", "ring8/k4", "ring4/k8", "ring8/k16"])
+@pytest.mark.parametrize("shape", RING_SHAPES)
+def test_gemm_ring_shapes(built_lib, cuda_dev, shape, variant):
+    """Small-M kernel: every ring depth x split-K factor, including K tiles fewer than the ring is deep (K=32: one tile),
+    ragged M / N edges and split-K slices of a single K tile."""
+    from tokenhmr_amd import ops
+    M, N, K = shape
+    ks = int(variant.split("/k")[1]) if "/k" in variant else 1
+    if K % (32 * ks):
+        pytest.skip("K not divisible by 32*ksplit (rejected, see test_gemm_ring_rejects)")
+    if ks > 1 and N % 4:
+        pytest.skip("split-K reducer needs N % 4 == 0")
+    a, w, b, r = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(N, seed=3), _rand(M, N, seed=4)
+    for epi in ("bias", "bias_resid", "bias_gelu"):
+        out = ops.gemm(a.to(cuda_dev), w.to(cuda_dev), b.to(cuda_dev), r.to(cuda_dev) if epi == "bias_resid" else None,
+                       epi=epi, variant=variant).cpu()
+        ref = _gemm_ref(a, w, b, r, epi, 1.0, 0)
+        assert torch.allclose(out, ref, atol=3e-5, rtol=1e-5), (epi, (out - ref).abs().max())
+
+
+def test_gemm_ring_deterministic_and_qscale(built_lib, cuda_dev):
+    from tokenhmr_amd import ops
+    a, w, b = _rand(192, 1280, seed=1).to(cuda_dev), _rand(3840, 1280, seed=2, scale=0.03).to(cuda_dev), _rand(3840, seed=3).to(cuda_dev)
+    kw = dict(epi="bias_qscale", qscale=80 ** -0.5, qcols=1280)
+    ref = ops.gemm(a, w, b, variant="128x160", **kw)
+    for v in ("ring8", "ring4/k4"):
+        o1, o2 = ops.gemm(a, w, b, variant=v, **kw), ops.gemm(a, w, b, variant=v, **kw)
+        assert torch.equal(o1, o2)                                  # fixed-order split-K reduction
+        assert torch.allclose(o1, ref, atol=2e-5, rtol=1e-5)
+    # ksplit = 1 accumulates K in the same order as the big-tile kernel: bit-identical
+    assert torch.equal(ops.gemm(a, w, b, variant="ring8", **kw), ref)
+
+
+def test_gemm_ring_rejects(built_lib, cuda_dev):
+    from tokenhmr_amd import ops, _cabi
+    a, w = _rand(64, 96, seed=1).to(cuda_dev), _rand(64, 96, seed=2).to(cuda_dev)
+    with pytest.raises(_cabi.EngineError):
+        ops.gemm(a, w, variant="ring4/k2")            # 96 % 64 != 0
+
+
 def test_gelu_epilogue_ulp(built_lib, cuda_dev):
     """The epilogue's branch-free erf (csrc/common.h erf_fast) against fp64 GELU on a dense grid.  A has x in column 0 and
     W a single 1, so C[m, n] = gelu(x_m) with no accumulation error.  fp32 GELU itself loses bits to the 1+erf cancellation

@@ -27,9 +27,15 @@ constexpr int KS = 88;   // K row stride in LDS (floats): conflict-free for ds_r
 constexpr int VS = 84;   // V row stride in LDS (floats): conflict-free for ds_read_b32 (rows 4 apart)
 constexpr int F4_PER_THREAD = NTOK * (HD / 4) / 256;   // 15 float4 of a 192x80 tile per thread
 
+// QT = 16-query tiles per wave: 3 -> one workgroup covers all 192 queries of a (crop, head) (batched path); 1 -> three
+// workgroups of 64 queries each, all staging the same K / V (few crops: B*16 workgroups cannot occupy 256 CUs).  Every query
+// is computed by the same instruction sequence either way, so the two variants are bit-identical.
+template <int QT>
 __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out) {
+    constexpr int QB = 3 / QT;      // query blocks per (crop, head)
     __shared__ __attribute__((aligned(16))) float smem[NTOK * KS];   // K, later overwritten by V
-    const int b = blockIdx.x / NH, h = blockIdx.x % NH;
+    const int bh = blockIdx.x / QB, qb = blockIdx.x - bh * QB;
+    const int b = bh / NH, h = bh % NH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const float* base = qkv + (int64_t)b * NTOK * QKV_LD + h * HD;
@@ -43,10 +49,10 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
     }
     // ---- Q fragments: B operand of S^T = K Q^T.  B[kslot g][j = query l15]; with the k-permutation,
     //      register qf[qt][j][t] = Q[q0 + 16 qt + l15][16 j + 4 g + t] ----
-    const int q0 = wave * 48;
-    f32x4 qf[3][5];
+    const int q0 = (qb * 4 + wave) * 16 * QT;
+    f32x4 qf[QT][5];
 #pragma unroll
-    for (int qt = 0; qt < 3; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int j = 0; j < 5; ++j)
             qf[qt][j] = *reinterpret_cast<const f32x4*>(base + (int64_t)(q0 + qt * 16 + l15) * QKV_LD + j * 16 + g * 4);
@@ -58,9 +64,9 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
     __syncthreads();
 
     // ---- S^T tiles: s[qt][kt][r] = S[q0 + 16 qt + l15][16 kt + 4 g + r] ----
-    f32x4 s[3][12];
+    f32x4 s[QT][12];
 #pragma unroll
-    for (int qt = 0; qt < 3; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int kt = 0; kt < 12; ++kt) s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int qt = 0; qt < 3; ++qt)
+                for (int qt = 0; qt < QT; ++qt)
                     s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[t], qf[qt][j][t], s[qt][kt], 0, 0, 0);
         }
     }
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
     // ---- softmax over the 192 keys of each query (4 lanes x 48 registers per query) ----
     constexpr float LOG2E = 1.44269504088896340736f;
 #pragma unroll
-    for (int qt = 0; qt < 3; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         float m = s[qt][0][0];
 #pragma unroll
         for (int kt = 0; kt < 12; ++kt)
@@ -124,9 +130,9 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
 
     // ---- O^T = V^T P^T: A[i = d l15][kslot g] = V[16 kt + 4 g + r][16 dt + l15], B[kslot g][j = query l15] = P register.
     //      The transposed product leaves each lane with 4 CONSECUTIVE d of one query -> 16-byte output stores. ----
-    f32x4 o[3][5];
+    f32x4 o[QT][5];
 #pragma unroll
-    for (int qt = 0; qt < 3; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int dt = 0; dt < 5; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
             for (int dt = 0; dt < 5; ++dt) {
                 const float vb = vrow[dt * 16];
 #pragma unroll
-                for (int qt = 0; qt < 3; ++qt)
+                for (int qt = 0; qt < QT; ++qt)
                     o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb, s[qt][kt][r], o[qt][dt], 0, 0, 0);
             }
         }
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
     // ---- store: D layout of 16x16: col = lane&15 -> query, row = 4*(lane>>4) + reg -> d  (one float4 per tile) ----
     float* obase = out + (int64_t)b * NTOK * DIM + h * HD;
 #pragma unroll
-    for (int qt = 0; qt < 3; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int dt = 0; dt < 5; ++dt)
             *reinterpret_cast<f32x4*>(obase + (int64_t)(q0 + qt * 16 + l15) * DIM + dt * 16 + g * 4) = o[qt][dt];
@@ -158,6 +164,8 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
 
 int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s) {
     if (B <= 0) return -1;
-    hipLaunchKernelGGL(vit_attention_kernel, dim3(B * NH), dim3(256), 0, s, qkv, out);
+    // while 48*B workgroups of 64 queries still fit the 512 resident slots (2 per CU) they finish sooner than 16*B of 192
+    if (B <= 10) hipLaunchKernelGGL(vit_attention_kernel<1>, dim3(B * NH * 3), dim3(256), 0, s, qkv, out);
+    else hipLaunchKernelGGL(vit_attention_kernel<3>, dim3(B * NH), dim3(256), 0, s, qkv, out);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -133,11 +133,17 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // host-side launch helpers (defined in the .hip files); all return 0 / negative
 int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s);          // gemm_f32.hip
+// small-M path: 64x64 tiles, `ring`-deep LDS-DMA ring (4 or 8), optional split-K into part[ksplit][M][N] (epilogue then
+// applied by launch_splitk_epilogue / launch_splitk_resid_ln)
+int launch_gemm_ring(const GemmArgs& a, int epi, int ring, int ksplit, float* part, hipStream_t s);   // gemm_f32.hip
 int launch_gemm_skinny(const GemmArgs& a, int epi, hipStream_t s);                // gemm_skinny.hip
 int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s);     // attention.hip
 // rowops.hip
 int launch_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int D, float eps, int relu,
                      hipStream_t s);
+int launch_splitk_epilogue(const GemmArgs& a, int epi, const float* part, int S, hipStream_t s);
+int launch_splitk_resid_ln(const float* part, int S, int rows, int D, const float* bias, const float* resid, float* xout,
+                           const float* gamma, const float* beta, float* y, float eps, hipStream_t s);
 int launch_add_ln64(const float* x, const float* y, const float* g, const float* b, float* s_out, float* z_out, int rows,
                     float eps, hipStream_t s);
 int launch_im2col_patch(const float* img, float* A, int B, hipStream_t s);

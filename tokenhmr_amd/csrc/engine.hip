@@ -30,6 +30,8 @@ constexpr int CODE = 256, VQW = 512, VQJ = 21;
 constexpr int NV = 6890, NJ = 24, NB = 10, NP = 207;
 constexpr float VIT_EPS = 1e-6f, LN_EPS = 1e-5f;
 constexpr float FOCAL = 5000.0f, IMG = 256.0f;
+// small-batch ViT path (gemm_ring_kernel): used while M = 192*B <= kSmallM; crossovers measured in profiles/r1_small_batch.md
+constexpr int kSmallM = 1152, kSplitKMax = 4;     // B <= 6
 
 thread_local std::string g_last_error;
 
@@ -73,7 +75,7 @@ struct thmr_engine {
     int vq_len[5] = {160, 125, 90, 55, 21};
     // scratch offsets (floats)
     struct {
-        size_t x, h, big;
+        size_t x, h, big, part;
         size_t dx, dh, dv, dq, dca, dff, ro;
         size_t mt, cf, cf2, y1, tT, u, yt, y, s, z0, zh, nl, nl2;
         size_t feat, gat, act0, act1, act2, bpose, tokidx;
@@ -297,6 +299,7 @@ void layout_scratch(thmr_engine* e) {
     s.x = take(M * DIM);
     s.h = take(M * DIM);
     s.big = take(M * 6144);
+    s.part = take((size_t)kSplitKMax * kSmallM * DIM);   // split-K partial sums of the small-batch proj / fc2 GEMMs
     s.dx = take(B * E); s.dh = take(B * E); s.dv = take(B * INNER); s.dq = take(B * INNER); s.dca = take(B * INNER);
     s.dff = take(B * DEC_MLP); s.ro = take(B * 32);
     s.mt = take(B * TN * HID); s.cf = take(B * TN * HID); s.cf2 = take(B * TN * HID);
@@ -364,47 +367,71 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         LAUNCH_OK(launch_gemm(a, EPI_BIAS_POS, -1, st));
     }
     const float qscale = 1.0f / sqrtf(80.0f);   // head_dim ** -0.5  (vit.py:101)
+    // Few crops (M <= kSmallM): the N = 1280 GEMMs run split-K on the 64x64 ring kernel and their partial sums are reduced
+    // inside the residual + LayerNorm kernel that follows them anyway; qkv / fc1 use the ring kernel up to M = 384.
+    const bool small = M <= kSmallM, ring_wide = M <= 384;
+    // one split factor for the whole regime, so a crop's result does not depend on how many crops share its batch (B <= 6)
+    const int ks_proj = kSplitKMax, ks_fc2 = kSplitKMax;
+    float* part = e->S(e->so.part);
+    // x += Linear(A) + bias;  y = LayerNorm(x)      (vit.py:149 / :150 followed by the next norm)
+    auto resid_linear_ln = [&](int cls, const float* A, int K, const float* Wt, const float* bias, int ks, const float* g,
+                               const float* bt, float* y) -> int {
+        const double fl = 2.0 * M * DIM * (double)K, by = 4.0 * ((double)M * K + (double)DIM * K + 2.0 * M * DIM);
+        if (small) {
+            {
+                ProfScope ps(e, st, cls, fl, by);
+                GemmArgs a = mk(A, K, Wt, K, nullptr, nullptr, 0, x, DIM, M, DIM, K);
+                LAUNCH_OK(launch_gemm_ring(a, EPI_NONE, 4, ks, part, st));
+            }
+            ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (ks + 3.0) * M * DIM);
+            LAUNCH_OK(launch_splitk_resid_ln(part, ks, M, DIM, bias, x, x, g, bt, y, VIT_EPS, st));
+        } else {
+            {
+                ProfScope ps(e, st, cls, fl, by);
+                GemmArgs a = mk(A, K, Wt, K, bias, x, DIM, x, DIM, M, DIM, K);
+                LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, -1, st));
+            }
+            ProfScope ps(e, st, THMR_PROF_LN, 0, 8.0 * M * DIM);
+            LAUNCH_OK(launch_layernorm(x, g, bt, y, M, DIM, VIT_EPS, 0, st));
+        }
+        return 0;
+    };
+    {
+        ProfScope ps(e, st, THMR_PROF_LN, 0, 8.0 * M * DIM);
+        LAUNCH_OK(launch_layernorm(x, e->W("backbone.blocks.0.norm1.weight"), e->W("backbone.blocks.0.norm1.bias"), h, M, DIM,
+                                   VIT_EPS, 0, st));
+    }
     for (int i = 0; i < e->vit_depth; ++i) {
         const std::string p = "backbone.blocks." + std::to_string(i) + ".";
-        {
-            ProfScope ps(e, st, THMR_PROF_LN, 0, 8.0 * M * DIM);
-            LAUNCH_OK(launch_layernorm(x, e->W(p + "norm1.weight"), e->W(p + "norm1.bias"), h, M, DIM, VIT_EPS, 0, st));
-        }
+        const bool last = i + 1 == e->vit_depth;
+        const std::string nn = last ? std::string("backbone.last_norm.") : "backbone.blocks." + std::to_string(i + 1) + ".norm1.";
         {   // qkv Linear; q columns scaled in the epilogue (vit.py:112,116)
             ProfScope ps(e, st, THMR_PROF_GEMM_QKV, 2.0 * M * DIM * 3.0 * DIM, 4.0 * ((double)M * DIM + 3.0 * DIM * DIM + 3.0 * M * DIM));
             GemmArgs a = mk(h, DIM, e->W(p + "attn.qkv.weight"), DIM, e->W(p + "attn.qkv.bias"), nullptr, 0, big, 3 * DIM, M,
                             3 * DIM, DIM);
             a.qscale = qscale; a.qcols = DIM;
-            LAUNCH_OK(launch_gemm(a, EPI_BIAS_QSCALE, -1, st));
+            if (ring_wide) LAUNCH_OK(launch_gemm_ring(a, EPI_BIAS_QSCALE, 4, 1, nullptr, st));
+            else LAUNCH_OK(launch_gemm(a, EPI_BIAS_QSCALE, -1, st));
         }
         {
             ProfScope ps(e, st, THMR_PROF_ATTN, 4.0 * B * HEADS * 192.0 * 192.0 * 80.0, 4.0 * (4.0 * M * DIM));
             LAUNCH_OK(launch_vit_attention(big, h, B, st));
         }
-        {   // proj + residual (vit.py:123,149)
-            ProfScope ps(e, st, THMR_PROF_GEMM_PROJ, 2.0 * M * DIM * (double)DIM, 4.0 * (3.0 * M * DIM + (double)DIM * DIM));
-            GemmArgs a = mk(h, DIM, e->W(p + "attn.proj.weight"), DIM, e->W(p + "attn.proj.bias"), x, DIM, x, DIM, M, DIM, DIM);
-            LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, -1, st));
-        }
-        {
-            ProfScope ps(e, st, THMR_PROF_LN, 0, 8.0 * M * DIM);
-            LAUNCH_OK(launch_layernorm(x, e->W(p + "norm2.weight"), e->W(p + "norm2.bias"), h, M, DIM, VIT_EPS, 0, st));
-        }
+        // proj + residual, then norm2 (vit.py:123,149,150)
+        if (int rc = resid_linear_ln(THMR_PROF_GEMM_PROJ, h, DIM, e->W(p + "attn.proj.weight"), e->W(p + "attn.proj.bias"), ks_proj,
+                                     e->W(p + "norm2.weight"), e->W(p + "norm2.bias"), h))
+            return rc;
         {   // fc1 + exact GELU (vit.py:83-84)
             ProfScope ps(e, st, THMR_PROF_GEMM_FC1, 2.0 * M * DIM * (double)MLP, 4.0 * ((double)M * DIM + (double)DIM * MLP + (double)M * MLP));
             GemmArgs a = mk(h, DIM, e->W(p + "mlp.fc1.weight"), DIM, e->W(p + "mlp.fc1.bias"), nullptr, 0, big, MLP, M, MLP, DIM);
-            LAUNCH_OK(launch_gemm(a, EPI_BIAS_GELU, -1, st));
+            if (ring_wide) LAUNCH_OK(launch_gemm_ring(a, EPI_BIAS_GELU, 4, 1, nullptr, st));
+            else LAUNCH_OK(launch_gemm(a, EPI_BIAS_GELU, -1, st));
         }
-        {   // fc2 + residual (vit.py:85,150)
-            ProfScope ps(e, st, THMR_PROF_GEMM_FC2, 2.0 * M * DIM * (double)MLP, 4.0 * ((double)M * MLP + (double)DIM * MLP + 2.0 * M * DIM));
-            GemmArgs a = mk(big, MLP, e->W(p + "mlp.fc2.weight"), MLP, e->W(p + "mlp.fc2.bias"), x, DIM, x, DIM, M, DIM, MLP);
-            LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, -1, st));
-        }
-    }
-    {   // last_norm (vit.py:335); kept token-major (the :337 permute is undone by token_head.py:69)
-        ProfScope ps(e, st, THMR_PROF_LN, 0, 8.0 * M * DIM);
-        LAUNCH_OK(launch_layernorm(x, e->W("backbone.last_norm.weight"), e->W("backbone.last_norm.bias"),
-                                   feats_out ? feats_out : h, M, DIM, VIT_EPS, 0, st));
+        // fc2 + residual (vit.py:85,150), then the next block's norm1 — or last_norm (vit.py:335), kept token-major: the
+        // :337 permute is undone by token_head.py:69
+        if (int rc = resid_linear_ln(THMR_PROF_GEMM_FC2, big, MLP, e->W(p + "mlp.fc2.weight"), e->W(p + "mlp.fc2.bias"), ks_fc2,
+                                     e->W(nn + "weight"), e->W(nn + "bias"), last && feats_out ? feats_out : h))
+            return rc;
     }
     return 0;
 }
@@ -918,8 +945,29 @@ int thmr_op_gemm(const float* A, int64_t lda, const float* W, const float* bias,
     if ((epi == EPI_BIAS_RESID || epi == EPI_BIAS_POS) && !resid) return fail(e, THMR_ERR_INVALID, "epilogue needs resid");
     GemmArgs a = mk(A, lda, W, K, bias, resid, ldc, C, ldc, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
-    if (variant == 2) { LAUNCH_OK(launch_gemm_skinny(a, epi, static_cast<hipStream_t>(stream))); }
-    else { LAUNCH_OK(launch_gemm(a, epi, variant, static_cast<hipStream_t>(stream))); }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (variant >= 100 && variant < 120) {
+        // small-M ring kernel: 100 + 10*(ring == 8) + log2(ksplit).  The stateless entry point keeps a grow-only partial-sum
+        // workspace per process (the engine uses its own scratch arena instead).
+        const int ring = variant >= 110 ? 8 : 4, ksplit = 1 << (variant % 10);
+        static float* ws = nullptr;
+        static size_t ws_floats = 0;
+        if (epi == EPI_BIAS_POS) return fail(e, THMR_ERR_INVALID, "ring GEMM has no pos-embed epilogue");
+        if (ksplit > 1) {
+            const size_t need = (size_t)ksplit * M * N;
+            if (need > ws_floats) {
+                if (ws) { HIP_OK(hipStreamSynchronize(st)); HIP_OK(hipFree(ws)); ws = nullptr; ws_floats = 0; }
+                HIP_OK(hipMalloc(&ws, need * sizeof(float)));
+                ws_floats = need;
+            }
+        }
+        LAUNCH_OK(launch_gemm_ring(a, epi, ring, ksplit, ws, st));
+        if (ksplit > 1) LAUNCH_OK(launch_splitk_epilogue(a, epi, ws, ksplit, st));
+    } else if (variant == 2) {
+        LAUNCH_OK(launch_gemm_skinny(a, epi, st));
+    } else {
+        LAUNCH_OK(launch_gemm(a, epi, variant, st));
+    }
     return 0;
 }
 

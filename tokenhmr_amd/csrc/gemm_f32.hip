@@ -378,6 +378,146 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
     store_tile<TM, TN, EPI>(a, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Small-M GEMM (few crops: M = 192*B with B <~ 8).  The big-tile kernel above leaves most of the 256 CUs idle there and
+// its 2-buffer pipeline pays one full memory round trip per 32-deep K tile when only one block sits on a CU
+// (measured 1.1 us per K tile at B = 1: 45 us for K = 1280, 157 us for K = 5120 — profiles/r1_small_batch.md).
+//   * 64x64 tiles (2x2 waves of 32x32), ST-deep LDS ring fed by global_load_lds: the copy of K tile kt+ST-1 is issued
+//     while tile kt is multiplied, completion is tracked with s_waitcnt vmcnt(N) (LDS-DMA returns in order), and the
+//     ONE barrier per K tile sits in the middle of the tile's MFMAs so it is covered by queued matrix work.
+//   * split-K: `ksplit` blocks share an output tile, each reducing K/ksplit, so the N = 1280 GEMMs (60 tiles at B = 1)
+//     still occupy every CU.  PARTIAL blocks write raw fp32 partial tiles to part[ksplit][M][N]; they are summed in
+//     a FIXED order (deterministic) by splitk_* kernels (rowops.hip), which also apply the epilogue and, in the engine,
+//     the LayerNorm that follows proj / fc2 anyway — so split-K adds no launch.
+//   * block -> work map: (column tile, K slice) pairs are dealt round-robin to the 8 XCDs and the tiles_m row tiles that
+//     share that W slice run on the same XCD, so W is fetched from HBM once and re-read from that XCD's L2.
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int ST, int EPI, bool PARTIAL>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs a, int tiles_m, int groups, int ksplit, float* part) {
+    constexpr int BM = 64, BN = 64, NP = 4;       // NP = DMA wave-instructions per wave per K tile (2 for A, 2 for W)
+    static_assert((ST & (ST - 1)) == 0 && ST >= 4, "ring depth must be a power of two >= 4");
+    __shared__ __attribute__((aligned(16))) float smem[ST * (BM + BN) * LDK];
+    float* As = smem;                       // [ST][BM][LDK]
+    float* Bs = smem + ST * BM * LDK;       // [ST][BN][LDK]
+
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int gl = within / tiles_m, tile_m = within - gl * tiles_m;
+    const int g = gl * 8 + xcd;
+    if (g >= groups) return;
+    const int tile_n = g / ksplit, sp = g - tile_n * ksplit;
+    const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+    const int kper = a.K / ksplit, kbeg = sp * kper, nk = kper / BK;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+
+    // wave instruction q = wave + 4p covers tile rows 8q..8q+7 (see the DMA notes of gemm_f32_kernel)
+    const float* Ag[2];
+    const float* Wg[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = (wave + 4 * p) * 8 + (lane >> 3), cs = (lane & 7) ^ ((row >> 1) & 7);
+        Ag[p] = a.A + (int64_t)min(bm0 + row, a.M - 1) * a.lda + kbeg + cs * 4;
+        Wg[p] = a.W + (int64_t)min(bn0 + row, a.N - 1) * a.ldw + kbeg + cs * 4;
+    }
+    auto dma_tile = [&](int kt) {
+        const int st = kt & (ST - 1), k0 = kt * BK;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)(Ag[p] + k0), (lds_void*)(As + (st * BM + (wave + 4 * p) * 8) * LDK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(Wg[p] + k0), (lds_void*)(Bs + (st * BN + (wave + 4 * p) * 8) * LDK), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
+    int koff[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) koff[j] = (((2 * j + lhalf) ^ ((lrow >> 1) & 7)) << 2);
+    f32x4 af[2], bf[2];
+    auto read_frags = [&](int kt, int j, int slot) {
+        const int st = kt & (ST - 1);
+        af[slot] = *reinterpret_cast<const f32x4*>(As + (st * BM + wm0 + lrow) * LDK + koff[j]);
+        bf[slot] = *reinterpret_cast<const f32x4*>(Bs + (st * BN + wn0 + lrow) * LDK + koff[j]);
+    };
+    // one k-group: MFMA 0, then the fragment reads of the NEXT group (nxt() may be empty), then MFMAs 1-3.  The order is
+    // pinned with sched_barrier fences: the reads must not precede MFMA 0 (hipcc waits lgkmcnt(0) before it, which would then
+    // also wait for the reads just issued) and must not sink below the MFMAs that hide their latency.
+    auto group = [&](int slot, auto nxt) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][0], bf[slot][0], acc[0][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        nxt();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 1; t < 4; ++t) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][t], bf[slot][t], acc[0][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // prologue: K tiles 0..ST-2 in flight; tile 0 must have landed (for every wave) before the first fragment read
+#pragma unroll
+    for (int t = 0; t < ST - 1; ++t)
+        if (t < nk) dma_tile(t);
+    if (nk >= ST - 1) wait_vm_barrier<(ST - 2) * NP>(); else wait_vm_barrier<0>();
+    read_frags(0, 0, 0);
+
+    auto tile = [&](int kt, bool last) {      // `last` is a literal at both call sites
+        group(0, [&] { read_frags(kt, 1, 1); });
+        group(1, [&] { read_frags(kt, 2, 0); });
+        if (!last) {
+            // tile kt+1 landed (in-order completion: at most the ST-3 younger tiles may still be in flight); after the
+            // barrier every wave is past tile kt-1, whose ring slot receives tile kt+ST-1
+            if (kt + ST - 2 < nk) wait_vm_barrier<(ST - 3) * NP>(); else wait_vm_barrier<0>();
+            if (kt + ST - 1 < nk) dma_tile(kt + ST - 1);
+        }
+        group(0, [&] { read_frags(kt, 3, 1); });
+        group(1, [&] { if (!last) read_frags(kt + 1, 0, 0); });
+    };
+    for (int kt = 0; kt < nk - 1; ++kt) tile(kt, false);
+    tile(nk - 1, true);
+
+    if constexpr (PARTIAL) {
+        GemmArgs pa = a;
+        pa.C = part + (int64_t)sp * a.M * a.N;
+        pa.ldc = a.N;
+        store_tile<1, 1, EPI_NONE>(pa, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
+    } else {
+        store_tile<1, 1, EPI>(a, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
+    }
+}
+
+template <int ST>
+int launch_ring(const GemmArgs& a, int epi, int ksplit, float* part, hipStream_t s) {
+    const int tiles_m = (a.M + 63) / 64, tiles_n = (a.N + 63) / 64;
+    const int groups = tiles_n * ksplit;
+    dim3 grid(8 * tiles_m * ((groups + 7) / 8)), block(256);
+    if (ksplit > 1) {
+        hipLaunchKernelGGL((gemm_ring_kernel<ST, EPI_NONE, true>), grid, block, 0, s, a, tiles_m, groups, ksplit, part);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+#define THMR_RING_CASE(E)                                                                                           \
+    case E:                                                                                                         \
+        hipLaunchKernelGGL((gemm_ring_kernel<ST, E, false>), grid, block, 0, s, a, tiles_m, groups, 1, nullptr);     \
+        break;
+    switch (epi) {
+        THMR_RING_CASE(EPI_NONE)
+        THMR_RING_CASE(EPI_BIAS)
+        THMR_RING_CASE(EPI_BIAS_GELU)
+        THMR_RING_CASE(EPI_BIAS_RELU)
+        THMR_RING_CASE(EPI_BIAS_RESID)
+        THMR_RING_CASE(EPI_BIAS_QSCALE)
+        default: return -1;
+    }
+#undef THMR_RING_CASE
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 template <int WM, int WN, int TM, int TN, bool DMA>
 int launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -451,4 +591,12 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         case 9: return launch_cfg<2, 2, 1, 1, true>(a, epi, s);
         default: return launch_cfg<2, 2, 2, 2, true>(a, epi, s);
     }
+}
+
+// ring = 4 | 8 (LDS ring depth: 64 KB -> 2 blocks/CU, 128 KB -> 1 block/CU with twice the prefetch distance);
+// ksplit > 1 writes raw partial sums to part[ksplit][M][N] and applies NO epilogue (see launch_splitk_*).
+int launch_gemm_ring(const GemmArgs& a, int epi, int ring, int ksplit, float* part, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || ksplit < 1 || (a.K % (BK * ksplit)) != 0) return -1;
+    if ((a.lda % 4) != 0 || (a.ldw % 4) != 0 || (ksplit > 1 && part == nullptr)) return -1;
+    return ring == 8 ? launch_ring<8>(a, epi, ksplit, part, s) : launch_ring<4>(a, epi, ksplit, part, s);
 }

@@ -265,6 +265,75 @@ __global__ void conv_repack_pad_kernel(const float* __restrict__ w, float* __res
     wp[idx] = ci < ci_n ? w[((int64_t)co * ci_n + ci) * kk + k] : 0.f;
 }
 
+// ---- split-K reducers for gemm_ring_kernel (gemm_f32.hip): part[S][M][N] summed over s in a FIXED order ----
+// generic: C = epilogue(sum_s part[s]) — float4 per thread
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs a, const float* __restrict__ part, int S) {
+    const int n4 = a.N >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)a.M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx - (int64_t)m * n4) * 4;
+    const int64_t mn = (int64_t)a.M * a.N;
+    const float* p = part + (int64_t)m * a.N + n;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(p + s * mn);
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI != EPI_NONE) bias = *reinterpret_cast<const f32x4*>(a.bias + n);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = gemm_epilogue<EPI>(a, v[e], bias[e], m, n + e);
+    *reinterpret_cast<f32x4*>(a.C + (int64_t)m * a.ldc + n) = o;
+}
+
+// fused for the ViT residual stream (vit.py:149-150 followed by the next norm, :149/:150/:335):
+//   x_new = resid + (sum_s part[s] + bias);  y = LayerNorm(x_new)        one wave per row, D = NV*256
+template <int NV>
+__global__ __launch_bounds__(256) void splitk_resid_ln_kernel(const float* __restrict__ part, int S, int64_t mn,
+                                                              const float* __restrict__ bias, const float* resid, float* xout,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ y, int rows, float eps) {
+    constexpr int D = NV * 256;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t ro = (int64_t)row * D;
+    f32x4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        f32x4 t = *reinterpret_cast<const f32x4*>(part + ro + c);
+        for (int s = 1; s < S; ++s) t += *reinterpret_cast<const f32x4*>(part + s * mn + ro + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + c);
+        const f32x4 r = *reinterpret_cast<const f32x4*>(resid + ro + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = r[e] + (t[e] + b[e]);
+        *reinterpret_cast<f32x4*>(xout + ro + c) = t;
+        v[i] = t;
+        sum += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+    const float mean = wave_sum(sum) * (1.0f / D);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            sq += d * d;
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) * (1.0f / D) + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+        *reinterpret_cast<f32x4*>(y + ro + c) = o;
+    }
+}
+
 }  // namespace
 
 int launch_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int D, float eps, int relu,
@@ -277,6 +346,33 @@ int launch_layernorm(const float* x, const float* g, const float* b, float* y, i
         hipLaunchKernelGGL(ln_wave_kernel<4>, grid, block, 0, s, x, g, b, y, rows, eps, relu);
     else
         hipLaunchKernelGGL(ln_generic_kernel, grid, block, 0, s, x, g, b, y, rows, D, eps, relu);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_splitk_epilogue(const GemmArgs& a, int epi, const float* part, int S, hipStream_t s) {
+    if ((a.N & 3) || (a.ldc & 3) || S < 1) return -1;
+    const int64_t total = (int64_t)a.M * (a.N >> 2);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+#define THMR_SK_CASE(E) \
+    case E: hipLaunchKernelGGL(splitk_epilogue_kernel<E>, grid, block, 0, s, a, part, S); break;
+    switch (epi) {
+        THMR_SK_CASE(EPI_NONE)
+        THMR_SK_CASE(EPI_BIAS)
+        THMR_SK_CASE(EPI_BIAS_GELU)
+        THMR_SK_CASE(EPI_BIAS_RELU)
+        THMR_SK_CASE(EPI_BIAS_RESID)
+        THMR_SK_CASE(EPI_BIAS_QSCALE)
+        default: return -1;
+    }
+#undef THMR_SK_CASE
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_splitk_resid_ln(const float* part, int S, int rows, int D, const float* bias, const float* resid, float* xout,
+                           const float* gamma, const float* beta, float* y, float eps, hipStream_t s) {
+    if (rows <= 0 || S < 1 || D != 1280) return -1;
+    hipLaunchKernelGGL(splitk_resid_ln_kernel<5>, dim3((rows + 3) / 4), dim3(256), 0, s, part, S, (int64_t)rows * D, bias, resid,
+                       xout, gamma, beta, y, rows, eps);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
