@@ -196,6 +196,32 @@ int thmr_eval_pose(const float* pred_joints_dev, const float* gt_joints_dev, int
 int thmr_regress_joints(const float* J_dev, const float* verts_dev, int32_t n_joints, int32_t n_verts, int32_t B,
                         float* out_dev, void* stream);
 
+/* Crop preprocessing right before the hot path: decoded uint8 frame on the device + one affine per crop ->
+ * normalised (n,3,patch,patch) fp32 = batch['img'].  Replaces, per crop, the reference's CPU-side
+ *   skimage.filters.gaussian anti-alias of the whole frame   tokenhmr/lib/datasets/vitdet_dataset.py:62-68, utils.py:583-587
+ *   cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT)            tokenhmr/lib/datasets/utils.py:351-356 (generate_image_patch_cv2)
+ *   [:, :, ::-1], HWC->CHW float32, (x - mean)/std           vitdet_dataset.py:75-80, utils.py:599-617
+ * with OpenCV's fixed-point bilinear and scipy's correlate1d arithmetic reproduced exactly (csrc/crop.hip).  The affine itself
+ * (gen_trans_from_patch_cv + cv2.getAffineTransform, utils.py:81-128) is 3 points of host arithmetic and stays with the caller
+ * (tokenhmr_amd/preprocess.py mirrors ViTDetDataset).
+ *   M       forward 2x3 matrix exactly as passed to cv2.warpAffine (src -> dst), row-major
+ *   sigma   gaussian sigma of the anti-alias blur applied before the warp, 0 = none; truncate: 4.0 (vitdet) / 3.0 (get_example)
+ *   frame   (H, W, 3) uint8, row_stride bytes per row; swap_rb = 1 flips the channel order (BGR frame -> RGB planes)
+ *   mean/std  in 0..255 units, indexed by OUTPUT channel.
+ * The handle owns grow-only device scratch for the blurred regions; growing it synchronises the stream. */
+typedef struct thmr_crop_desc {
+    double M[6];
+    double sigma;
+    double truncate;
+} thmr_crop_desc;
+typedef struct thmr_cropper thmr_cropper;
+int  thmr_cropper_create(int32_t device, thmr_cropper** out);
+void thmr_cropper_destroy(thmr_cropper* c);
+const char* thmr_cropper_last_error(const thmr_cropper* c);
+int  thmr_cropper_run(thmr_cropper* c, const uint8_t* frame_dev, int32_t H, int32_t W, int64_t row_stride,
+                      const thmr_crop_desc* crops_host, int32_t n, int32_t patch, int32_t swap_rb, const float* mean_host,
+                      const float* std_host, float* out_dev, void* stream);
+
 /* Built-in profiler: HIP events recorded on the launch stream around each kernel class. */
 int thmr_prof_enable(thmr_engine* e, int32_t on);
 int thmr_prof_collect(thmr_engine* e, thmr_prof_entry* entries /*[THMR_PROF_NUM]*/, int32_t reset);

@@ -42,6 +42,10 @@ class Outputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in OUTPUT_FIELDS]
 
 
+class CropDesc(C.Structure):
+    _fields_ = [("M", C.c_double * 6), ("sigma", C.c_double), ("truncate", C.c_double)]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double), ("launches", C.c_int64)]
 
@@ -100,11 +104,18 @@ def load():
     lib.thmr_smpl_forward.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
     lib.thmr_eval_pose.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.thmr_regress_joints.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    lib.thmr_cropper_create.argtypes = [i32, C.POINTER(vp)]
+    lib.thmr_cropper_destroy.argtypes = [vp]
+    lib.thmr_cropper_destroy.restype = None
+    lib.thmr_cropper_last_error.argtypes = [vp]
+    lib.thmr_cropper_last_error.restype = C.c_char_p
+    lib.thmr_cropper_run.argtypes = [vp, vp, i32, i32, i64, C.POINTER(CropDesc), i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, vp]
     lib.thmr_prof_enable.argtypes = [vp, i32]
     lib.thmr_prof_collect.argtypes = [vp, C.POINTER(ProfEntry), i32]
     for name in declared_symbols():
         fn = getattr(lib, name)
-        if name not in ("thmr_build_info", "thmr_last_error", "thmr_destroy", "thmr_smpl_destroy"):
+        if name not in ("thmr_build_info", "thmr_last_error", "thmr_destroy", "thmr_smpl_destroy", "thmr_cropper_destroy",
+                        "thmr_cropper_last_error"):
             fn.restype = C.c_int
     if lib.thmr_abi_version() != ABI_VERSION:
         raise RuntimeError("libtokenhmr_hip.so ABI version mismatch")
