@@ -222,7 +222,9 @@ int  thmr_cropper_run(thmr_cropper* c, const uint8_t* frame_dev, int32_t H, int3
                       const thmr_crop_desc* crops_host, int32_t n, int32_t patch, int32_t swap_rb, const float* mean_host,
                       const float* std_host, float* out_dev, void* stream);
 
-/* Built-in profiler: HIP events recorded on the launch stream around each kernel class. */
+/* Built-in profiler: HIP events recorded on the launch stream around each kernel class.
+ * on = 0 off, 1 every class, 2 only the four ViT GEMM classes (an event pair costs ~2 us of stream time; ~330 pairs per
+ * call with on = 1 is ~1 % of a B = 64 step, which is why bench.py times with on = 2). */
 int thmr_prof_enable(thmr_engine* e, int32_t on);
 int thmr_prof_collect(thmr_engine* e, thmr_prof_entry* entries /*[THMR_PROF_NUM]*/, int32_t reset);
 

@@ -83,7 +83,7 @@ struct thmr_engine {
         size_t total;
     } so{};
     // profiler
-    bool prof_on = false;
+    int prof_on = 0;            // 0 off, 1 every kernel class, 2 only the four ViT GEMM classes
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_next = 0;
@@ -323,7 +323,7 @@ struct ProfScope {
     hipStream_t s;
     bool on;
     size_t rec = 0;
-    ProfScope(thmr_engine* e_, hipStream_t s_, int cls, double flops, double bytes) : e(e_), s(s_), on(e_->prof_on) {
+    ProfScope(thmr_engine* e_, hipStream_t s_, int cls, double flops, double bytes) : e(e_), s(s_), on(e_->prof_on == 1 || (e_->prof_on == 2 && cls <= THMR_PROF_GEMM_FC2)) {
         if (!on) return;
         if (e->ev_next + 2 > e->ev_pool.size()) {
             for (int i = 0; i < 512; ++i) {
@@ -1087,7 +1087,7 @@ int thmr_regress_joints(const float* J, const float* verts, int32_t nj, int32_t 
 // ---- profiler ----
 int thmr_prof_enable(thmr_engine* e, int32_t on) {
     if (!e) return fail(e, THMR_ERR_INVALID, "null engine");
-    e->prof_on = on != 0;
+    e->prof_on = on < 0 ? 0 : (on > 2 ? 1 : on);
     return 0;
 }
 

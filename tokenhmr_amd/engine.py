@@ -211,7 +211,8 @@ class Engine:
 
     # ------------------------------------------------------------------ profiler
     def prof_enable(self, on=True):
-        _cabi.check(self.lib.thmr_prof_enable(self.h, 1 if on else 0), self.h)
+        """on: False / True (every kernel class) / "gemm" (only the four ViT GEMM classes: cheapest, see the header)."""
+        _cabi.check(self.lib.thmr_prof_enable(self.h, 2 if on == "gemm" else (1 if on else 0)), self.h)
 
     def prof_collect(self, reset=True):
         arr = (_cabi.ProfEntry * len(_cabi.PROF_NAMES))()
