@@ -41,6 +41,10 @@ struct Slot {
     bool loaded = false;
 };
 
+struct VitBlockW {      // weights of one ViT block (vit.py:128-151), pointers into the weight arena
+    const float *n1w, *n1b, *qkvw, *qkvb, *pw, *pb, *n2w, *n2b, *f1w, *f1b, *f2w, *f2b;
+};
+
 struct ProfRec {
     int cls;
     double flops, bytes;
@@ -58,6 +62,7 @@ struct thmr_engine {
     size_t wfloats = 0, sfloats = 0;
     std::unordered_map<std::string, Slot> slots;
     std::vector<std::string> required;
+    std::vector<VitBlockW> vitw;      // filled by thmr_finalize_weights
     bool smpl_loaded = false, finalized = false;
     std::string err;
     // derived / constant regions (float offsets in weight arena)
@@ -398,17 +403,18 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
     };
     {
         ProfScope ps(e, st, THMR_PROF_LN, 0, 8.0 * M * DIM);
-        LAUNCH_OK(launch_layernorm(x, e->W("backbone.blocks.0.norm1.weight"), e->W("backbone.blocks.0.norm1.bias"), h, M, DIM,
-                                   VIT_EPS, 0, st));
+        LAUNCH_OK(launch_layernorm(x, e->vitw[0].n1w, e->vitw[0].n1b, h, M, DIM, VIT_EPS, 0, st));
     }
+    const float* lastn_w = e->W("backbone.last_norm.weight");
+    const float* lastn_b = e->W("backbone.last_norm.bias");
     for (int i = 0; i < e->vit_depth; ++i) {
-        const std::string p = "backbone.blocks." + std::to_string(i) + ".";
+        const VitBlockW& w = e->vitw[i];
         const bool last = i + 1 == e->vit_depth;
-        const std::string nn = last ? std::string("backbone.last_norm.") : "backbone.blocks." + std::to_string(i + 1) + ".norm1.";
+        const float* nxt_w = last ? lastn_w : e->vitw[i + 1].n1w;      // the norm that follows this block's fc2
+        const float* nxt_b = last ? lastn_b : e->vitw[i + 1].n1b;
         {   // qkv Linear; q columns scaled in the epilogue (vit.py:112,116)
             ProfScope ps(e, st, THMR_PROF_GEMM_QKV, 2.0 * M * DIM * 3.0 * DIM, 4.0 * ((double)M * DIM + 3.0 * DIM * DIM + 3.0 * M * DIM));
-            GemmArgs a = mk(h, DIM, e->W(p + "attn.qkv.weight"), DIM, e->W(p + "attn.qkv.bias"), nullptr, 0, big, 3 * DIM, M,
-                            3 * DIM, DIM);
+            GemmArgs a = mk(h, DIM, w.qkvw, DIM, w.qkvb, nullptr, 0, big, 3 * DIM, M, 3 * DIM, DIM);
             a.qscale = qscale; a.qcols = DIM;
             if (ring_wide) LAUNCH_OK(launch_gemm_ring(a, EPI_BIAS_QSCALE, 4, 1, nullptr, st));
             else LAUNCH_OK(launch_gemm(a, EPI_BIAS_QSCALE, -1, st));
@@ -418,19 +424,16 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             LAUNCH_OK(launch_vit_attention(big, h, B, st));
         }
         // proj + residual, then norm2 (vit.py:123,149,150)
-        if (int rc = resid_linear_ln(THMR_PROF_GEMM_PROJ, h, DIM, e->W(p + "attn.proj.weight"), e->W(p + "attn.proj.bias"), ks_proj,
-                                     e->W(p + "norm2.weight"), e->W(p + "norm2.bias"), h))
-            return rc;
+        if (int rc = resid_linear_ln(THMR_PROF_GEMM_PROJ, h, DIM, w.pw, w.pb, ks_proj, w.n2w, w.n2b, h)) return rc;
         {   // fc1 + exact GELU (vit.py:83-84)
             ProfScope ps(e, st, THMR_PROF_GEMM_FC1, 2.0 * M * DIM * (double)MLP, 4.0 * ((double)M * DIM + (double)DIM * MLP + (double)M * MLP));
-            GemmArgs a = mk(h, DIM, e->W(p + "mlp.fc1.weight"), DIM, e->W(p + "mlp.fc1.bias"), nullptr, 0, big, MLP, M, MLP, DIM);
+            GemmArgs a = mk(h, DIM, w.f1w, DIM, w.f1b, nullptr, 0, big, MLP, M, MLP, DIM);
             if (ring_wide) LAUNCH_OK(launch_gemm_ring(a, EPI_BIAS_GELU, 4, 1, nullptr, st));
             else LAUNCH_OK(launch_gemm(a, EPI_BIAS_GELU, -1, st));
         }
         // fc2 + residual (vit.py:85,150), then the next block's norm1 — or last_norm (vit.py:335), kept token-major: the
         // :337 permute is undone by token_head.py:69
-        if (int rc = resid_linear_ln(THMR_PROF_GEMM_FC2, big, MLP, e->W(p + "mlp.fc2.weight"), e->W(p + "mlp.fc2.bias"), ks_fc2,
-                                     e->W(nn + "weight"), e->W(nn + "bias"), last && feats_out ? feats_out : h))
+        if (int rc = resid_linear_ln(THMR_PROF_GEMM_FC2, big, MLP, w.f2w, w.f2b, ks_fc2, nxt_w, nxt_b, last && feats_out ? feats_out : h))
             return rc;
     }
     return 0;
@@ -794,6 +797,18 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
             if (kEnc[i].ks > 1)
                 LAUNCH_OK(launch_conv_repack_pad(e->W(std::string(kEnc[i].name) + ".weight"), e->warena + e->enc_convp[i],
                                                  kEnc[i].co, kEnc[i].ci, kEnc[i].cp, kEnc[i].ks, st));
+    // per-block weight pointers of the ViT loop, resolved once (the name map is for load time, not for the hot path)
+    e->vitw.resize(e->vit_depth);
+    for (int i = 0; i < e->vit_depth; ++i) {
+        const std::string p = "backbone.blocks." + std::to_string(i) + ".";
+        VitBlockW& w = e->vitw[i];
+        w.n1w = e->W(p + "norm1.weight"); w.n1b = e->W(p + "norm1.bias");
+        w.qkvw = e->W(p + "attn.qkv.weight"); w.qkvb = e->W(p + "attn.qkv.bias");
+        w.pw = e->W(p + "attn.proj.weight"); w.pb = e->W(p + "attn.proj.bias");
+        w.n2w = e->W(p + "norm2.weight"); w.n2b = e->W(p + "norm2.bias");
+        w.f1w = e->W(p + "mlp.fc1.weight"); w.f1b = e->W(p + "mlp.fc1.bias");
+        w.f2w = e->W(p + "mlp.fc2.weight"); w.f2b = e->W(p + "mlp.fc2.bias");
+    }
     e->finalized = true;
     return 0;
 }

@@ -155,10 +155,14 @@ def load_tokenhmr(checkpoint_path="", model_cfg="", dataset_dir="", is_train_sta
     if not os.path.exists(checkpoint_path):
         raise FileNotFoundError(f"Missing full pretrained model from {checkpoint_path}")   # reference: exit(1), misc.py:252-254
     td = dict(cfg.MODEL.SMPL_HEAD.TRANSFORMER_DECODER.__dict__)
-    hcfg = HMRConfig(dec_depth=int(td.get("depth", 6)))
     # torch>=2.6 defaults weights_only=True, but these checkpoints pickle config nodes
     ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)["state_dict"]
     state = {k: v for k, v in ckpt.items() if k.startswith(("backbone.", "smpl_head."))}
+    # the backbone depth is a property of the checkpoint (32 for the released ViT-H, vit.py:17), not of model_config.yaml
+    blocks = {int(k.split(".")[2]) for k in state if k.startswith("backbone.blocks.")}
+    if not blocks or blocks != set(range(len(blocks))):
+        raise KeyError(f"checkpoint has no contiguous 'backbone.blocks.N.*' tensors (found indices {sorted(blocks)[:8]})")
+    hcfg = HMRConfig(vit_depth=len(blocks), dec_depth=int(td.get("depth", 6)))
     tok = torch.load(cfg.MODEL.TOKENIZER_CHECKPOINT_PATH, map_location="cpu", weights_only=False)["net"]
     tok = {k: v for k, v in tok.items() if k.startswith("decoder.decoder.") or k == "quantizer.codebook"}
     mean = __import__("numpy").load(cfg.SMPL.MEAN_PARAMS)
