@@ -52,6 +52,12 @@ def _worker(rank, world, port, total, q):
         out = runner(img)
         ref = D.unpack_records(D.pack_records(_fake_forward(img)))
         ok = all(torch.equal(out[k], ref[k]) for k in ref)
+        # pipelined form used by bench.py: two gathers issued back to back, joined later, in order
+        h1 = D.all_gather_records(D.pack_records(_fake_forward(img[s:e])), total, async_op=True)
+        h2 = D.all_gather_records(D.pack_records(_fake_forward(2.0 * img[s:e])), total, async_op=True)
+        o1, o2 = D.unpack_records(h1.wait()), D.unpack_records(h2.wait())
+        ref2 = D.unpack_records(D.pack_records(_fake_forward(2.0 * img)))
+        ok = ok and all(torch.equal(o1[k], ref[k]) for k in ref) and all(torch.equal(o2[k], ref2[k]) for k in ref2)
         q.put((rank, (s, e), ok, int(out["pred_cam"].shape[0])))
     finally:
         dist.destroy_process_group()

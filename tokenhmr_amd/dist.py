@@ -65,11 +65,29 @@ def broadcast_weights(engine, src: int = 0):
         dist.broadcast(engine.weight_arena, src=src)
 
 
-def all_gather_records(local_rec, total: int):
+class GatherHandle:
+    """An all-gather in flight on the process group's own (RCCL) stream.  wait() makes the CURRENT stream wait for it (no host
+    block) and returns the (total, RECORD_WORDS) records in crop order."""
+
+    def __init__(self, work, buf, sizes, mx):
+        self.work, self.buf, self.sizes, self.mx = work, buf, sizes, mx
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if all(s == self.mx for s in self.sizes):
+            return self.buf                                  # equal shards: the gathered buffer IS the result (no copy)
+        return torch.cat([self.buf[r * self.mx: r * self.mx + s] for r, s in enumerate(self.sizes)], dim=0)
+
+
+def all_gather_records(local_rec, total: int, async_op: bool = False):
     """All-gather the packed records of every rank's shard; returns (total, RECORD_WORDS) in crop order.
-    Shards may differ by one crop, so each rank pads to the maximum shard size."""
+    Shards may differ by one crop, so each rank pads to the maximum shard size.  async_op=True returns a GatherHandle
+    instead: the collective then runs on the RCCL stream while the caller's stream goes on with the next batch (xGMI traffic
+    under the next ViT), and is joined with handle.wait()."""
     if not dist.is_initialized():
-        return local_rec
+        return GatherHandle(None, local_rec, [local_rec.shape[0]], local_rec.shape[0]) if async_op else local_rec
     world = dist.get_world_size()
     sizes = shard_sizes(total, world)
     mx = max(sizes)
@@ -78,9 +96,9 @@ def all_gather_records(local_rec, total: int):
         pad = torch.zeros(mx, local_rec.shape[1], dtype=local_rec.dtype, device=local_rec.device)
         pad[: local_rec.shape[0]] = local_rec
     buf = torch.empty(world * mx, local_rec.shape[1], dtype=local_rec.dtype, device=local_rec.device)
-    dist.all_gather_into_tensor(buf, pad.contiguous())
-    chunks = [buf[r * mx: r * mx + sizes[r]] for r in range(world)]
-    return torch.cat(chunks, dim=0)
+    work = dist.all_gather_into_tensor(buf, pad.contiguous(), async_op=True)
+    h = GatherHandle(work, buf, sizes, mx)
+    return h if async_op else h.wait()
 
 
 class ShardedRunner:
