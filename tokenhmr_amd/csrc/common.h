@@ -168,9 +168,13 @@ int launch_vq_argmin_rows(const float* x, const float* dot, const float* cnorm, 
 int launch_code_norm(const float* cb, float* cn, int ncode, hipStream_t s);
 // lbs.hip
 int launch_lbs_jreg(const float* Jreg, const float* vt, const float* sd, float* Jt, float* Jsd, hipStream_t s);
+// dirsT (20670 x 224): [shapedirs | posedirs | 0]^T built once by launch_lbs_build_dirs; scratch A (B,24,12),
+// xf (B, THMR_LBS_XF) [224 operand floats per crop, then 27*57 regressor partial sums per crop], Jtr (B,24,3), vposed (B,20670)
+constexpr int THMR_LBS_KX = 224, THMR_LBS_XF = 224 + 27 * 57;
+int launch_lbs_build_dirs(const float* sd, const float* pd, float* dirsT, hipStream_t s);
 int launch_lbs(const float* rotmat, const float* betas, const float* cam_t, const float* Jt, const float* Jsd,
-               const int32_t* parents, const float* vt, const float* sd, const float* pd, const float* W,
-               const float* J19, const int32_t* extra, const int32_t* jmap, float* A, float* pf, float* Jtr, float* verts,
+               const int32_t* parents, const float* vt, const float* dirsT, const float* W, const float* J19,
+               const int32_t* extra, const int32_t* jmap, float* A, float* xf, float* Jtr, float* vposed, float* verts,
                float* joints, float* kp2d, float focal_over_size, int B, hipStream_t s);
 int launch_rodrigues(const float* aa, float* R, int n, hipStream_t s);
 // eval.hip

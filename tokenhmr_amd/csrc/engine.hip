@@ -70,7 +70,7 @@ struct thmr_engine {
     size_t o_convp[7] = {0};      // repacked k=3 convs: 0,3,6,9,12, res0.conv1, res1.conv1, 14.1, 15 -> see conv_names
     size_t o_cbT = 0, o_cnorm = 0, o_idx = 0;   // idx tables as int32 within the float arena
     size_t o_smpl_vt = 0, o_smpl_sd = 0, o_smpl_pd = 0, o_smpl_jr = 0, o_smpl_w = 0, o_smpl_j19 = 0, o_smpl_int = 0,
-           o_smpl_jt = 0, o_smpl_jsd = 0;
+           o_smpl_jt = 0, o_smpl_jsd = 0, o_smpl_dirs = 0;
     std::vector<size_t> convp;    // repacked conv offsets, index by conv id
     // optional tokenizer ENCODER (EncodeTokens, vanilla_pose_vqvae.py:304-346): 'encoder.encoder.*' tensors
     std::vector<std::string> enc_names;
@@ -84,7 +84,7 @@ struct thmr_engine {
         size_t dx, dh, dv, dq, dca, dff, ro;
         size_t mt, cf, cf2, y1, tT, u, yt, y, s, z0, zh, nl, nl2;
         size_t feat, gat, act0, act1, act2, bpose, tokidx;
-        size_t A, pf, Jtr, rot, betas, cam, camt, verts, joints, pose6d;
+        size_t A, pf, Jtr, vposed, rot, betas, cam, camt, verts, joints, pose6d;
         size_t total;
     } so{};
     // profiler
@@ -277,6 +277,7 @@ void layout_weights(thmr_engine* e) {
     e->o_smpl_int = off; off = align64(off + 128);       // parents(24) | extra(21) | jmap(25) as int32
     e->o_smpl_jt = off;  off = align64(off + NJ * 3);
     e->o_smpl_jsd = off; off = align64(off + NJ * 30);
+    e->o_smpl_dirs = off; off = align64(off + (size_t)NV * 3 * THMR_LBS_KX);   // [shapedirs | posedirs | 0]^T, derived
     // optional tokenizer encoder (tokenizer.pth 'encoder.encoder.*'): raw tensors, repacked convs, resample tables
     for (int i = 0; i < kEncN; ++i) {
         const std::string n = kEnc[i].name;
@@ -315,7 +316,7 @@ void layout_scratch(thmr_engine* e) {
     s.gat = take(B * 125 * 3 * VQW);                 // largest gather: T=125, 3*512 (> 160*768)
     s.act0 = take(B * TN * VQW); s.act1 = take(B * TN * VQW); s.act2 = take(B * TN * VQW);
     s.bpose = take(B * 128); s.tokidx = take(B * TN);
-    s.A = take(B * NJ * 12); s.pf = take(B * NP + 1); s.Jtr = take(B * NJ * 3);
+    s.A = take(B * NJ * 12); s.pf = take(B * THMR_LBS_XF); s.Jtr = take(B * NJ * 3); s.vposed = take(B * NV * 3);
     s.rot = take(B * NJ * 9); s.betas = take(B * NB); s.cam = take(B * 3); s.camt = take(B * 3);
     s.verts = take(B * NV * 3); s.joints = take(B * 132); s.pose6d = take(B * 144);
     s.total = off;
@@ -614,9 +615,9 @@ int lbs(thmr_engine* e, const float* rot, const float* betas, const float* camt,
     const int32_t* ints = reinterpret_cast<const int32_t*>(e->warena + e->o_smpl_int);
     if (!verts) verts = e->S(so.verts);
     LAUNCH_OK(launch_lbs(rot, betas, camt, e->warena + e->o_smpl_jt, e->warena + e->o_smpl_jsd, ints,
-                         e->warena + e->o_smpl_vt, e->warena + e->o_smpl_sd, e->warena + e->o_smpl_pd,
-                         e->warena + e->o_smpl_w, e->warena + e->o_smpl_j19, ints + 24, ints + 48, e->S(so.A), e->S(so.pf),
-                         e->S(so.Jtr), verts, joints, kp2d, FOCAL / IMG, B, st));
+                         e->warena + e->o_smpl_vt, e->warena + e->o_smpl_dirs, e->warena + e->o_smpl_w,
+                         e->warena + e->o_smpl_j19, ints + 24, ints + 48, e->S(so.A), e->S(so.pf), e->S(so.Jtr),
+                         e->S(so.vposed), verts, joints, kp2d, FOCAL / IMG, B, st));
     return 0;
 }
 
@@ -785,6 +786,7 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
     LAUNCH_OK(launch_code_norm(e->W("quantizer.codebook"), e->warena + e->o_cnorm, NCLS, st));
     LAUNCH_OK(launch_lbs_jreg(e->warena + e->o_smpl_jr, e->warena + e->o_smpl_vt, e->warena + e->o_smpl_sd,
                               e->warena + e->o_smpl_jt, e->warena + e->o_smpl_jsd, st));
+    LAUNCH_OK(launch_lbs_build_dirs(e->warena + e->o_smpl_sd, e->warena + e->o_smpl_pd, e->warena + e->o_smpl_dirs, st));
     // optional encoder: ready only when every 'encoder.encoder.*' tensor arrived (all-or-nothing)
     size_t enc_loaded = 0;
     for (auto& n : e->enc_names) enc_loaded += e->slots[n].loaded ? 1 : 0;
@@ -1012,7 +1014,7 @@ int thmr_op_rot6d(const float* x, float* R, int32_t n, void* stream) {
 struct thmr_smpl {
     float* mem = nullptr;
     int max_batch = 0;
-    size_t o_vt, o_sd, o_pd, o_jr, o_w, o_j19, o_int, o_jt, o_jsd, o_A, o_pf, o_Jtr, o_rot, o_joints, total;
+    size_t o_vt, o_sd, o_pd, o_jr, o_w, o_j19, o_int, o_jt, o_jsd, o_dirs, o_A, o_pf, o_Jtr, o_vposed, o_rot, o_joints, total;
 };
 
 int thmr_smpl_create(const thmr_smpl_desc* d, int32_t max_batch, int32_t device, thmr_smpl** out) {
@@ -1029,9 +1031,10 @@ int thmr_smpl_create(const thmr_smpl_desc* d, int32_t max_batch, int32_t device,
     auto take = [&](size_t n) { size_t o = off; off = align64(off + n); return o; };
     m->o_vt = take((size_t)NV * 3); m->o_sd = take((size_t)NV * 30); m->o_pd = take((size_t)NP * NV * 3);
     m->o_jr = take((size_t)NJ * NV); m->o_w = take((size_t)NV * NJ); m->o_j19 = take((size_t)19 * NV);
-    m->o_int = take(128); m->o_jt = take(NJ * 3); m->o_jsd = take(NJ * 30);
+    m->o_int = take(128); m->o_jt = take(NJ * 3); m->o_jsd = take(NJ * 30); m->o_dirs = take((size_t)NV * 3 * THMR_LBS_KX);
     const size_t B = (size_t)max_batch;
-    m->o_A = take(B * NJ * 12); m->o_pf = take(B * NP + 1); m->o_Jtr = take(B * NJ * 3); m->o_rot = take(B * NJ * 9);
+    m->o_A = take(B * NJ * 12); m->o_pf = take(B * THMR_LBS_XF); m->o_Jtr = take(B * NJ * 3); m->o_rot = take(B * NJ * 9);
+    m->o_vposed = take(B * NV * 3);
     m->o_joints = take(B * 132);
     m->total = off;
     if (hipMalloc(&m->mem, off * sizeof(float)) != hipSuccess) { delete m; return fail(e, THMR_ERR_NOMEM, "hipMalloc(smpl) failed"); }
@@ -1045,6 +1048,7 @@ int thmr_smpl_create(const thmr_smpl_desc* d, int32_t max_batch, int32_t device,
               hipMemcpy(ints + 24, d->extra_verts, sizeof(int32_t) * 21, k) == hipSuccess &&
               hipMemcpy(ints + 48, d->joint_map, sizeof(int32_t) * 25, k) == hipSuccess;
     if (!ok || launch_lbs_jreg(m->mem + m->o_jr, m->mem + m->o_vt, m->mem + m->o_sd, m->mem + m->o_jt, m->mem + m->o_jsd, nullptr) != 0 ||
+        launch_lbs_build_dirs(m->mem + m->o_sd, m->mem + m->o_pd, m->mem + m->o_dirs, nullptr) != 0 ||
         hipDeviceSynchronize() != hipSuccess) {
         thmr_smpl_destroy(m);
         return fail(e, THMR_ERR_HIP, "SMPL constant upload failed");
@@ -1071,9 +1075,9 @@ int thmr_smpl_forward(thmr_smpl* m, const float* pose, int32_t pose2rot, const f
         rot = m->mem + m->o_rot;
     }
     const int32_t* ints = reinterpret_cast<const int32_t*>(m->mem + m->o_int);
-    LAUNCH_OK(launch_lbs(rot, betas, nullptr, m->mem + m->o_jt, m->mem + m->o_jsd, ints, m->mem + m->o_vt, m->mem + m->o_sd,
-                         m->mem + m->o_pd, m->mem + m->o_w, m->mem + m->o_j19, ints + 24, ints + 48, m->mem + m->o_A,
-                         m->mem + m->o_pf, m->mem + m->o_Jtr, verts, joints ? joints : m->mem + m->o_joints, nullptr,
+    LAUNCH_OK(launch_lbs(rot, betas, nullptr, m->mem + m->o_jt, m->mem + m->o_jsd, ints, m->mem + m->o_vt, m->mem + m->o_dirs,
+                         m->mem + m->o_w, m->mem + m->o_j19, ints + 24, ints + 48, m->mem + m->o_A, m->mem + m->o_pf,
+                         m->mem + m->o_Jtr, m->mem + m->o_vposed, verts, joints ? joints : m->mem + m->o_joints, nullptr,
                          FOCAL / IMG, B, st));
     return 0;
 }

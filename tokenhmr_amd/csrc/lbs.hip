@@ -9,17 +9,19 @@
 // HBM-bound stage (83 KB written per crop; 19.8 MB of constants).  Layout decisions:
 //   * J = J_regressor . v_shaped is linear in betas, so J_template (24x3) and J_shapedirs (24x3x10) are
 //     precomputed once in fp64 at load time: no per-crop reduction over 6890 vertices before the chain.
-//   * skin kernel: a block owns 32 vertices (a 207 x 96 slice of posedirs, staged ONCE in LDS) and loops over
-//     32 crops, so the 17 MB posedirs stream is read from HBM once per 32 crops instead of once per crop;
-//     pose features, betas and the 24 bone matrices of those crops sit in LDS too (broadcast reads).
-//   * every global access is coalesced: consecutive lanes = consecutive vertices (12 B each) on stores.
+//   * blend shapes + pose correctives are ONE matrix product: v_posed (B x 20670) = [betas | pose_feature] (B x 217, zero-
+//     padded to 224) . dirs^T + v_template, with dirs^T (20670 x 224, K-contiguous) built once at load from shapedirs and
+//     posedirs.  It runs on the MFMA GEMM (gemm_f32.hip) with the template as the bias epilogue, so the 18.5 MB dirs
+//     stream is read once per 64-row tile of crops at matrix-core speed (the first version did these 6890*621 FMAs per
+//     crop on the VALU out of LDS and took 107 us at B = 64).
+//   * skin kernel: one thread per (crop, vertex): 24 weights x 24 bone matrices (LDS broadcast) -> 3x4 transform.
+//   * every global access is coalesced: consecutive lanes = consecutive vertices (12 B each) on loads and stores.
 #include "common.h"
 
 namespace {
 
 constexpr int NV = 6890, NJ = 24, NB = 10, NP = 207;
-constexpr int VCH = 32;      // vertices per block
-constexpr int CG = 32;       // crops per block (4 per thread)
+constexpr int KX = 224;      // 10 betas + 207 pose features, zero-padded to a multiple of the GEMM's 32-deep K tile
 
 // ---- one-time: J_template[j][i], J_shapedirs[j][i][l] in fp64 -> fp32 ----
 __global__ __launch_bounds__(256) void lbs_jreg_kernel(const float* __restrict__ Jreg, const float* __restrict__ vt,
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void lbs_jreg_kernel(const float* __restrict__
 __global__ __launch_bounds__(128) void lbs_prep_kernel(const float* __restrict__ rotmat, const float* __restrict__ betas,
                                                        const float* __restrict__ Jt, const float* __restrict__ Jsd,
                                                        const int32_t* __restrict__ parents, float* __restrict__ A,
-                                                       float* __restrict__ pf, float* __restrict__ Jtr) {
+                                                       float* __restrict__ xf, float* __restrict__ Jtr) {
     __shared__ float J[NJ][3];
     __shared__ float G[NJ][12];
     __shared__ float R[NJ][9];
@@ -64,10 +66,15 @@ __global__ __launch_bounds__(128) void lbs_prep_kernel(const float* __restrict__
         for (int l = 0; l < NB; ++l) v = fmaf(bs[l], Jsd[t * NB + l], v);
         J[t / 3][t % 3] = Jt[t] + v;
     }
-    // pose_feature = (R[1:] - I).view(207)   (smplx lbs.py: pose_feature)
-    for (int i = t; i < NP; i += 128) {
-        const int j = 1 + i / 9, e = i % 9;
-        pf[(int64_t)b * NP + i] = R[j][e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+    // blend-shape GEMM operand row: [betas (10) | pose_feature = (R[1:] - I).view(207) (smplx lbs.py) | 0 x 7]
+    for (int i = t; i < KX; i += 128) {
+        float v = 0.f;
+        if (i < NB) v = bs[i];
+        else if (i < NB + NP) {
+            const int q = i - NB, j = 1 + q / 9, e = q % 9;
+            v = R[j][e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+        }
+        xf[(int64_t)b * KX + i] = v;
     }
     __syncthreads();
     // kinematic chain (smplx batch_rigid_transform): G_0 = T_0, G_i = G_parent(i) . T_i,  T_i = [R_i | J_i - J_parent]
@@ -98,122 +105,77 @@ __global__ __launch_bounds__(128) void lbs_prep_kernel(const float* __restrict__
     if (t < NJ * 3) Jtr[(int64_t)b * NJ * 3 + t] = G[t / 3][(t % 3) * 4 + 3];
 }
 
-// ---- skinning: blend shapes + pose correctives + weighted bone transform, 32 vertices x 32 crops per block ----
-__global__ __launch_bounds__(256, 1) void lbs_skin_kernel(const float* __restrict__ vt, const float* __restrict__ sd,
-                                                          const float* __restrict__ pd, const float* __restrict__ W,
-                                                          const float* __restrict__ A, const float* __restrict__ pf,
-                                                          const float* __restrict__ betas, float* __restrict__ verts, int B) {
-    __shared__ __attribute__((aligned(16))) float pdS[NP * VCH * 3];      // 79,488 B
-    __shared__ __attribute__((aligned(16))) float pfS[CG * NP];            // 26,496 B
-    __shared__ __attribute__((aligned(16))) float AS[CG * NJ * 12];        // 36,864 B
-    __shared__ float bS[CG * NB];
-    const int tid = threadIdx.x;
-    const int v0 = blockIdx.x * VCH, c0 = blockIdx.y * CG;
-    const int nc = min(CG, B - c0);
-    const int ncols = min(VCH, NV - v0) * 3;
+// ---- one-time: dirs^T[n][k], n = 3*vertex + coordinate: k < 10 shapedirs, 10 <= k < 217 posedirs, rest 0 ----
+__global__ __launch_bounds__(256) void lbs_build_dirs_kernel(const float* __restrict__ sd, const float* __restrict__ pd,
+                                                             float* __restrict__ dirsT) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)NV * 3 * KX) return;
+    const int n = (int)(idx / KX), k = (int)(idx % KX);
+    float v = 0.f;
+    if (k < NB) v = sd[(int64_t)n * NB + k];                         // shapedirs (6890,3,10) == [n][10]
+    else if (k < NB + NP) v = pd[(int64_t)(k - NB) * (NV * 3) + n];   // posedirs (207, 20670)
+    dirsT[idx] = v;
+}
 
-    for (int i = tid; i < NP * VCH * 3; i += 256) {
-        const int k = i / (VCH * 3), col = i % (VCH * 3);
-        pdS[i] = (col < ncols) ? pd[(int64_t)k * (NV * 3) + v0 * 3 + col] : 0.f;
-    }
-    for (int i = tid; i < CG * NP; i += 256) pfS[i] = (i < nc * NP) ? pf[(int64_t)c0 * NP + i] : 0.f;
-    for (int i = tid; i < CG * NJ * 12; i += 256) AS[i] = (i < nc * NJ * 12) ? A[(int64_t)c0 * NJ * 12 + i] : 0.f;
-    for (int i = tid; i < CG * NB; i += 256) bS[i] = (i < nc * NB) ? betas[(int64_t)c0 * NB + i] : 0.f;
+// ---- skinning: T = sum_j W[v][j] * A[b][j] (3x4), out = T . [v_posed; 1] — one thread per (crop, vertex).
+//      The block also reduces its 256 vertices against the 19 rows of the extra joint regressor (smpl_wrapper.py:38-39)
+//      while the skinned coordinates are still in registers: jpart[b][block][19*3], combined in a fixed order by the joints
+//      kernel (the regressor would otherwise re-read every vertex of every crop with one block per crop). ----
+constexpr int SKB = (NV + 255) / 256;     // skin blocks per crop = 27
+__global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__ vposed, const float* __restrict__ W,
+                                                       const float* __restrict__ A, const float* __restrict__ J19,
+                                                       float* __restrict__ verts, float* __restrict__ jpart) {
+    __shared__ f32x4 AS[NJ * 3];
+    __shared__ float red[4][57];
+    const int b = blockIdx.y, tid = threadIdx.x, v = blockIdx.x * 256 + tid, lane = tid & 63, wave = tid >> 6;
+    if (tid < NJ * 3) AS[tid] = reinterpret_cast<const f32x4*>(A + (int64_t)b * NJ * 12)[tid];
     __syncthreads();
-
-    const int vl = tid & 31, slot = tid >> 5;      // crops slot, slot+8, slot+16, slot+24
-    const int v = v0 + vl;
     const bool vok = v < NV;
     const int vv = vok ? v : NV - 1;
-
-    // pose correctives: off[c][i] = sum_k pf[c][k] * posedirs[k][3v+i]
-    float off[4][3];
+    const float* p = vposed + ((int64_t)b * NV + vv) * 3;
+    const float x = p[0], y = p[1], z = p[2];
+    f32x4 wv[NJ / 4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) off[c][0] = off[c][1] = off[c][2] = 0.f;
-    const float* pcol = pdS + vl * 3;
-    for (int k = 0; k < NP; ++k) {
-        const float p0 = pcol[k * VCH * 3 + 0], p1 = pcol[k * VCH * 3 + 1], p2 = pcol[k * VCH * 3 + 2];
+    for (int q = 0; q < NJ / 4; ++q) wv[q] = reinterpret_cast<const f32x4*>(W + (int64_t)vv * NJ)[q];
+    f32x4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float f = pfS[(slot + 8 * c) * NP + k];
-            off[c][0] = fmaf(f, p0, off[c][0]);
-            off[c][1] = fmaf(f, p1, off[c][1]);
-            off[c][2] = fmaf(f, p2, off[c][2]);
-        }
+    for (int j = 0; j < NJ; ++j) {
+        const float w = wv[j >> 2][j & 3];
+        T0 += w * AS[j * 3 + 0];
+        T1 += w * AS[j * 3 + 1];
+        T2 += w * AS[j * 3 + 2];
     }
-    // shape blend: v_shaped = v_template + shapedirs . betas
-    float sdv[30];
-#pragma unroll
-    for (int i = 0; i < 30; ++i) sdv[i] = sd[(int64_t)vv * 30 + i];
-    const float t0 = vt[vv * 3 + 0], t1 = vt[vv * 3 + 1], t2 = vt[vv * 3 + 2];
-    float wv[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) wv[j] = W[(int64_t)vv * NJ + j];
-
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int cl = slot + 8 * c;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int l = 0; l < NB; ++l) {
-            const float bt = bS[cl * NB + l];
-            s0 = fmaf(bt, sdv[0 * NB + l], s0);
-            s1 = fmaf(bt, sdv[1 * NB + l], s1);
-            s2 = fmaf(bt, sdv[2 * NB + l], s2);
-        }
-        const float x = (t0 + s0) + off[c][0], y = (t1 + s1) + off[c][1], z = (t2 + s2) + off[c][2];
-        // T = sum_j W[v][j] * A[c][j]  (3x4)
-        f32x4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0;
-        const f32x4* Ac = reinterpret_cast<const f32x4*>(AS + cl * NJ * 12);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const float w = wv[j];
-            T0 += w * Ac[j * 3 + 0];
-            T1 += w * Ac[j * 3 + 1];
-            T2 += w * Ac[j * 3 + 2];
-        }
-        const float ox = T0[0] * x + T0[1] * y + T0[2] * z + T0[3];
-        const float oy = T1[0] * x + T1[1] * y + T1[2] * z + T1[3];
-        const float oz = T2[0] * x + T2[1] * y + T2[2] * z + T2[3];
-        if (vok && cl < nc) {
-            float* o = verts + ((int64_t)(c0 + cl) * NV + v) * 3;
-            o[0] = ox; o[1] = oy; o[2] = oz;
-        }
+    const float ox = T0[0] * x + T0[1] * y + T0[2] * z + T0[3];
+    const float oy = T1[0] * x + T1[1] * y + T1[2] * z + T1[3];
+    const float oz = T2[0] * x + T2[1] * y + T2[2] * z + T2[3];
+    if (vok) {
+        float* o = verts + ((int64_t)b * NV + v) * 3;
+        o[0] = ox; o[1] = oy; o[2] = oz;
     }
+#pragma unroll
+    for (int j = 0; j < 19; ++j) {
+        const float w = vok ? J19[(int64_t)j * NV + v] : 0.f;
+        const float s0 = wave_sum(w * ox), s1 = wave_sum(w * oy), s2 = wave_sum(w * oz);
+        if (lane == 0) { red[wave][j * 3 + 0] = s0; red[wave][j * 3 + 1] = s1; red[wave][j * 3 + 2] = s2; }
+    }
+    __syncthreads();
+    if (tid < 57) jpart[((int64_t)b * SKB + blockIdx.x) * 57 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
 // ---- joints: 24 chain joints + 21 vertex picks -> joint_map(25) ++ J19 regressor(19) = 44, + projection ----
 __global__ __launch_bounds__(256) void lbs_joints_kernel(const float* __restrict__ verts, const float* __restrict__ Jtr,
-                                                         const float* __restrict__ J19, const int32_t* __restrict__ extra,
+                                                         const float* __restrict__ jpart, const int32_t* __restrict__ extra,
                                                          const int32_t* __restrict__ jmap, const float* __restrict__ cam_t,
                                                          float* __restrict__ joints, float* __restrict__ kp2d,
                                                          float focal_over_size) {
-    __shared__ float part[4][57];
     __shared__ float jo[44][3];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const float* vb = verts + (int64_t)b * NV * 3;
-    float acc[19][3];
-#pragma unroll
-    for (int j = 0; j < 19; ++j) acc[j][0] = acc[j][1] = acc[j][2] = 0.f;
-    for (int v = tid; v < NV; v += 256) {
-        const float x = vb[v * 3 + 0], y = vb[v * 3 + 1], z = vb[v * 3 + 2];
-#pragma unroll
-        for (int j = 0; j < 19; ++j) {
-            const float w = J19[(int64_t)j * NV + v];
-            acc[j][0] = fmaf(w, x, acc[j][0]);
-            acc[j][1] = fmaf(w, y, acc[j][1]);
-            acc[j][2] = fmaf(w, z, acc[j][2]);
-        }
+    if (tid < 57) {          // J19 regressor: the skin blocks' partial sums, block 0 .. 26 in order
+        float s = 0.f;
+        for (int k = 0; k < SKB; ++k) s += jpart[((int64_t)b * SKB + k) * 57 + tid];
+        jo[25 + tid / 3][tid % 3] = s;
     }
-#pragma unroll
-    for (int j = 0; j < 19; ++j)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float s = wave_sum(acc[j][i]);
-            if (lane == 0) part[wave][j * 3 + i] = s;
-        }
-    __syncthreads();
-    if (tid < 57) jo[25 + tid / 3][tid % 3] = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
     if (tid >= 64 && tid < 64 + 75) {
         const int t = tid - 64, j = t / 3, i = t % 3;
         const int src = jmap[j];
@@ -260,14 +222,26 @@ int launch_lbs_jreg(const float* Jreg, const float* vt, const float* sd, float* 
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+int launch_lbs_build_dirs(const float* sd, const float* pd, float* dirsT, hipStream_t s) {
+    const int64_t total = (int64_t)NV * 3 * KX;
+    hipLaunchKernelGGL(lbs_build_dirs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sd, pd, dirsT);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// scratch: A (B,24,12), xf (B, 224 + 27*57) [operand rows, then J19 partial sums], Jtr (B,24,3), vposed (B,20670)
 int launch_lbs(const float* rotmat, const float* betas, const float* cam_t, const float* Jt, const float* Jsd,
-               const int32_t* parents, const float* vt, const float* sd, const float* pd, const float* W,
-               const float* J19, const int32_t* extra, const int32_t* jmap, float* A, float* pf, float* Jtr, float* verts,
+               const int32_t* parents, const float* vt, const float* dirsT, const float* W, const float* J19,
+               const int32_t* extra, const int32_t* jmap, float* A, float* xf, float* Jtr, float* vposed, float* verts,
                float* joints, float* kp2d, float focal_over_size, int B, hipStream_t s) {
-    hipLaunchKernelGGL(lbs_prep_kernel, dim3(B), dim3(128), 0, s, rotmat, betas, Jt, Jsd, parents, A, pf, Jtr);
-    hipLaunchKernelGGL(lbs_skin_kernel, dim3((NV + VCH - 1) / VCH, (B + CG - 1) / CG), dim3(256), 0, s, vt, sd, pd, W, A, pf,
-                       betas, verts, B);
-    hipLaunchKernelGGL(lbs_joints_kernel, dim3(B), dim3(256), 0, s, verts, Jtr, J19, extra, jmap, cam_t, joints, kp2d,
+    hipLaunchKernelGGL(lbs_prep_kernel, dim3(B), dim3(128), 0, s, rotmat, betas, Jt, Jsd, parents, A, xf, Jtr);
+    GemmArgs g{};
+    g.A = xf; g.lda = KX; g.W = dirsT; g.ldw = KX; g.bias = vt; g.resid = nullptr; g.ldr = 0;
+    g.C = vposed; g.ldc = NV * 3; g.M = B; g.N = NV * 3; g.K = KX; g.qscale = 1.f; g.qcols = 0;
+    if (int r = launch_gemm(g, EPI_BIAS, -1, s)) return r;
+    // the J19 partial sums live behind the (B,224) operand rows in the xf scratch: B * 27 * 57 floats
+    float* jpart = xf + (size_t)B * KX;
+    hipLaunchKernelGGL(lbs_skin_kernel, dim3(SKB, B), dim3(256), 0, s, vposed, W, A, J19, verts, jpart);
+    hipLaunchKernelGGL(lbs_joints_kernel, dim3(B), dim3(256), 0, s, verts, Jtr, jpart, extra, jmap, cam_t, joints, kp2d,
                        focal_over_size);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
