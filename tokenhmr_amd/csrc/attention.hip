@@ -70,16 +70,33 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
 #pragma unroll
         for (int kt = 0; kt < 12; ++kt) s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // QT = 1 (few crops, mostly one workgroup per CU): software-pipelined — the K fragment of step i+1 is read BEFORE the
+    // MFMAs of step i are issued (pinned with sched_barrier; hipcc's own schedule is read -> s_waitcnt lgkmcnt(0) -> MFMAs,
+    // which exposes the LDS latency every step): +10 %.  QT = 3: the co-resident workgroup already covers that latency and
+    // the extra live registers cost more than they save (profiles/r1_attention_experiments.log), so the plain loop is kept.
+    constexpr bool PIPE = QT == 1;
+    {
+        f32x4 ka = *reinterpret_cast<const f32x4*>(&smem[l15 * KS + g * 4]);
 #pragma unroll
-    for (int kt = 0; kt < 12; ++kt) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const f32x4 ka = *reinterpret_cast<const f32x4*>(&smem[(kt * 16 + l15) * KS + j * 16 + g * 4]);
+        for (int i = 0; i < 60; ++i) {
+            const int kt = i / 5, j = i % 5;
+            f32x4 kn = ka;
+            if constexpr (PIPE) {
+                if (i + 1 < 60)
+                    kn = *reinterpret_cast<const f32x4*>(&smem[(((i + 1) / 5) * 16 + l15) * KS + ((i + 1) % 5) * 16 + g * 4]);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                ka = *reinterpret_cast<const f32x4*>(&smem[(kt * 16 + l15) * KS + j * 16 + g * 4]);
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
                     s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[t], qf[qt][j][t], s[qt][kt], 0, 0, 0);
+            if constexpr (PIPE) {
+                __builtin_amdgcn_sched_barrier(0);
+                ka = kn;
+            }
         }
     }
 
@@ -136,17 +153,32 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
 #pragma unroll
         for (int dt = 0; dt < 5; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // (QT = 1: software-pipelined like the S phase — the five V values of key step i+1 are read before the MFMAs of step i)
+    {
+        float vc[5], vn[5];
 #pragma unroll
-    for (int kt = 0; kt < 12; ++kt) {
+        for (int dt = 0; dt < 5; ++dt) vc[dt] = smem[(g * 4) * VS + l15 + dt * 16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float* vrow = &smem[(kt * 16 + g * 4 + r) * VS + l15];
+        for (int i = 0; i < 48; ++i) {
+            const int kt = i / 4, r = i % 4;
+            if constexpr (PIPE) {
 #pragma unroll
-            for (int dt = 0; dt < 5; ++dt) {
-                const float vb = vrow[dt * 16];
+                for (int dt = 0; dt < 5; ++dt)
+                    vn[dt] = (i + 1 < 48) ? smem[(((i + 1) / 4) * 16 + g * 4 + (i + 1) % 4) * VS + l15 + dt * 16] : 0.f;
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt) vc[dt] = smem[(kt * 16 + g * 4 + r) * VS + l15 + dt * 16];
+            }
+#pragma unroll
+            for (int dt = 0; dt < 5; ++dt)
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
-                    o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb, s[qt][kt][r], o[qt][dt], 0, 0, 0);
+                    o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc[dt], s[qt][kt][r], o[qt][dt], 0, 0, 0);
+            if constexpr (PIPE) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt) vc[dt] = vn[dt];
             }
         }
     }
