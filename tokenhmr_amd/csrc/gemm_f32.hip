@@ -567,6 +567,10 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         };
         const double c7 = cost(128, 128, 0.97), c8 = cost(128, 160, 1.0), c9 = cost(64, 64, 0.80);
         variant = (c8 <= c7 && c8 <= c9) ? 8 : (c7 <= c9 ? 7 : 9);
+        // at most one 64x64 block per CU: nothing hides the 2-buffer kernel's per-K-tile memory round trip, so the 4-deep
+        // ring version of the same tile is used (same K order, bit-identical; measured 46 -> ~30 us on the head's B = 1 convs)
+        const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+        if (variant == 9 && tiles64 <= 256 && epi != EPI_BIAS_POS) return launch_ring<4>(a, epi, 1, nullptr, s);
     }
 #ifdef THMR_GEMM_ABLATION
     switch (variant) {     // 30 + ABL: timing-only ablations of the 128x160 DMA kernel (EPI_NONE)

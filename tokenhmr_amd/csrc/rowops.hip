@@ -287,7 +287,9 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs a, const 
 
 // fused for the ViT residual stream (vit.py:149-150 followed by the next norm, :149/:150/:335):
 //   x_new = resid + (sum_s part[s] + bias);  y = LayerNorm(x_new)        one wave per row, D = NV*256
-template <int NV>
+// ST > 0: the split factor is a compile-time constant, so all ST*NV partial loads of a lane are issued before the first add
+// (the engine's factor 4: 8.8 -> ~5 us at 192 rows, where the kernel is one dependent-load chain per wave); ST = 0: runtime S.
+template <int NV, int ST>
 __global__ __launch_bounds__(256) void splitk_resid_ln_kernel(const float* __restrict__ part, int S, int64_t mn,
                                                               const float* __restrict__ bias, const float* resid, float* xout,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -303,7 +305,15 @@ __global__ __launch_bounds__(256) void splitk_resid_ln_kernel(const float* __res
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         f32x4 t = *reinterpret_cast<const f32x4*>(part + ro + c);
-        for (int s = 1; s < S; ++s) t += *reinterpret_cast<const f32x4*>(part + s * mn + ro + c);
+        if constexpr (ST > 0) {
+            f32x4 ps[ST > 1 ? ST - 1 : 1];
+#pragma unroll
+            for (int s = 1; s < ST; ++s) ps[s - 1] = *reinterpret_cast<const f32x4*>(part + s * mn + ro + c);
+#pragma unroll
+            for (int s = 1; s < ST; ++s) t += ps[s - 1];
+        } else {
+            for (int s = 1; s < S; ++s) t += *reinterpret_cast<const f32x4*>(part + s * mn + ro + c);
+        }
         const f32x4 b = *reinterpret_cast<const f32x4*>(bias + c);
         const f32x4 r = *reinterpret_cast<const f32x4*>(resid + ro + c);
 #pragma unroll
@@ -371,8 +381,12 @@ int launch_splitk_epilogue(const GemmArgs& a, int epi, const float* part, int S,
 int launch_splitk_resid_ln(const float* part, int S, int rows, int D, const float* bias, const float* resid, float* xout,
                            const float* gamma, const float* beta, float* y, float eps, hipStream_t s) {
     if (rows <= 0 || S < 1 || D != 1280) return -1;
-    hipLaunchKernelGGL(splitk_resid_ln_kernel<5>, dim3((rows + 3) / 4), dim3(256), 0, s, part, S, (int64_t)rows * D, bias, resid,
-                       xout, gamma, beta, y, rows, eps);
+    if (S == 4)
+        hipLaunchKernelGGL((splitk_resid_ln_kernel<5, 4>), dim3((rows + 3) / 4), dim3(256), 0, s, part, S, (int64_t)rows * D, bias,
+                           resid, xout, gamma, beta, y, rows, eps);
+    else
+        hipLaunchKernelGGL((splitk_resid_ln_kernel<5, 0>), dim3((rows + 3) / 4), dim3(256), 0, s, part, S, (int64_t)rows * D, bias,
+                           resid, xout, gamma, beta, y, rows, eps);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
