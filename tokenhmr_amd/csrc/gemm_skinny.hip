@@ -31,16 +31,33 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int k = 0; k < kper; k += 16) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(wp + k);
-        f32x4 x[4];
+    // The stream is read once and nothing else hides its latency, so the loads run THREE K steps (of 16) ahead of the MFMAs
+    // that consume them: a 4-slot register ring (the first version loaded and multiplied step by step: one exposed memory
+    // round trip per 16 k).
+    constexpr int PF = 3;
+    f32x4 wq[PF + 1], xq[PF + 1][4];
+    auto fetch = [&](int k, int slot) {
+        wq[slot] = *reinterpret_cast<const f32x4*>(wp + k);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) x[mt] = *reinterpret_cast<const f32x4*>(ap[mt] + k);
+        for (int mt = 0; mt < 4; ++mt) xq[slot][mt] = *reinterpret_cast<const f32x4*>(ap[mt] + k);
+    };
+    const int nstep = kper >> 4;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+    for (int i = 0; i < PF; ++i)
+        if (i < nstep) fetch(i * 16, i);
+    for (int i0 = 0; i0 < nstep; i0 += PF + 1) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt][t], w[t], acc[mt], 0, 0, 0);
+        for (int u = 0; u < PF + 1; ++u) {          // ring slots are compile-time constants (registers, not scratch)
+            const int i = i0 + u;
+            if (i < nstep) {
+                if (i + PF < nstep) fetch((i + PF) * 16, (u + PF) % (PF + 1));
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[u][mt][t], wq[u][t], acc[mt], 0, 0, 0);
+            }
+        }
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4*>(&red[wave][mt][lane][0]) = acc[mt];
