@@ -102,7 +102,9 @@ def _to_cpu(o):
     return {k: ({kk: vv.cpu() for kk, vv in v.items()} if isinstance(v, dict) else v.cpu()) for k, v in o.items()}
 
 
-def _check_golden(model, cfg, sd, tok, name):
+def _check_golden(model, cfg, sd, tok, name, pad_to=None):
+    """Golden parity of the fixture's crops; with pad_to they are the first crops of a larger batch (rest: duplicates of
+    them, then random crops) and the full output dict of that batch is returned for further property checks."""
     from tokenhmr_amd import weights as W
     g = np.load(os.path.join(GOLDEN_DIR, name))
     vd, dd, B, seed = [int(v) for v in g["meta"]]
@@ -111,7 +113,13 @@ def _check_golden(model, cfg, sd, tok, name):
         "synthetic weight generator drifted from the one that produced the golden file"
     img = _inputs(B, seed)
     assert abs(float(img.double().sum()) - g["img_checksum"][0]) < 1e-6
-    out = _to_cpu(model({"img": img.to(model.engine.device)}))
+    full = None
+    if pad_to:
+        batch = torch.cat([img, img, _inputs(pad_to - 2 * B, seed + 77)], 0)
+        full = model({"img": batch.to(model.engine.device)})
+        out = {k: ({kk: vv[:B].cpu() for kk, vv in v.items()} if isinstance(v, dict) else v[:B].cpu()) for k, v in full.items()}
+    else:
+        out = _to_cpu(model({"img": img.to(model.engine.device)}))
     T = lambda k: torch.from_numpy(g[k])  # noqa: E731
 
     def md(a, b):
@@ -133,6 +141,7 @@ def _check_golden(model, cfg, sd, tok, name):
     assert idx_eq[safe].all() and rep["idx_mismatch_frac"] < 0.02, rep
     assert rep["pose6d"] < 1e-4 and rep["rot"] < 1e-4 and rep["betas"] < 1e-4 and rep["cam"] < 1e-4, rep
     assert rep["verts"] < 1e-4 and rep["joints"] < 1e-4 and rep["kp2d"] < 1e-3, rep
+    return full, (batch if pad_to else img)
 
 
 def test_small_vs_golden(small):
@@ -141,13 +150,27 @@ def test_small_vs_golden(small):
 
 
 def test_full_depth_vs_golden(built_lib, cuda_dev):
-    """ViT-H depth 32 + 6-layer decoder: the release architecture, B=2, vs tensors the reference's own modules produced."""
+    """ViT-H depth 32 + 6-layer decoder: the release architecture, vs tensors the reference's own modules produced — once as
+    the fixture's own B=2 batch (small-batch regime) and once at BASELINE.json's full size, B=64 (large-batch regime), where
+    the fixture crops are rows 0-1 of the batch.  Size-independent properties at B=64: duplicated crops (rows 2-3) give
+    bit-identical rows, a crop's result does not depend on the batch it rides in (the first 8 crops as their own batch),
+    and two runs agree bit for bit."""
     from tokenhmr_amd.config import RELEASE
     from tokenhmr_amd.model import TokenHMR
     sd, tok, smpl = _assets(RELEASE)
-    model = TokenHMR.from_state(RELEASE, sd, tok, smpl, max_batch=2, device=cuda_dev)
+    model = TokenHMR.from_state(RELEASE, sd, tok, smpl, max_batch=64, device=cuda_dev)
     model.return_taps = True
     _check_golden(model, RELEASE, sd, tok, "full_d32.npz")
+    full, batch = _check_golden(model, RELEASE, sd, tok, "full_d32.npz", pad_to=64)
+    keys = ("pred_vertices", "pred_keypoints_3d", "pred_keypoints_2d", "pred_cam", "cls_logits_softmax", "token_idx")
+    for k in keys:
+        assert torch.equal(full[k][2:4], full[k][0:2]), k                    # duplicated crops
+    again = model({"img": batch.to(cuda_dev)})
+    eight = model({"img": batch[:8].to(cuda_dev)})
+    for k in keys:
+        assert torch.equal(again[k], full[k]), k                              # deterministic
+        assert torch.equal(eight[k], full[k][:8]), k                          # batch-size invariant within the regime
+    assert torch.isfinite(full["pred_vertices"]).all() and full["pred_vertices"].shape == (64, 6890, 3)
     del model
     torch.cuda.empty_cache()
 
