@@ -171,6 +171,9 @@ int thmr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* b
 int thmr_op_vit_attention(const float* qkv_dev, float* out_dev /*(B,192,1280)*/, int32_t B, void* stream);
 /* rot6d_to_rotmat (geometry.py:64-84): (n,6) -> (n,3,3) */
 int thmr_op_rot6d(const float* x_dev, float* R_dev, int32_t n, void* stream);
+/* aa_to_rotmat (geometry.py:5-44; axis-angle -> quaternion -> rotation matrix, the reference's in-tree "Rodrigues" used for
+ * ground-truth poses at tokenhmr.py:235,260,357): (n,3) -> (n,3,3) */
+int thmr_op_aa_to_rotmat(const float* aa_dev, float* R_dev, int32_t n, void* stream);
 
 /* Stand-alone SMPL model: the GT-side meshes the reference computes per sample on the CPU with
  * smplx.SMPL(gender) inside dataset workers (tokenhmr/lib/datasets/image_dataset.py:151-164,254-270, emdb_dataset.py:184-199)

@@ -232,6 +232,23 @@ def rot6d_to_rotmat(x):
     return torch.stack((b1, b2, b3), dim=-2)
 
 
+def aa_to_rotmat(theta):
+    """tokenhmr/lib/utils/geometry.py:5-44: axis-angle -> quaternion (angle = ||theta + 1e-8||, axis = theta / angle) ->
+    quat_to_rotmat (re-normalised quaternion, the 9 quadratic forms)."""
+    norm = torch.norm(theta + 1e-8, p=2, dim=1)
+    angle = norm.unsqueeze(-1)
+    normalized = theta / angle
+    angle = angle * 0.5
+    quat = torch.cat([torch.cos(angle), torch.sin(angle) * normalized], dim=1)
+    q = quat / quat.norm(p=2, dim=1, keepdim=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    w2, x2, y2, z2 = w.pow(2), x.pow(2), y.pow(2), z.pow(2)
+    wx, wy, wz, xy, xz, yz = w * x, w * y, w * z, x * y, x * z, y * z
+    return torch.stack([w2 + x2 - y2 - z2, 2 * xy - 2 * wz, 2 * wy + 2 * xz,
+                        2 * wz + 2 * xy, w2 - x2 + y2 - z2, 2 * yz - 2 * wx,
+                        2 * xz - 2 * wy, 2 * wx + 2 * yz, w2 - x2 - y2 + z2], dim=1).view(-1, 3, 3)
+
+
 def perspective_projection(points, translation, focal):
     """geometry.py:86-124 with rotation=I, camera_center=0: ((p+t)/z) * f."""
     p = points + translation.unsqueeze(1)

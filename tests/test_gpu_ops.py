@@ -214,3 +214,20 @@ def test_rot6d(built_lib, cuda_dev):
     eye = torch.eye(3).expand_as(out)
     assert torch.allclose(out @ out.transpose(1, 2), eye, atol=1e-5)      # orthonormal (size-independent property)
     assert torch.allclose(torch.linalg.det(out), torch.ones(out.shape[0]), atol=1e-5)
+
+
+def test_aa_to_rotmat_vs_reference_golden(built_lib, cuda_dev):
+    """thmr_op_aa_to_rotmat vs the reference's own aa_to_rotmat (golden fixture) and vs fp64: tolerance 2e-6 (sin/cos/sqrt
+    of ocml vs ATen), zero and tiny rotations included."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN_DIR
+    from oracle import tokenhmr_oracle as O
+    from tokenhmr_amd import ops
+    g = np.load(os.path.join(GOLDEN_DIR, "geometry_small.npz"))
+    th = torch.from_numpy(g["theta"])
+    R = ops.aa_to_rotmat(th.to(cuda_dev)).cpu()
+    assert (R - torch.from_numpy(g["rotmat"])).abs().max() < 2e-6
+    big = 3.0 * _rand(4096, 3, seed=5)
+    R2 = ops.aa_to_rotmat(big.to(cuda_dev)).cpu()
+    assert (R2.double() - O.aa_to_rotmat(big.double())).abs().max() < 2e-6

@@ -130,3 +130,14 @@ def test_token_indices_tie_break_lowest():
     logits[0, 0, [3, 5]] = 1.0
     logits[0, 1, 7] = 2.0
     assert O.token_indices(logits).tolist() == [[3, 7]]
+
+
+def test_aa_to_rotmat_oracle_vs_reference_golden():
+    """geometry.py:5-44 restated in the oracle == tensors the reference's own function produced (oracle/gen_golden_geometry.py),
+    including a zero rotation (the 1e-8 epsilon path) and tiny angles; and the matrices are rotations."""
+    import numpy as np
+    from oracle import tokenhmr_oracle as O
+    g = np.load(os.path.join(GOLDEN_DIR, "geometry_small.npz"))
+    R = O.aa_to_rotmat(torch.from_numpy(g["theta"]))
+    assert torch.equal(R, torch.from_numpy(g["rotmat"]))
+    assert (R @ R.transpose(1, 2) - torch.eye(3)).abs().max() < 1e-5 and (torch.linalg.det(R) - 1).abs().max() < 1e-5

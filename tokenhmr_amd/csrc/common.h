@@ -162,6 +162,7 @@ int launch_assemble(const float* ro, int ldro, const float* bpose, const float* 
                     const float* init_cam, float* pose6d, float* rotmat, float* betas, float* cam, float* cam_t,
                     float* focal, float focal_length, float img_size, int B, hipStream_t s);
 int launch_rot6d(const float* x, float* R, int n, hipStream_t s);
+int launch_aa_to_rotmat(const float* aa, float* R, int n, hipStream_t s);
 int launch_cam_t(const float* cam, float* cam_t, float focal_length, float img_size, int B, hipStream_t s);
 int launch_vq_argmin_rows(const float* x, const float* dot, const float* cnorm, int32_t* idx, float* dist, int rows,
                           hipStream_t s);

@@ -1010,6 +1010,13 @@ int thmr_op_rot6d(const float* x, float* R, int32_t n, void* stream) {
     return 0;
 }
 
+int thmr_op_aa_to_rotmat(const float* aa, float* R, int32_t n, void* stream) {
+    thmr_engine* e = nullptr;
+    if (!aa || !R || n < 1) return fail(e, THMR_ERR_INVALID, "bad argument");
+    LAUNCH_OK(launch_aa_to_rotmat(aa, R, n, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 // ---- stand-alone SMPL model ----
 struct thmr_smpl {
     float* mem = nullptr;

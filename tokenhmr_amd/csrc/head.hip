@@ -141,6 +141,28 @@ __global__ void rot6d_kernel(const float* __restrict__ x, float* __restrict__ Rm
     R[6] = b1y * b2z - b1z * b2y; R[7] = b1z * b2x - b1x * b2z; R[8] = b1x * b2y - b1y * b2x;
 }
 
+// aa_to_rotmat (tokenhmr/lib/utils/geometry.py:5-44): axis-angle -> quaternion -> rotation matrix, operation by operation
+// (angle = ||theta + 1e-8||, axis = theta / angle, half-angle quaternion, re-normalised, nine quadratic forms)
+__global__ void aa_to_rotmat_kernel(const float* __restrict__ aa, float* __restrict__ Rm, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float tx = aa[i * 3 + 0], ty = aa[i * 3 + 1], tz = aa[i * 3 + 2];
+    const float ex = tx + 1e-8f, ey = ty + 1e-8f, ez = tz + 1e-8f;
+    const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float nx = tx / angle, ny = ty / angle, nz = tz / angle;
+    const float half = angle * 0.5f;
+    const float qw = cosf(half), sn = sinf(half);
+    const float qx = sn * nx, qy = sn * ny, qz = sn * nz;
+    const float qn = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+    const float w = qw / qn, x = qx / qn, y = qy / qn, z = qz / qn;
+    const float w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z;
+    const float wx = w * x, wy = w * y, wz = w * z, xy = x * y, xz = x * z, yz = y * z;
+    float* R = Rm + (int64_t)i * 9;
+    R[0] = w2 + x2 - y2 - z2; R[1] = 2 * xy - 2 * wz;    R[2] = 2 * wy + 2 * xz;
+    R[3] = 2 * wz + 2 * xy;    R[4] = w2 - x2 + y2 - z2; R[5] = 2 * yz - 2 * wx;
+    R[6] = 2 * xz - 2 * wy;    R[7] = 2 * wx + 2 * yz;    R[8] = w2 - x2 - y2 + z2;
+}
+
 // QuantizeEMAReset.quantize (tokenization/models/quantize_cnn.py:80-86), second half: given dot = x.C^T (MFMA GEMM),
 // dist[k] = (sum(x^2) - 2*dot[k]) + sum(C_k^2), argmin with lowest-index tie-break; wavefront min-reduction.
 __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict__ x, const float* __restrict__ dot,
@@ -207,6 +229,11 @@ int launch_cam_t(const float* cam, float* cam_t, float focal_length, float img_s
     hipLaunchKernelGGL(cam_t_kernel, dim3((B + 255) / 256), dim3(256), 0, s, cam, cam_t, focal_length, img_size, B);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+int launch_aa_to_rotmat(const float* aa, float* R, int n, hipStream_t s) {
+    hipLaunchKernelGGL(aa_to_rotmat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, aa, R, n);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_rot6d(const float* x, float* R, int n, hipStream_t s) {
     hipLaunchKernelGGL(rot6d_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, R, n);
     return hipGetLastError() == hipSuccess ? 0 : -2;

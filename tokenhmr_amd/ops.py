@@ -66,3 +66,14 @@ def rot6d_to_rotmat(x):
     with torch.cuda.device(x.device):
         _cabi.check(_cabi.load().thmr_op_rot6d(_p(x2), _p(R), n, _s(x)))
     return R
+
+
+def aa_to_rotmat(theta):
+    """geometry.py:5-44 aa_to_rotmat: (n,3) axis-angle -> (n,3,3)."""
+    _req(theta)
+    x = theta.reshape(-1, 3).contiguous()
+    n = x.shape[0]
+    R = torch.empty(n, 3, 3, device=theta.device, dtype=torch.float32)
+    with torch.cuda.device(theta.device):
+        _cabi.check(_cabi.load().thmr_op_aa_to_rotmat(_p(x), _p(R), n, _s(theta)))
+    return R
