@@ -30,7 +30,7 @@ constexpr int CODE = 256, VQW = 512, VQJ = 21;
 constexpr int NV = 6890, NJ = 24, NB = 10, NP = 207;
 constexpr float VIT_EPS = 1e-6f, LN_EPS = 1e-5f;
 constexpr float FOCAL = 5000.0f, IMG = 256.0f;
-// small-batch ViT path (gemm_ring_kernel): used while M = 192*B <= kSmallM; crossovers measured in profiles/r1_small_batch.md
+// small-batch ViT path (gemm_ring_kernel): used while M = 192*B <= kSmallM; crossovers measured in profiles/r1_small_gemm_variants.log
 constexpr int kSmallM = 1152, kSplitKMax = 4;     // B <= 6
 
 thread_local std::string g_last_error;

@@ -16,7 +16,7 @@
 //            8 slots), so the swizzle is applied to the per-lane SOURCE address: lane (r, p) fetches the
 //            logical slot p ^ ((r>>1)&7) of row r.  Every 8 lanes still read one whole 128-B line.
 //       REG  (kept for A/B): float4 global loads -> registers -> ds_write_b128 in the MFMA shadow.
-//     Ablation on MI355X (profiles/r1_gemm_ablation.md): the register staging traffic cost 10-13 % of the
+//     Ablation on MI355X (profiles/r1_gemm_ablation_raw.log, r1_gemm_dma_ablation_raw.log): the register staging traffic cost 10-13 % of the
 //     MFMA rate, the barrier 0-4 %, a pure-MFMA loop of this shape runs at 145-155 TF.
 //   * pipeline: two LDS buffers, ONE barrier per 32-deep K tile, 2 blocks per CU (the co-resident block
 //     covers the barrier / first-fragment bubble; 3-stage single-block variants measured 15 % slower).
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
 // ---------------------------------------------------------------------------------------------------------------------
 // Small-M GEMM (few crops: M = 192*B with B <~ 8).  The big-tile kernel above leaves most of the 256 CUs idle there and
 // its 2-buffer pipeline pays one full memory round trip per 32-deep K tile when only one block sits on a CU
-// (measured 1.1 us per K tile at B = 1: 45 us for K = 1280, 157 us for K = 5120 — profiles/r1_small_batch.md).
+// (measured 1.1 us per K tile at B = 1: 45 us for K = 1280, 157 us for K = 5120 — profiles/r1_small_batch_classes.log).
 //   * 64x64 tiles (2x2 waves of 32x32), ST-deep LDS ring fed by global_load_lds: the copy of K tile kt+ST-1 is issued
 //     while tile kt is multiplied, completion is tracked with s_waitcnt vmcnt(N) (LDS-DMA returns in order), and the
 //     ONE barrier per K tile sits in the middle of the tile's MFMAs so it is covered by queued matrix work.
