@@ -71,3 +71,20 @@ def test_eval_loop_with_all_dropins(built_lib, cuda_dev):
     top2 = ref["cls_logits"].topk(2, dim=-1).values
     safe = (top2[..., 0] - top2[..., 1]) > 1e-2
     assert (out["token_idx"].cpu() == ref["token_idx"])[safe].all()
+
+
+def test_track_py_style_sliced_input(built_lib, cuda_dev):
+    """track.py:33-39 hands the model a NON-contiguous view: batch['img'] = x[:, :3] of a 4-channel (RGB + mask) crop."""
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd import weights as W
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    from tokenhmr_amd.model import TokenHMR
+    cfg = HMRConfig(vit_depth=1, dec_depth=1)
+    model = TokenHMR.from_state(cfg, W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0), make_synthetic_smpl(cfg, 0),
+                                max_batch=4, device=cuda_dev)
+    x = torch.randn(3, 4, 256, 256, generator=torch.Generator().manual_seed(2)).to(cuda_dev)
+    view = x[:, :3, :, :]
+    assert not view.is_contiguous()
+    a, b = model({"img": view, "mask": x[:, 3].clip(0, 1)}), model({"img": view.contiguous()})
+    assert torch.equal(a["pred_vertices"], b["pred_vertices"]) and torch.equal(a["pred_cam"], b["pred_cam"])
+    assert set(a["pred_smpl_params"]) == {"global_orient", "body_pose", "betas"}
