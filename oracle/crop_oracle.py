@@ -6,9 +6,15 @@ What the reference does (tokenhmr/lib/datasets/vitdet_dataset.py:44-88 for demo.
 
   * box -> affine:  `gen_trans_from_patch_cv`   lib/datasets/utils.py:81-128   (restated line by line, numpy)
                     + cv2.getAffineTransform      THIRD PARTY (opencv-python, requirements: not vendored, absent here)
-  * anti-alias:     skimage.filters.gaussian      THIRD PARTY (scikit-image, absent here); it is a thin wrapper of
-                    scipy.ndimage.gaussian_filter(mode='nearest', truncate=4.0, sigma=(s, s, 0)) on the float64 image, and
-                    scipy IS present — the blur is computed by the real backend.
+  * anti-alias:     skimage.filters.gaussian      THIRD PARTY (scikit-image); it is a thin wrapper of
+                    scipy.ndimage.gaussian_filter(mode='nearest', truncate=4.0, sigma=(s, s, 0)) on the float64 image.
+                    The system python has scipy but not scikit-image; the image's second interpreter
+                    (/opt/conda/bin/python3.9: numpy 1.26, scikit-image 0.18.3) has both, and the reference's dataset
+                    code run THERE with the real skimage gives tensors this module reproduces bit for bit
+                    (oracle/gen_golden_crop_numpy1.py -> tests/golden/crop_numpy1.npz): PINNED.
+  * numpy version:  the reference pins numpy==1.23.1 (legacy value-based promotion).  Three expressions of the crop code
+                    change precision under numpy >= 2 (float32 box arithmetic in expand_to_aspect_ratio, float32 sigma,
+                    float64 normalisation); `numpy1=True` restates the pinned behaviour and is what the fixture above pins.
   * warp:           cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT)   THIRD PARTY, absent here.  `warp_affine` below restates
                     OpenCV 4.x imgwarp.cpp: inverse of the 2x3 matrix in double; fixed-point source coordinates with
                     AB_BITS = 10 and INTER_BITS = 5 (X = (rint((M1*y+M2)*1024) + 16 + rint(M0*x*1024)) >> 5, integer part
@@ -138,16 +144,19 @@ def gaussian_antialias(img, sigma, truncate=4.0):
     return ndimage.gaussian_filter(img.astype(np.float64), [sigma, sigma, 0], mode="nearest", cval=0, truncate=truncate)
 
 
-def expand_to_aspect_ratio(input_shape, target_aspect_ratio=None):
-    """lib/datasets/utils.py:14-33"""
+def expand_to_aspect_ratio(input_shape, target_aspect_ratio=None, numpy1=False):
+    """lib/datasets/utils.py:14-33.  w, h arrive as numpy float32 scalars and w_t, h_t as Python ints: the pinned numpy 1.23
+    promotes `w * h_t / w_t` to float64 (legacy scalar promotion), numpy >= 2 keeps float32.  numpy1=True restates the pinned
+    behaviour with Python floats (same IEEE double operations)."""
     if target_aspect_ratio is None:
         return input_shape
     w, h = input_shape
     w_t, h_t = target_aspect_ratio
+    wd, hd = (float(w), float(h)) if numpy1 else (w, h)
     if h / w < h_t / w_t:
-        h_new, w_new = max(w * h_t / w_t, h), w
+        h_new, w_new = max(wd * h_t / w_t, h), w
     else:
-        h_new, w_new = h, max(h * w_t / h_t, w)
+        h_new, w_new = h, max(hd * w_t / h_t, w)
     return np.array([w_new, h_new])
 
 
@@ -175,7 +184,7 @@ def vitdet_item(img_cv2, box, img_size=256, bbox_shape=None, mean=(0.485, 0.456,
     box = np.asarray(box).astype(np.float32)
     center = (box[2:4] + box[0:2]) / 2.0
     scale = (box[2:4] - box[0:2]) / 200.0
-    bbox_size = expand_to_aspect_ratio(scale * 200, target_aspect_ratio=bbox_shape).max()
+    bbox_size = expand_to_aspect_ratio(scale * 200, target_aspect_ratio=bbox_shape, numpy1=numpy1).max()
     cvimg = img_cv2.copy()
     # vitdet_dataset.py:64-65.  bbox_size is a numpy float32 scalar: under the pinned numpy 1.23 `bbox_size*1.0` is a float64
     # and sigma / the gaussian weights are computed in double; numpy >= 2 keeps float32 (and scipy then squares sigma in

@@ -56,14 +56,17 @@ def gen_trans_from_patch_cv(c_x, c_y, src_width, src_height, dst_width, dst_heig
 
 
 def expand_to_aspect_ratio(input_shape, target_aspect_ratio=None):
-    """lib/datasets/utils.py:14-33"""
+    """lib/datasets/utils.py:14-33.  w, h are numpy float32 scalars and w_t, h_t Python ints; under the numpy the reference
+    pins (1.23.1, legacy scalar promotion) `w * h_t / w_t` is evaluated in float64, so the expanded side — and with it the
+    bbox size, the anti-alias sigma and the affine — is a double-precision function of the float32 box.  Python floats
+    reproduce exactly that (verified against the reference's code run under numpy 1.26: tests/golden/crop_numpy1.npz)."""
     if target_aspect_ratio is None:
         return input_shape
     w, h = input_shape
     w_t, h_t = target_aspect_ratio
     if h / w < h_t / w_t:
-        return np.array([w, max(w * h_t / w_t, h)])
-    return np.array([max(h * w_t / h_t, w), h])
+        return np.array([w, max(float(w) * h_t / w_t, h)])
+    return np.array([max(float(h) * w_t / h_t, w), h])
 
 
 class Cropper:
@@ -190,7 +193,7 @@ class ViTDetDataset:
         return {"img": img,
                 "personid": torch.as_tensor(self.personid[idxs].astype(np.int64), device=dev),
                 "box_center": torch.as_tensor(self.center[idxs], device=dev),
-                "box_size": torch.as_tensor(np.array([p[0] for p in ps], dtype=np.float32), device=dev),
+                "box_size": torch.as_tensor(np.array([float(p[0]) for p in ps], dtype=np.float64), device=dev),   # float64, as collated under the pinned numpy
                 "img_size": torch.as_tensor(np.tile(1.0 * np.array([W, H]), (len(idxs), 1)), device=dev)}
 
 
