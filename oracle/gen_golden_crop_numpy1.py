@@ -110,6 +110,23 @@ def main():
               float(np.abs(img - mine).max()))
         out[f"img_{tag}"] = img[:, :, ::4, ::4]
         out[f"box_size_{tag}"] = np.array([it["box_size"] for it in items], dtype=np.float64)
+    # Plausibility bound for the UNPINNED primitive: the restated cv2.warpAffine (5-bit fixed-point bilinear) against
+    # scikit-image's independent floating-point bilinear affine warp on the un-blurred crops.  They are different algorithms
+    # (coordinates quantised to 1/32 px, integer weights and rounding in OpenCV), so only closeness is expected: a wrong
+    # matrix convention, a half-pixel offset or swapped axes would show up as tens of grey levels.
+    from skimage.transform import AffineTransform, warp
+    sk = []
+    for b in boxes:
+        o = CO.vitdet_item(frame, b, 256, [192, 256])
+        T = AffineTransform(matrix=np.vstack([o["trans"], [0, 0, 1]]))
+        ref = warp(frame, T.inverse, output_shape=(256, 256), order=1, mode="constant", cval=0, preserve_range=True)
+        mine = CO.warp_affine(frame, o["trans"], (256, 256)).astype(np.float64)
+        d = np.abs(mine - ref)
+        print("restated cv2.warpAffine vs skimage bilinear warp: mean |diff| %.3f  p99 %.3f  max %.3f grey levels" %
+              (d.mean(), np.percentile(d, 99), d.max()))
+        assert d.mean() < 0.5 and np.percentile(d, 99) < 1.5 and d.max() < 6.0
+        sk.append(ref[::4, ::4].astype(np.float32))
+    out["skimage_bilinear_small"] = np.stack(sk)
     path = os.path.join(ROOT, "tests", "golden", "crop_numpy1.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

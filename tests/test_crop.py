@@ -243,3 +243,17 @@ def test_gpu_vs_numpy1_realskimage_fixture(built_lib, cuda_dev):
                 assert d.max() == 0, (tag, i, d.max())
             else:
                 assert d.max() < 1e-6 and (d > 0).mean() < 1e-3, (tag, i, d.max(), (d > 0).mean())
+
+
+def test_restated_warp_is_close_to_an_independent_bilinear_warp():
+    """cv2.warpAffine itself cannot be pinned here (opencv is absent), but its restatement can be bounded: against
+    scikit-image's floating-point bilinear affine warp (fixture produced by the real skimage, see
+    oracle/gen_golden_crop_numpy1.py) the 5-bit fixed-point result differs by well under one grey level on average.  A wrong
+    matrix convention, half-pixel offset or axis swap would show tens of levels."""
+    g1 = dict(np.load(GOLD1))
+    small = dict(np.load(GOLD))
+    for i, box in enumerate(small["boxes"]):
+        o = CO.vitdet_item(small["frame"], box, 256, [192, 256])
+        mine = CO.warp_affine(small["frame"], o["trans"], (256, 256)).astype(np.float64)[::4, ::4]
+        d = np.abs(mine - g1["skimage_bilinear_small"][i])
+        assert d.mean() < 0.5 and np.percentile(d, 99) < 1.6 and d.max() < 6.0, (i, d.mean(), d.max())
