@@ -88,3 +88,32 @@ def test_track_py_style_sliced_input(built_lib, cuda_dev):
     a, b = model({"img": view, "mask": x[:, 3].clip(0, 1)}), model({"img": view.contiguous()})
     assert torch.equal(a["pred_vertices"], b["pred_vertices"]) and torch.equal(a["pred_cam"], b["pred_cam"])
     assert set(a["pred_smpl_params"]) == {"global_orient", "body_pose", "betas"}
+
+
+def test_second_engine_shares_the_weight_arena(built_lib, cuda_dev):
+    """Several engines on one GPU (e.g. one per caller thread / stream) can share one packed weight arena: the second engine
+    only adds its scratch.  Results are bit-identical, also when both run concurrently on two streams."""
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd import weights as W
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    from tokenhmr_amd.engine import Engine
+    cfg = HMRConfig(vit_depth=2, dec_depth=2)
+    e1 = Engine(cfg, max_batch=4, device=cuda_dev)
+    e1.load_state(W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0))
+    e1.load_smpl(make_synthetic_smpl(cfg, 0))
+    e1.finalize()
+    e2 = Engine(cfg, max_batch=4, device=cuda_dev, weight_arena=e1.weight_arena)
+    e2.finalize(assume_all_loaded=True)
+    img = torch.randn(4, 3, 256, 256, generator=torch.Generator().manual_seed(3)).to(cuda_dev)
+    ref = e1.forward(img)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        a = e1.forward(img)
+    with torch.cuda.stream(s2):
+        b = e2.forward(img)
+    torch.cuda.synchronize()
+    for k in ("pred_vertices", "pred_keypoints_3d", "token_idx"):
+        assert torch.equal(a[k], ref[k]) and torch.equal(b[k], ref[k]), k
+    with pytest.raises(ValueError):
+        Engine(HMRConfig(vit_depth=1, dec_depth=1), max_batch=4, device=cuda_dev, weight_arena=e1.weight_arena)

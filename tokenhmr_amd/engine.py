@@ -21,7 +21,9 @@ class Engine:
     """One engine per GPU.  The weight arena is a torch uint8 tensor so that
     torch.distributed.broadcast (RCCL) can replicate it across ranks."""
 
-    def __init__(self, cfg: HMRConfig = RELEASE, max_batch: int = 64, device="cuda:0"):
+    def __init__(self, cfg: HMRConfig = RELEASE, max_batch: int = 64, device="cuda:0", weight_arena=None):
+        """weight_arena: share another engine's (already loaded) packed weights — a second engine on the same GPU then only
+        adds its own scratch arena (finalize it with assume_all_loaded=True)."""
         self.lib = _cabi.load()
         self.cfg = cfg
         self.max_batch = int(max_batch)
@@ -36,7 +38,12 @@ class Engine:
         _cabi.check(self.lib.thmr_arena_bytes(C.byref(self._ccfg), C.byref(wb), C.byref(sb)))
         self.weight_bytes, self.scratch_bytes = wb.value, sb.value
         with torch.cuda.device(self.device):
-            self.weight_arena = torch.empty(self.weight_bytes, dtype=torch.uint8, device=self.device)
+            if weight_arena is not None:
+                if weight_arena.numel() != self.weight_bytes or weight_arena.dtype != torch.uint8 or weight_arena.device != self.device:
+                    raise ValueError("weight_arena must be the uint8 arena of an engine with the same config on the same device")
+                self.weight_arena = weight_arena
+            else:
+                self.weight_arena = torch.empty(self.weight_bytes, dtype=torch.uint8, device=self.device)
             self.scratch_arena = torch.empty(self.scratch_bytes, dtype=torch.uint8, device=self.device)
             h = C.c_void_p(0)
             _cabi.check(self.lib.thmr_create(C.byref(self._ccfg), _ptr(self.weight_arena), _ptr(self.scratch_arena),
