@@ -231,3 +231,23 @@ def test_aa_to_rotmat_vs_reference_golden(built_lib, cuda_dev):
     big = 3.0 * _rand(4096, 3, seed=5)
     R2 = ops.aa_to_rotmat(big.to(cuda_dev)).cpu()
     assert (R2.double() - O.aa_to_rotmat(big.double())).abs().max() < 2e-6
+
+
+def test_vit_attention_stress_both_variants_and_determinism(built_lib, cuda_dev):
+    """The attention kernel stages K / V by asynchronous LDS-DMA tracked with s_waitcnt vmcnt(N): a missed wait or barrier shows
+    up as a wrong or run-to-run varying result.  Many workgroups (B = 64: four per CU), both query-tile variants (B <= 10 uses
+    64-query workgroups, larger batches 192-query ones; the first 10 crops must agree bit for bit between them), ten repeats."""
+    from tokenhmr_amd import ops
+    B = 64
+    qkv = _rand(B, 192, 3840, seed=21)
+    qkv[:, :, :1280] *= 80 ** -0.5
+    t = qkv.reshape(B, 192, 3, 16, 80).permute(2, 0, 3, 1, 4).double()
+    ref = ((t[0] @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]).transpose(1, 2).reshape(B, 192, 1280)
+    d = qkv.to(cuda_dev)
+    first = ops.vit_attention(d)
+    assert (first.cpu().double() - ref).abs().max() < 5e-6
+    small = ops.vit_attention(d[:10].contiguous())                 # 64-query variant
+    assert torch.equal(small, first[:10])
+    for _ in range(10):
+        assert torch.equal(ops.vit_attention(d), first)
+        assert torch.equal(ops.vit_attention(d[:10].contiguous()), small)
