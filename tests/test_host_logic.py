@@ -158,3 +158,26 @@ def test_product_path_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_stateless_entry_points_reject_bad_arguments_without_a_gpu(built_lib):
+    """Argument validation happens before any HIP call, so it is testable here: null buffers, bad epilogue ids, missing
+    bias / residual, null handles.  Every failure is a negative status plus a message, never a crash."""
+    L = built_lib
+    null = C.c_void_p(0)
+    one = C.c_void_p(16)             # any non-null address: validation fails before it is dereferenced
+    assert L.thmr_op_gemm(null, 32, one, null, null, one, 32, 1, 1, 32, 0, 1.0, 0, -1, null) < 0          # null A
+    assert L.thmr_op_gemm(one, 32, one, null, null, one, 32, 1, 1, 32, 99, 1.0, 0, -1, null) < 0          # bad epilogue id
+    assert L.thmr_op_gemm(one, 32, one, null, null, one, 32, 1, 1, 32, 1, 1.0, 0, -1, null) < 0           # bias epilogue, no bias
+    assert L.thmr_op_gemm(one, 32, one, one, null, one, 32, 1, 1, 32, 4, 1.0, 0, -1, null) < 0            # residual epilogue, no residual
+    assert b"resid" in L.thmr_last_error(None)
+    assert L.thmr_op_layernorm(null, one, one, one, 1, 64, 1e-5, 0, null) < 0
+    assert L.thmr_op_rot6d(null, one, 1, null) < 0 and L.thmr_op_aa_to_rotmat(one, null, 1, null) < 0
+    assert L.thmr_op_aa_to_rotmat(one, one, 0, null) < 0
+    assert L.thmr_forward(null, one, 1, None, null) < 0 and L.thmr_vit_forward(null, one, 1, one, null) < 0
+    assert L.thmr_encode_tokens(null, one, 1, one, null, null) < 0 and L.thmr_vq_decode(null, one, 1, one, null) < 0
+    assert L.thmr_cropper_run(null, one, 8, 8, 24, None, 1, 256, 1, None, None, one, null) < 0
+    assert b"null cropper" in L.thmr_cropper_last_error(None)
+    assert L.thmr_smpl_create(None, 1, 0, None) < 0
+    h = C.c_void_p(0)
+    assert L.thmr_cropper_create(-1, C.byref(h)) < 0 and not h.value
