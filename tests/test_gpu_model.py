@@ -358,3 +358,25 @@ def test_odd_batch_sizes_vs_oracle(built_lib, cuda_dev, B):
     top2 = orc["cls_logits"].topk(2, dim=-1).values
     safe = (top2[..., 0] - top2[..., 1]) > 1e-2
     assert (out["token_idx"] == orc["token_idx"])[safe].all()
+
+
+def test_large_ragged_batch_equals_its_chunks(built_lib, cuda_dev):
+    """Maximum-size edge: one call with B = 200 (M = 38400 rows: 300 row tiles, the last LBS crop group and the skinny-GEMM
+    row groups partially filled) must give every crop exactly the result of running it inside a 64-crop call — per-crop
+    results may not depend on the batch they travel in (large-batch regime, B >= 7)."""
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd.model import TokenHMR
+    cfg = HMRConfig(vit_depth=2, dec_depth=2)
+    sd, tok, smpl = _assets(cfg, seed=8)
+    model = TokenHMR.from_state(cfg, sd, tok, smpl, max_batch=200, device=cuda_dev)
+    img = _inputs(200, seed=21).to(cuda_dev)
+    whole = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in model({"img": img}).items()}
+    for s in range(0, 200, 64):
+        part = model({"img": img[s:s + 64]})
+        n = part["pred_cam"].shape[0]
+        for k in ("pred_vertices", "pred_keypoints_3d", "pred_keypoints_2d", "pred_cam", "pred_cam_t", "token_idx",
+                  "cls_logits_softmax"):
+            assert torch.equal(part[k], whole[k][s:s + n]), (k, s)
+    assert torch.isfinite(whole["pred_vertices"]).all()
+    del model
+    torch.cuda.empty_cache()
