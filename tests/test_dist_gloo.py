@@ -95,3 +95,61 @@ def test_single_process_is_identity():
     out = D.ShardedRunner(_fake_forward)(img)
     ref = _fake_forward(img)
     assert all(torch.equal(out[k], ref[k]) for k in ref)
+
+
+class _StubEvaluator:
+    """The state the reference's Evaluator keeps (pose_utils.py:160-175): metric arrays, a fill counter, image names."""
+    metrics = ["mode_re", "mode_mpjpe", "mode_pve"]
+
+    def __init__(self, n=16):
+        import numpy as np
+        for m in self.metrics:
+            setattr(self, m, np.zeros((n,)))
+        self.counter, self.imgnames = 0, []
+
+    def feed(self, idx):
+        for i in idx:
+            for k, m in enumerate(self.metrics):
+                getattr(self, m)[self.counter] = 10.0 * (k + 1) + 0.37 * i * (k + 1)
+            self.imgnames.append(f"img{i}")
+            self.counter += 1
+
+
+def _eval_worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ev = _StubEvaluator(n=8)                       # smaller than the merged length: merge must grow the arrays
+        s, e = D.shard_range(total, world, rank)
+        ev.feed(range(s, e))
+        D.merge_evaluator(ev, total)
+        q.put((rank, ev.counter, [float(x) for x in ev.mode_mpjpe[:ev.counter]], list(ev.imgnames)))
+        try:
+            D.merge_evaluator(ev, total + 1)
+            q.put((rank, "no error"))
+        except ValueError:
+            q.put((rank, "raised"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_evaluators_merge_to_the_single_process_result():
+    total = 11
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_eval_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(4)]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    one = _StubEvaluator(n=16)
+    one.feed(range(total))
+    assert D.merge_evaluator(one, total) is one                     # no process group: identity
+    res = [g for g in got if len(g) == 4]
+    assert len(res) == 2 and sorted(g[1] for g in got if len(g) == 2) == ["raised", "raised"]
+    for _, counter, mpjpe, names in res:
+        assert counter == total and names == one.imgnames
+        assert mpjpe == [float(x) for x in one.mode_mpjpe[:total]]

@@ -117,3 +117,47 @@ def test_second_engine_shares_the_weight_arena(built_lib, cuda_dev):
         assert torch.equal(a[k], ref[k]) and torch.equal(b[k], ref[k]), k
     with pytest.raises(ValueError):
         Engine(HMRConfig(vit_depth=1, dec_depth=1), max_batch=4, device=cuda_dev, weight_arena=e1.weight_arena)
+
+
+def test_run_eval_loop_matches_manual_loop(built_lib, cuda_dev):
+    """tokenhmr_amd.eval_dp.run_eval (eval.py:116-158 as a shardable job) on one process = the hand-written loop, for any
+    batch size (per-sample metrics, so batching cannot change the means beyond fp32 regime differences)."""
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd import weights as W
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    from tokenhmr_amd.model import TokenHMR
+    from tokenhmr_amd.evaluator import Evaluator
+    from tokenhmr_amd.eval_dp import run_eval, recursive_to
+
+    cfg = HMRConfig(vit_depth=1, dec_depth=1)
+    model = TokenHMR.from_state(cfg, W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0), make_synthetic_smpl(cfg, 0),
+                                max_batch=16, device=cuda_dev)
+    n = 19
+    g = torch.Generator().manual_seed(17)
+    imgs = torch.randn(n, 3, 256, 256, generator=g)
+    kp3d = torch.cat([0.3 * torch.randn(n, 44, 3, generator=g), torch.ones(n, 44, 1)], -1)
+    verts = 0.3 * torch.randn(n, 6890, 3, generator=g)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return n
+
+        def __getitem__(self, i):
+            return {"img": imgs[i], "keypoints_3d": kp3d[i], "vertices": verts[i], "imgname": f"im{i:03d}", "idx": i}
+
+    def make_ev():
+        return Evaluator(int(1e6), KP, 39, metrics=["mode_re", "mode_mpjpe", "mode_pve"], dataset="3DPW-TEST")
+
+    ev_a, ev_b, ev_m = make_ev(), make_ev(), make_ev()
+    a = run_eval(model, DS(), ev_a, batch_size=8, device=cuda_dev)
+    b = run_eval(model, DS(), ev_b, batch_size=16, device=cuda_dev)
+    for s in range(0, n, 8):
+        batch = recursive_to({"img": imgs[s:s + 8], "keypoints_3d": kp3d[s:s + 8], "vertices": verts[s:s + 8],
+                              "imgname": [f"im{i:03d}" for i in range(s, min(n, s + 8))]}, cuda_dev)
+        ev_m(model(batch), batch)
+    m = ev_m.get_metrics_dict()
+    assert ev_a.counter == n and ev_a.get_imgnames() == [f"im{i:03d}" for i in range(n)] == ev_m.get_imgnames()
+    for k in m:
+        assert a[k] == m[k], (k, a[k], m[k])                      # same batches -> same bits
+        assert abs(b[k] - m[k]) < 1e-3, (k, b[k], m[k])           # other batching: mm-scale metrics agree to 1e-3 mm
+    assert np.isfinite(list(m.values())).all() and m["mode_mpjpe"] > 0

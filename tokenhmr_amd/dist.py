@@ -122,3 +122,45 @@ class ShardedRunner:
         if not self.gather:
             return unpack_records(rec)
         return unpack_records(all_gather_records(rec, total))
+
+
+def merge_evaluator(ev, total=None):
+    """Sharded evaluation (BASELINE config 5: eval.py over the 8 GPUs of a node).  Every rank has run the reference's
+    evaluator protocol (pose_utils.py:201-275: per-sample metric arrays filled up to `counter`, `imgnames`) over ITS
+    contiguous shard shard_range(total, world, rank) of the dataset; after this call every rank's evaluator holds the metric
+    arrays and image names of ALL samples in dataset order, so `log()` / `get_metrics_dict()` (eval.py:154-158) report the
+    whole-dataset means — identical to a one-process run because only per-sample values travel, never partial means.
+    Two small collectives: the shard lengths and one padded (samples, metrics) float64 gather."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        if total is not None and ev.counter != total:
+            raise ValueError(f"evaluator saw {ev.counter} samples, expected {total}")
+        return ev
+    import numpy as np
+    world = dist.get_world_size()
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    cnt = torch.tensor([ev.counter], dtype=torch.int64, device=dev)
+    cnts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(cnts, cnt)
+    counts = [int(c) for c in cnts.cpu()]
+    if total is not None and sum(counts) != total:
+        raise ValueError(f"ranks evaluated {counts} samples, expected {total} in all")
+    mx, nm = max(counts), len(ev.metrics)
+    local = torch.zeros(mx, nm, dtype=torch.float64)
+    if ev.counter:
+        local[: ev.counter] = torch.from_numpy(np.stack([getattr(ev, m)[: ev.counter] for m in ev.metrics], 1))
+    buf = torch.empty(world * mx, nm, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(buf, local.to(dev))
+    buf = buf.cpu().numpy()
+    merged = np.concatenate([buf[r * mx: r * mx + c] for r, c in enumerate(counts)], 0)
+    names = [None] * world
+    dist.all_gather_object(names, list(ev.imgnames))
+    n = merged.shape[0]
+    for i, m in enumerate(ev.metrics):
+        arr = getattr(ev, m)
+        if arr.shape[0] < n:
+            arr = np.zeros((n,))
+            setattr(ev, m, arr)
+        arr[:n] = merged[:, i]
+    ev.counter = n
+    ev.imgnames = [x for part in names for x in part]
+    return ev
