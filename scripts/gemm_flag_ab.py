@@ -11,11 +11,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 AB = os.path.join(ROOT, "build_ab")
 sys.path.insert(0, ROOT)
 
-# name -> extra hipcc flags.  Round-1 experiment (profiles/r1_gemm_setprio_ntstore_experiment.log): -DTHMR_SETPRIO=1/2
-# (s_setprio 3 in the K loop / in the epilogue) and -DTHMR_NT_STORE (non-temporal C stores) were all within +-0.3 % of base,
-# so the macros were removed from gemm_f32.hip again; add an entry here together with the #if it switches.
+# name -> extra hipcc flags (an entry "src=<path>" compiles that file instead of tokenhmr_amd/csrc/gemm_f32.hip, e.g. a copy of
+# an older revision: git show <rev>:tokenhmr_amd/csrc/gemm_f32.hip > build_ab/gemm_f32_old.hip).
+# Round-1 experiments: profiles/r1_gemm_setprio_ntstore_experiment.log (-DTHMR_SETPRIO=1/2, -DTHMR_NT_STORE: no effect, macros
+# removed again) and profiles/r1_gemm_zero_valu_loop.log (old = builtin DMA with VALU address updates, new = saddr DMA).
 VARIANTS = {
     "base": [],
+    "old": ["src=build_ab/gemm_f32_old.hip"],
+    "bar8": ["-DTHMR_GEMM_BARPOS=8"],
+    "bar32": ["-DTHMR_GEMM_BARPOS=32"],
 }
 
 
@@ -27,8 +31,16 @@ def build():
     procs = []
     for name, flags in VARIANTS.items():
         o = os.path.join(AB, f"gemm_f32_{name}.o")
-        procs.append((name, o, subprocess.Popen([G._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
-                                                + flags + ["-c", os.path.join(G.CSRC, "gemm_f32.hip"), "-o", o])))
+        src = os.path.join(G.CSRC, "gemm_f32.hip")
+        for f in flags:
+            if f.startswith("src="):
+                src = os.path.join(ROOT, f[4:])
+        if not os.path.exists(src):
+            print("skipping", name, "(no", src, ")")
+            continue
+        flags = [f for f in flags if not f.startswith("src=")]
+        procs.append((name, o, subprocess.Popen([G._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+                                                 "-I", G.CSRC] + flags + ["-c", src, "-o", o])))
     for name, o, p in procs:
         assert p.wait() == 0
         subprocess.check_call([G._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(AB, f"libv_{name}.so"), o] + others)
@@ -41,6 +53,8 @@ def run(rounds):
     libs = {}
     vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
     for name in VARIANTS:
+        if not os.path.exists(os.path.join(AB, f"libv_{name}.so")):
+            continue
         lib = C.CDLL(os.path.join(AB, f"libv_{name}.so"))
         lib.thmr_op_gemm.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, i32, i32, vp]
         libs[name] = lib

@@ -36,6 +36,26 @@ constexpr int BK = 32;
 constexpr int LDK = 32;   // LDS row (floats) = 8 slots of 16 B; slot' = slot ^ ((row >> 1) & 7)
 constexpr int NJ = BK / 8;
 
+template <int V>
+struct IntC {
+    constexpr operator int() const { return V; }
+};
+
+// One LDS-DMA wave instruction in the saddr form: 64 x 16 B from {uniform 64-bit base} + {per-lane 32-bit byte offset} to the
+// 1 KiB of LDS at `lds_base` (wave-uniform, goes through M0).  Written as inline assembly because hipcc only selects the
+// saddr form when the zero-extension of the offset sits in the same basic block as the load; with the offsets hoisted out of
+// the K loop it falls back to a 64-bit VALU add per copy.  The compiler does not count these copies in vmcnt: every consumer
+// must wait with dma_wait_barrier() below.  M0 is a reserved register that cannot be named as a clobber; the kernels using
+// this helper have no other M0 user (no LDS-DMA builtin, no movrel / sendmsg), and hipcc re-materialises M0 before its own uses.
+__device__ __forceinline__ void dma16_saddr(const char* base, uint32_t voff, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_base));
+}
+__device__ __forceinline__ uint32_t lds_addr(const float* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+}
+// all of this wave's LDS-DMA copies and LDS reads done, then the workgroup barrier
+__device__ __forceinline__ void dma_wait_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
@@ -170,9 +190,12 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, f32x16 (&acc)[TM][
 // DMA = true: global_load_lds staging; DMA = false: register staging
 // ABL (timing-only experiments, results are garbage): bit0 no DMA copies in the loop, bit1 no per-tile barrier,
 // bit2 no LDS fragment reads.  ABL = 0 is the product kernel.
-// DS: one DMA piece every DS-th MFMA (0 = auto).  BARPOS: 0 = barrier after the last MFMA in program order (hipcc hoists it
-// above the register-only MFMA tail), k > 0 = barrier pinned k MFMAs before the end of the tile.
-template <int WM, int WN, int TM, int TN, bool DMA, int EPI, int ABL = 0, int DSP = 0, int BARPOS = 0>
+// DS: one DMA piece every DS-th MFMA (0 = auto).  BARPOS (DMA path): per-tile barrier pinned BARPOS (0 = 32) MFMAs before the
+// end of the tile, never before the tile's last staging instruction (see GBAR below).
+#ifndef THMR_GEMM_BARPOS
+#define THMR_GEMM_BARPOS 0
+#endif
+template <int WM, int WN, int TM, int TN, bool DMA, int EPI, int ABL = 0, int DSP = 0, int BARPOS = THMR_GEMM_BARPOS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int tiles_m, int tiles_n) {
     constexpr int NW = WM * WN;
     constexpr int NT = NW * 64;
@@ -220,6 +243,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
         Wg[i] = a.W + (int64_t)min(bn0 + row, a.N - 1) * a.ldw + cs * 4;
     }
 
+    // DMA path: the same addresses as {uniform 64-bit base of the tile's first row, advanced by one K tile per iteration on
+    // the SALU} + {per-lane 32-bit byte offset, constant over K}, i.e. the saddr form of global_load_lds.  The K loop then
+    // has NO per-piece VALU address arithmetic: on gfx950 every VALU instruction issued between MFMAs takes 4-14 cycles away
+    // from the matrix pipe even with a second wave resident (profiles/r1_mfma_valu_microbench.log).
+    uint32_t Aoff[DMA ? A_F4 : 1], Woff[DMA ? B_F4 : 1];
+    const char* Abase = reinterpret_cast<const char*>(a.A + (int64_t)bm0 * a.lda);
+    const char* Wbase = reinterpret_cast<const char*>(a.W + (int64_t)bn0 * a.ldw);
+    if constexpr (DMA) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int row = (wave + i * NW) * 8 + (lane >> 3), cs = (lane & 7) ^ ((row >> 1) & 7);
+            Aoff[i] = ((uint32_t)(min(bm0 + row, a.M - 1) - bm0) * (uint32_t)a.lda + (uint32_t)cs * 4u) * 4u;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int row = (wave + i * NW) * 8 + (lane >> 3), cs = (lane & 7) ^ ((row >> 1) & 7);
+            Woff[i] = ((uint32_t)(min(bn0 + row, a.N - 1) - bn0) * (uint32_t)a.ldw + (uint32_t)cs * 4u) * 4u;
+        }
+    }
+
     // register staging path
     f32x4 ra[DMA ? 1 : A_F4], rb[DMA ? 1 : B_F4];
     auto load_global = [&](int kt) {
@@ -249,13 +292,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
     constexpr int NP = A_F4 + B_F4;     // DMA pieces per wave per K tile
     auto dma_piece = [&](int kt, int buf, int p) {      // p is a compile-time constant after unrolling
         if constexpr (DMA) {
-            const int k0 = kt * BK;
+            const int64_t k0b = (int64_t)kt * (BK * 4);      // wave-uniform: added to the base on the SALU
             if (p < A_F4)
-                __builtin_amdgcn_global_load_lds((gbl_void*)(Ag[p] + k0),
-                                                 (lds_void*)(As + (buf * BM + (wave + p * NW) * 8) * LDK), 16, 0, 0);
+                dma16_saddr(Abase + k0b, Aoff[p], lds_addr(As + (buf * BM + (wave + p * NW) * 8) * LDK));
             else
-                __builtin_amdgcn_global_load_lds((gbl_void*)(Wg[p - A_F4] + k0),
-                                                 (lds_void*)(Bs + (buf * BN + (wave + (p - A_F4) * NW) * 8) * LDK), 16, 0, 0);
+                dma16_saddr(Wbase + k0b, Woff[p - A_F4], lds_addr(Bs + (buf * BN + (wave + (p - A_F4) * NW) * 8) * LDK));
         }
     };
     auto dma_tile = [&](int kt, int buf) {
@@ -295,7 +336,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
         store_lds(0);
         load_global(min(1, nk - 1));
     }
-    __syncthreads();    // with LDS-DMA pending this is s_waitcnt vmcnt(0) + s_barrier
+    if constexpr (DMA) dma_wait_barrier();
+    else __syncthreads();
 
     // one fragment (f < TM: A rows, else W rows) of k-group j into register slot `slot`
     auto read_one = [&](int buf, int j, int slot, int f) {
@@ -309,9 +351,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
     constexpr int DS = DSP > 0 ? DSP : DS_AUTO;                     // measured: spreading the copies 4 MFMAs apart +2-5 %
     constexpr int OFF0 = (NP < G - (TM + TN)) ? NP : G - (TM + TN);  // where the fragment prefetch starts in k-group 0
     static_assert(TM + TN <= G && NP * DS <= NJ * G, "tile too small for the staging interleave");
+    // The per-tile barrier (this wave's copies of tile kt+1 landed + its LDS reads of tile kt returned) goes 32 MFMAs before
+    // the end of the tile, but never before the tile's last staging instruction: the MFMAs after it only touch registers
+    // and hide the barrier skew.  (A/B on the ViT shapes, profiles/r1_gemm_zero_valu_loop.log: 32 before the end is 0.3-1 %
+    // faster than 8 or 15 before the end.)
+    constexpr int LAST_READ = NJ >= 2 ? (NJ - 2) * G + (NJ == 2 ? OFF0 : 0) + TM + TN - 1 : 0;
+    constexpr int LAST_DMA = (NP - 1) * DS;
+    constexpr int LAST_STAGE = LAST_READ > LAST_DMA ? LAST_READ : LAST_DMA;
+    constexpr int GBAR_WANT = NJ * G - 1 - (BARPOS > 0 ? BARPOS : 32);
+    constexpr int GBAR = GBAR_WANT > LAST_STAGE ? GBAR_WANT : LAST_STAGE;
+    static_assert(GBAR < NJ * G, "barrier position");
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    // One K tile.  `bufc` is an integral constant on the DMA path (the loop below is unrolled by two), so every LDS address
+    // of the tile is {per-lane base computed once before the loop} + {immediate offset}: no VALU address updates per tile.
+    auto ktile = [&](int kt, auto bufc) {
+        const int buf = bufc;
         if constexpr (DMA) {
             // Issue order pinned with sched_barrier fences (hipcc otherwise clusters the DMA copies up front and sinks
             // the fragment prefetch below the MFMAs it should hide under):
@@ -339,10 +393,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
                             if constexpr (!(ABL & 1)) { if (do_dma) dma_piece(ktn, buf ^ 1, g / DS); }
                             if constexpr (!(ABL & 4)) { if (do_read) read_one(buf, j + 1, (j + 1) & 1, ridx); }
                             if (do_dma || do_read) __builtin_amdgcn_sched_barrier(0);
-                            if constexpr (BARPOS > 0 && !(ABL & 2)) {
-                                if (g == NJ * G - 1 - BARPOS) {
+                            if constexpr (!(ABL & 2)) {
+                                if (g == GBAR) {
                                     __builtin_amdgcn_sched_barrier(0);
-                                    __syncthreads();
+                                    dma_wait_barrier();
                                     __builtin_amdgcn_sched_barrier(0);
                                 }
                             }
@@ -366,13 +420,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
                 if (j == 1) load_global(min(kt + 2, nk - 1));
             }
         }
-        if constexpr (!(ABL & 2) && !(DMA && BARPOS > 0)) __syncthreads();
+        if constexpr (!(ABL & 2) && !DMA) __syncthreads();
         if constexpr ((ABL & 4) != 0) {
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) asm volatile("" : "+v"(af[0][mi]), "+v"(af[1][mi]));
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) asm volatile("" : "+v"(bf[0][ni]), "+v"(bf[1][ni]));
         }
+    };
+    if constexpr (DMA) {
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            ktile(kt, IntC<0>{});
+            ktile(kt + 1, IntC<1>{});
+        }
+        if (kt < nk) ktile(kt, IntC<0>{});
+    } else {
+        for (int kt = 0; kt < nk; ++kt) ktile(kt, kt & 1);
     }
 
     store_tile<TM, TN, EPI>(a, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
