@@ -40,6 +40,14 @@ template <int V>
 struct IntC {
     constexpr operator int() const { return V; }
 };
+// f(IntC<0>{}), f(IntC<1>{}), ..., f(IntC<N-1>{})
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(IntC<I>{});
+        static_for<N, I + 1>(f);
+    }
+}
 
 // One LDS-DMA wave instruction in the saddr form: 64 x 16 B from {uniform 64-bit base} + {per-lane 32-bit byte offset} to the
 // 1 KiB of LDS at `lds_base` (wave-uniform, goes through M0).  Written as inline assembly because hipcc only selects the
@@ -481,21 +489,26 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs a, int tiles_m,
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
     const int lrow = lane & 31, lhalf = lane >> 5;
 
-    // wave instruction q = wave + 4p covers tile rows 8q..8q+7 (see the DMA notes of gemm_f32_kernel)
-    const float* Ag[2];
-    const float* Wg[2];
+    // wave instruction q = wave + 4p covers tile rows 8q..8q+7 (see the DMA notes of gemm_f32_kernel).  As there, the copies use
+    // the saddr form (uniform base + constant 32-bit lane offset) and the ring slot of every tile is a compile-time constant
+    // (the K loop is unrolled by ST), so the K loop contains no VALU instruction at all: with 16 MFMAs per tile the 17 address
+    // VALU instructions of the first version cost >10 % of the matrix pipe (profiles/r1_mfma_valu_microbench.log).
+    uint32_t Aoff[2], Woff[2];
+    const char* Abase = reinterpret_cast<const char*>(a.A + (int64_t)bm0 * a.lda + kbeg);
+    const char* Wbase = reinterpret_cast<const char*>(a.W + (int64_t)bn0 * a.ldw + kbeg);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int row = (wave + 4 * p) * 8 + (lane >> 3), cs = (lane & 7) ^ ((row >> 1) & 7);
-        Ag[p] = a.A + (int64_t)min(bm0 + row, a.M - 1) * a.lda + kbeg + cs * 4;
-        Wg[p] = a.W + (int64_t)min(bn0 + row, a.N - 1) * a.ldw + kbeg + cs * 4;
+        Aoff[p] = ((uint32_t)(min(bm0 + row, a.M - 1) - bm0) * (uint32_t)a.lda + (uint32_t)cs * 4u) * 4u;
+        Woff[p] = ((uint32_t)(min(bn0 + row, a.N - 1) - bn0) * (uint32_t)a.ldw + (uint32_t)cs * 4u) * 4u;
     }
-    auto dma_tile = [&](int kt) {
-        const int st = kt & (ST - 1), k0 = kt * BK;
+    auto dma_tile = [&](int kt, auto stc) {      // K tile kt -> ring slot stc (= kt % ST, an integral constant)
+        const int st = stc;
+        const int64_t k0b = (int64_t)kt * (BK * 4);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            __builtin_amdgcn_global_load_lds((gbl_void*)(Ag[p] + k0), (lds_void*)(As + (st * BM + (wave + 4 * p) * 8) * LDK), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(Wg[p] + k0), (lds_void*)(Bs + (st * BN + (wave + 4 * p) * 8) * LDK), 16, 0, 0);
+            dma16_saddr(Abase + k0b, Aoff[p], lds_addr(As + (st * BM + (wave + 4 * p) * 8) * LDK));
+            dma16_saddr(Wbase + k0b, Woff[p], lds_addr(Bs + (st * BN + (wave + 4 * p) * 8) * LDK));
         }
     };
 
@@ -506,8 +519,8 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs a, int tiles_m,
 #pragma unroll
     for (int j = 0; j < NJ; ++j) koff[j] = (((2 * j + lhalf) ^ ((lrow >> 1) & 7)) << 2);
     f32x4 af[2], bf[2];
-    auto read_frags = [&](int kt, int j, int slot) {
-        const int st = kt & (ST - 1);
+    auto read_frags = [&](auto stc, int j, int slot) {
+        const int st = stc;
         af[slot] = *reinterpret_cast<const f32x4*>(As + (st * BM + wm0 + lrow) * LDK + koff[j]);
         bf[slot] = *reinterpret_cast<const f32x4*>(Bs + (st * BN + wn0 + lrow) * LDK + koff[j]);
     };
@@ -525,26 +538,33 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs a, int tiles_m,
     };
 
     // prologue: K tiles 0..ST-2 in flight; tile 0 must have landed (for every wave) before the first fragment read
-#pragma unroll
-    for (int t = 0; t < ST - 1; ++t)
-        if (t < nk) dma_tile(t);
+    static_for<ST - 1>([&](auto t) {
+        if (t < nk) dma_tile(t, t);
+    });
     if (nk >= ST - 1) wait_vm_barrier<(ST - 2) * NP>(); else wait_vm_barrier<0>();
-    read_frags(0, 0, 0);
+    read_frags(IntC<0>{}, 0, 0);
 
-    auto tile = [&](int kt, bool last) {      // `last` is a literal at both call sites
-        group(0, [&] { read_frags(kt, 1, 1); });
-        group(1, [&] { read_frags(kt, 2, 0); });
+    auto tile = [&](int kt, auto stc, bool last) {      // stc = kt % ST; `last` is a literal at every call site
+        constexpr int S = decltype(stc){};
+        group(0, [&] { read_frags(stc, 1, 1); });
+        group(1, [&] { read_frags(stc, 2, 0); });
         if (!last) {
             // tile kt+1 landed (in-order completion: at most the ST-3 younger tiles may still be in flight); after the
             // barrier every wave is past tile kt-1, whose ring slot receives tile kt+ST-1
             if (kt + ST - 2 < nk) wait_vm_barrier<(ST - 3) * NP>(); else wait_vm_barrier<0>();
-            if (kt + ST - 1 < nk) dma_tile(kt + ST - 1);
+            if (kt + ST - 1 < nk) dma_tile(kt + ST - 1, IntC<(S + ST - 1) % ST>{});
         }
-        group(0, [&] { read_frags(kt, 3, 1); });
-        group(1, [&] { if (!last) read_frags(kt + 1, 0, 0); });
+        group(0, [&] { read_frags(stc, 3, 1); });
+        group(1, [&] { if (!last) read_frags(IntC<(S + 1) % ST>{}, 0, 0); });
     };
-    for (int kt = 0; kt < nk - 1; ++kt) tile(kt, false);
-    tile(nk - 1, true);
+    int kt = 0;
+    for (; kt + ST <= nk - 1; kt += ST) static_for<ST>([&](auto sc) { tile(kt + sc, sc, false); });
+    static_for<ST>([&](auto sc) {            // < ST tiles left before the last one; kt is a multiple of ST
+        if (kt + sc < nk - 1) tile(kt + sc, sc, false);
+    });
+    static_for<ST>([&](auto sc) {
+        if (((nk - 1) & (ST - 1)) == sc) tile(nk - 1, sc, true);
+    });
 
     if constexpr (PARTIAL) {
         GemmArgs pa = a;
