@@ -10,7 +10,7 @@ from hypothesis import HealthCheck, given, settings, strategies as st
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = ["128x128", "128x160", "64x64", "ring4", "ring8", "auto"]
+VARIANTS = ["128x128", "128x160", "128x96", "64x64", "ring4", "ring8", "auto"]
 EPIS = ["none", "bias", "bias_gelu", "bias_relu", "bias_resid", "bias_qscale"]
 
 

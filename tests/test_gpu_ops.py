@@ -39,7 +39,7 @@ SHAPES = [(128, 128, 32), (256, 320, 64), (384, 1280, 1280), (200, 72, 96), (130
           (384, 3840, 1280), (384, 1280, 5120), (1, 160, 64), (1344, 512, 512)]
 
 
-@pytest.mark.parametrize("variant", ["128x128", "128x160", "64x64", "128x128reg", "128x160reg", "auto"])
+@pytest.mark.parametrize("variant", ["128x128", "128x160", "128x96", "64x64", "128x128reg", "128x160reg", "auto"])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_gemm_shapes(built_lib, cuda_dev, shape, variant):
     from tokenhmr_amd import ops

@@ -638,19 +638,27 @@ int launch_abl(const GemmArgs& a, hipStream_t s) {
 
 // variant: 0 = 128x128 REG (2x2 waves of 64x64)   1 = 128x160 REG (4x1 waves of 32x160)
 //          7 = 128x128 DMA                         8 = 128x160 DMA            9 = 64x64 DMA (2x2 waves of 32x32)
+//         10 = 128x96 DMA (4x1 waves of 32x96)
 //         -1 = DMA, tile picked by a cost model over 256 CUs   (2 is the skinny kernel, see thmr_op_gemm)
 int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % BK) != 0) return -1;
     if ((a.lda % 4) != 0 || (a.ldw % 4) != 0) return -1;
     if (variant < 0) {
-        // relative time ~ (rounds over 256 CUs) x tile area / tile efficiency; small grids (the VQ decoder's
-        // M = B*21 convs) cannot fill 256 CUs with big tiles and are latency-bound -> 64x64 tiles
+        // relative time ~ (rounds over 256 CUs) x tile area / tile efficiency.  A half-filled last round costs about one
+        // tile time, not two (a block that is alone on its CU runs almost twice as fast), so rounds are counted over 256 CUs
+        // although 512 blocks are resident.  Since the K loops carry no VALU work all tiles have nearly the same per-area
+        // efficiency (fitted on profiles/r1_tile_sweep.log: B = 7 ... 64 on the four ViT shapes) and the choice is mostly tile
+        // quantisation; small grids (the VQ decoder's M = B*21 convs) end up on the 64x64 tile.
         auto cost = [&](int BM, int BN, double eff) {
             const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
             return (double)((tiles + 255) / 256) * BM * BN / eff;
         };
-        const double c7 = cost(128, 128, 0.97), c8 = cost(128, 160, 1.0), c9 = cost(64, 64, 0.80);
-        variant = (c8 <= c7 && c8 <= c9) ? 8 : (c7 <= c9 ? 7 : 9);
+        const double c7 = cost(128, 128, 0.99), c8 = cost(128, 160, 1.0), c9 = cost(64, 64, 0.95), c10 = cost(128, 96, 0.985);
+        variant = 8;
+        double best = c8;
+        if (c7 < best) { best = c7; variant = 7; }
+        if (c10 < best) { best = c10; variant = 10; }
+        if (c9 < best) { best = c9; variant = 9; }
         // at most one 64x64 block per CU: nothing hides the 2-buffer kernel's per-K-tile memory round trip, so the 4-deep
         // ring version of the same tile is used (same K order, bit-identical; measured 46 -> ~30 us on the head's B = 1 convs)
         const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
@@ -677,6 +685,7 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         case 1: return launch_cfg<4, 1, 1, 5, false>(a, epi, s);
         case 8: return launch_cfg<4, 1, 1, 5, true>(a, epi, s);
         case 9: return launch_cfg<2, 2, 1, 1, true>(a, epi, s);
+        case 10: return launch_cfg<4, 1, 1, 3, true>(a, epi, s);     // 128x96
         default: return launch_cfg<2, 2, 2, 2, true>(a, epi, s);
     }
 }
