@@ -20,6 +20,10 @@
 //     MFMA rate, the barrier 0-4 %, a pure-MFMA loop of this shape runs at 145-155 TF.
 //   * pipeline: two LDS buffers, ONE barrier per 32-deep K tile, 2 blocks per CU (the co-resident block
 //     covers the barrier / first-fragment bubble; 3-stage single-block variants measured 15 % slower).
+//   * NO VALU instruction in the K loop: on gfx950 a VALU instruction issued between fp32 MFMAs costs 4-14 cycles of
+//     matrix-pipe time even with a second wave resident (profiles/r1_mfma_valu_microbench.log).  The copies use the saddr
+//     form (uniform base bumped on the SALU + constant 32-bit lane offsets, inline asm) and the K loop is unrolled by two
+//     so that every LDS address is a loop-invariant register + an immediate: +5-7 % (profiles/r1_gemm_zero_valu_loop.log).
 //   * k-permutation trick: one ds_read_b128 gives a lane 4 consecutive k of its row; lanes 0-31 take
 //     k0..k0+3 and lanes 32-63 take k0+4..k0+7, so MFMA step t multiplies k0+t (lower half) and
 //     k0+4+t (upper half).  A and W use the same permutation, hence the sum over k is unchanged.
@@ -643,6 +647,7 @@ int launch_abl(const GemmArgs& a, hipStream_t s) {
 int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % BK) != 0) return -1;
     if ((a.lda % 4) != 0 || (a.ldw % 4) != 0) return -1;
+    if (a.lda >= (1 << 22) || a.ldw >= (1 << 22)) return -1;     // per-lane byte offsets within a tile are 32-bit
     if (variant < 0) {
         // relative time ~ (rounds over 256 CUs) x tile area / tile efficiency.  A half-filled last round costs about one
         // tile time, not two (a block that is alone on its CU runs almost twice as fast), so rounds are counted over 256 CUs
@@ -695,5 +700,6 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
 int launch_gemm_ring(const GemmArgs& a, int epi, int ring, int ksplit, float* part, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || ksplit < 1 || (a.K % (BK * ksplit)) != 0) return -1;
     if ((a.lda % 4) != 0 || (a.ldw % 4) != 0 || (ksplit > 1 && part == nullptr)) return -1;
+    if (a.lda >= (1 << 22) || a.ldw >= (1 << 22)) return -1;
     return ring == 8 ? launch_ring<8>(a, epi, ksplit, part, s) : launch_ring<4>(a, epi, ksplit, part, s);
 }
