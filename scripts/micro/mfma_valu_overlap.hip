@@ -66,7 +66,21 @@ void run(float* out, int blocks, int iters) {
            mf / ms / 1e9, vf / ms / 1e9, (mf + vf) / ms / 1e9);
 }
 
-int main() {
+// second experiment (argument "occ"): MFMA-only kernel at 2 / 3 / 4 / 8 waves per SIMD in alternating order (the alternation
+// separates an occupancy effect from clock drift over the run)
+static void occupancy(float* out) {
+    const int iters = 20000;
+    for (int rep = 0; rep < 2; ++rep)
+        for (int blocks : {512, 1024, 768, 2048, 256, 512}) run<0, true>(out, blocks, iters);
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1) {
+        float* o;
+        (void)hipMalloc(&o, 4096 * 256 * sizeof(float));
+        occupancy(o);
+        return 0;
+    }
     float* out;
     hipMalloc(&out, 4096 * 256 * sizeof(float));
     const int iters = 20000;
