@@ -53,8 +53,18 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.thmr_destroy(self.h)
-            self.h = None
+            h, self.h = self.h, None
+            try:
+                ctx = torch.cuda.device(self.device)
+                ctx.__enter__()
+            except Exception:          # interpreter shutdown: torch may already be gone
+                ctx = None
+            self.lib.thmr_destroy(h)
+            if ctx is not None:
+                try:
+                    ctx.__exit__(None, None, None)
+                except Exception:
+                    pass
 
     def __del__(self):
         try:
@@ -219,10 +229,12 @@ class Engine:
     # ------------------------------------------------------------------ profiler
     def prof_enable(self, on=True):
         """on: False / True (every kernel class) / "gemm" (only the four ViT GEMM classes: cheapest, see the header)."""
-        _cabi.check(self.lib.thmr_prof_enable(self.h, 2 if on == "gemm" else (1 if on else 0)), self.h)
+        with torch.cuda.device(self.device):
+            _cabi.check(self.lib.thmr_prof_enable(self.h, 2 if on == "gemm" else (1 if on else 0)), self.h)
 
     def prof_collect(self, reset=True):
         arr = (_cabi.ProfEntry * len(_cabi.PROF_NAMES))()
-        _cabi.check(self.lib.thmr_prof_collect(self.h, arr, 1 if reset else 0), self.h)
+        with torch.cuda.device(self.device):
+            _cabi.check(self.lib.thmr_prof_collect(self.h, arr, 1 if reset else 0), self.h)
         return {n: dict(ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes, launches=arr[i].launches)
                 for i, n in enumerate(_cabi.PROF_NAMES)}
