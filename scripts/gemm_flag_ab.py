@@ -17,9 +17,7 @@ sys.path.insert(0, ROOT)
 # removed again) and profiles/r1_gemm_zero_valu_loop.log (old = builtin DMA with VALU address updates, new = saddr DMA).
 VARIANTS = {
     "base": [],
-    "old": ["src=build_ab/gemm_f32_old.hip"],
-    "bar8": ["-DTHMR_GEMM_BARPOS=8"],
-    "bar32": ["-DTHMR_GEMM_BARPOS=32"],
+    # "vgprform": ["-mllvm", "-amdgpu-mfma-vgpr-form"],   # accumulators in VGPRs: no effect (profiles/r1_gemm_vgpr_form_experiment.log)
 }
 
 
