@@ -181,3 +181,55 @@ def test_stateless_entry_points_reject_bad_arguments_without_a_gpu(built_lib):
     assert L.thmr_smpl_create(None, 1, 0, None) < 0
     h = C.c_void_p(0)
     assert L.thmr_cropper_create(-1, C.byref(h)) < 0 and not h.value
+
+
+def test_gemm_k_loops_carry_no_valu_instruction(built_lib, tmp_path):
+    """ISA-level regression guard (CPU): on gfx950 every VALU instruction issued between fp32 MFMAs costs matrix-pipe time
+    (profiles/r1_mfma_valu_microbench.log), so the K loops of the product GEMM (128x160 tile, fc1 epilogue) and of the
+    small-batch ring kernel must consist of MFMA / LDS / LDS-DMA / SALU instructions only, with saddr-form copies."""
+    import glob
+    import re
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    obj = os.path.join(os.path.dirname(_cabi.LIB_PATH), "gemm_f32.o")
+    if not (os.path.exists(objdump) and os.path.exists(obj)):
+        pytest.skip("llvm-objdump or the GEMM object file is not available")
+    work = str(tmp_path / "gemm_f32.o")
+    shutil.copy(obj, work)
+    subprocess.run([objdump, "-d", "--offloading", work], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=str(tmp_path), check=False)
+    cos = glob.glob(work + "*gfx950*")
+    assert cos, "no gfx950 code object inside gemm_f32.o"
+    text = subprocess.run([objdump, "-d", cos[0]], capture_output=True, text=True, check=True).stdout.split("\n")
+
+    def k_loop(symbol_re, min_mfma):
+        start = [i for i, l in enumerate(text) if re.match(r"^[0-9a-f]+ <.*" + symbol_re, l)]
+        assert start, symbol_re
+        end = next(i for i in range(start[0], len(text)) if "s_endpgm" in text[i])
+        ins = []
+        for l in text[start[0]:end + 1]:
+            m = re.match(r"\s+(\S+)\s+(.*?)\s*//\s*([0-9A-F]+):", l)
+            if m:
+                ins.append((int(m.group(3), 16), m.group(1), m.group(2)))
+        loops = []
+        for addr, op, args in ins:
+            if op.startswith("s_cbranch") or op == "s_branch":
+                m = re.search(r"(\d+)\s*$", args.split("<")[0].strip())
+                if not m:
+                    continue
+                off = int(m.group(1))
+                off -= 65536 if off >= 32768 else 0
+                tgt = addr + 4 + off * 4
+                if tgt < addr:
+                    seg = [x for x in ins if tgt <= x[0] <= addr]
+                    if sum(1 for x in seg if x[1].startswith("v_mfma")) >= min_mfma:
+                        loops.append(seg)
+        assert loops, "no MFMA loop found in " + symbol_re
+        return min(loops, key=len)                      # the innermost loop with that many MFMAs
+
+    for sym, min_mfma in ((r"gemm_f32_kernelILi4ELi1ELi1ELi5ELb1ELi2", 160), (r"gemm_ring_kernelILi4ELi5ELb0", 64)):
+        seg = k_loop(sym, min_mfma)
+        valu = [op for _, op, _ in seg if op.startswith("v_") and not op.startswith("v_mfma")]
+        dma = [(op, args) for _, op, args in seg if op.startswith("global_load_lds")]
+        assert not valu, (sym, valu[:8])
+        assert dma and all(re.search(r"s\[\d+:\d+\]", args) for _, args in dma), (sym, dma[:2])
