@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 # removed again) and profiles/r1_gemm_zero_valu_loop.log (old = builtin DMA with VALU address updates, new = saddr DMA).
 VARIANTS = {
     "base": [],
+    # "gelu2": ["-DTHMR_GELU_IMPL=2"],      # the two-piece erf_fast epilogue (previous default): profiles/r1_gelu_single_piece_ab.log
     # "vgprform": ["-mllvm", "-amdgpu-mfma-vgpr-form"],   # accumulators in VGPRs: no effect (profiles/r1_gemm_vgpr_form_experiment.log)
 }
 

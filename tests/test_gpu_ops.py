@@ -109,7 +109,7 @@ def test_gemm_ring_rejects(built_lib, cuda_dev):
 
 
 def test_gelu_epilogue_ulp(built_lib, cuda_dev):
-    """The epilogue's branch-free erf (csrc/common.h erf_fast) against fp64 GELU on a dense grid.  A has x in column 0 and
+    """The epilogue's branch-free erf (csrc/common.h erf_gelu; erf_fast in the THMR_GELU_IMPL=1/2 builds) against fp64 GELU on a dense grid.  A has x in column 0 and
     W a single 1, so C[m, n] = gelu(x_m) with no accumulation error.  fp32 GELU itself loses bits to the 1+erf cancellation
     for x << 0 (torch's fp32 kernel does too), hence the |x|-scaled absolute term: 2 ulp of (1+erf) * |x|/2."""
     from tokenhmr_amd import ops
