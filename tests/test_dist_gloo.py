@@ -153,3 +153,70 @@ def test_sharded_evaluators_merge_to_the_single_process_result():
     for _, counter, mpjpe, names in res:
         assert counter == total and names == one.imgnames
         assert mpjpe == [float(x) for x in one.mode_mpjpe[:total]]
+
+
+class _ToyDataset(torch.utils.data.Dataset):
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return {"img": torch.full((3, 2, 2), float(i)), "gt": torch.tensor([float(i) * 0.5]), "imgname": f"img{i}"}
+
+
+class _ToyEvaluator(_StubEvaluator):
+    """Reference protocol (pose_utils.py:201-275): called per batch, appends per-sample metrics."""
+
+    def __call__(self, out, batch):
+        err = (out["pred"] - batch["gt"]).abs().reshape(-1)
+        for j in range(err.shape[0]):
+            for k, m in enumerate(self.metrics):
+                getattr(self, m)[self.counter] = float(err[j]) * (k + 1)
+            self.imgnames.append(batch["imgname"][j])
+            self.counter += 1
+
+    def log(self):
+        pass
+
+    def get_metrics_dict(self):
+        return {m: float(getattr(self, m)[:self.counter].mean()) for m in self.metrics}
+
+
+def _toy_model(batch):
+    return {"pred": batch["img"][:, 0, 0, :1] * 0.75}         # per-crop function of the crop alone
+
+
+def _run_eval_worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tokenhmr_amd.eval_dp import run_eval
+        ev = _ToyEvaluator(n=total + 4)
+        res = run_eval(_toy_model, _ToyDataset(total), ev, batch_size=4, device="cpu")
+        q.put((rank, res, ev.counter, list(ev.imgnames)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_run_eval_sharded_over_two_ranks_equals_one_process():
+    """tokenhmr_amd.eval_dp.run_eval (eval.py:116-158 as a data-parallel job): 2 ranks x contiguous shards -> every rank reports
+    the metrics and image order a single process computes."""
+    from tokenhmr_amd.eval_dp import run_eval
+    total = 13
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_run_eval_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    one = _ToyEvaluator(n=total)
+    ref = run_eval(_toy_model, _ToyDataset(total), one, batch_size=4, device="cpu")
+    for _, res, counter, names in got:
+        assert counter == total and names == one.imgnames == [f"img{i}" for i in range(total)]
+        assert res.keys() == ref.keys() and all(abs(res[k] - ref[k]) < 1e-12 for k in ref)
