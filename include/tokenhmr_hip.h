@@ -74,7 +74,7 @@ typedef struct {
     const int32_t* extra_verts;     /* (21) smplx vertex_ids['smplh'] */
     const int32_t* joint_map;       /* (25) smpl_wrapper.py:19-20 */
     int32_t        on_device;
-    int32_t        reserved;
+    int32_t        update_hips;     /* SMPL(update_hips=...) smpl_wrapper.py:11,33-36: 1 = shift the two hip joints (mapped joints 9, 12) */
 } thmr_smpl_desc;
 
 /* Output buffers of one forward (tokenhmr.py:156-188).  Any pointer may be NULL (= not wanted). */

@@ -288,6 +288,10 @@ def smpl_forward(global_orient, body_pose, betas, smpl):
     verts = torch.matmul(Tv, vh.unsqueeze(-1))[:, :, :3, 0]
     joints = torch.cat([J_transformed, verts[:, smpl["extra_verts"].long()]], dim=1)       # 45
     joints = joints[:, smpl["joint_map"].long()]                                            # 25
+    if smpl.get("update_hips", False):                                                      # smpl_wrapper.py:33-36
+        joints[:, [9, 12]] = joints[:, [9, 12]] + \
+            0.25 * (joints[:, [9, 12]] - joints[:, [12, 9]]) + \
+            0.5 * (joints[:, [8]] - 0.5 * (joints[:, [9, 12]] + joints[:, [12, 9]]))
     extra = torch.einsum("bik,ji->bjk", verts, smpl["J19_regressor"])                       # 19
     return verts, torch.cat([joints, extra], dim=1)
 

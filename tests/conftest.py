@@ -14,11 +14,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def built_lib():
-    """The in-tree HIP library; built on demand where hipcc exists, never replaced by a fallback."""
+    """The in-tree HIP library, ALWAYS brought up to date first (build() is incremental by content hash and verifies that
+    the loaded library reports the hash of the current sources), never replaced by a fallback.  Round 1 built only when the
+    .so was missing, so an edited kernel could be tested against yesterday's binary."""
+    import __graft_entry__
+    __graft_entry__.build()
     from tokenhmr_amd import _cabi
-    if not os.path.exists(_cabi.LIB_PATH):
-        import __graft_entry__
-        __graft_entry__.build()
     return _cabi.load()
 
 

@@ -1,0 +1,103 @@
+"""bench.py's launch contract.  CPU (-m "not gpu"): `python bench.py --gpus 2` with no launcher re-executes itself under
+torch.distributed.run with 2 ranks; `--backend gloo --fake-engine` runs exactly the N-rank orchestration (rank 0 loads,
+ONE broadcast of the arena, per-step async packed all-gather joined one step later, barrier-bracketed timing, MAX over
+ranks, one JSON line from rank 0) on CPU tensors.  GPU (-m gpu): the same self-launch path on the nccl (= RCCL) backend at
+world size 1, and the broadcast -> finalize -> forward -> async all-gather -> unpack chain against the direct call."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _run(args, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env,
+                          timeout=timeout, cwd=ROOT)
+
+
+def _line(r):
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_gpus2_self_launches_two_gloo_ranks():
+    j = _line(_run(["--gpus", "2", "--backend", "gloo", "--fake-engine", "--steps", "3", "--warmup", "1", "--batch", "4"]))
+    assert j["n_gpus"] == 2 and j["config"]["ranks"] == 2 and j["config"]["backend"] == "gloo"
+    assert j["config"]["global_batch"] == 8 and j["config"]["batch_per_gpu"] == 4 and j["config"]["parallelism"] == "dp2"
+    assert j["config"]["allgather_outputs"] is True and j["gathered_records_ok"] is True
+    assert j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak" and j["metric"] == "crops_per_sec"
+    assert j["value"] > 0 and abs(j["value"] - 8 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-3
+    assert "dry_run" in j
+
+
+def test_gpus_flag_must_agree_with_the_launcher():
+    """Under a launcher (WORLD_SIZE set) a mismatching --gpus is a one-line error, not an AssertionError traceback."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = _run(["--gpus", "2", "--backend", "gloo", "--fake-engine"],
+             {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr and "Traceback" not in r.stderr
+
+
+def test_fake_engine_is_refused_on_the_gpu_backend():
+    r = _run(["--fake-engine", "--backend", "nccl"])
+    assert r.returncode != 0 and "dry run" in r.stderr
+
+
+@pytest.mark.gpu
+def test_self_launch_on_rccl_world1(built_lib, cuda_dev):
+    """`--gpus 1 --self-launch`: the N-rank code path (torch.distributed.run, nccl backend, broadcast, per-step all-gather)
+    with one rank, at a reduced depth so it takes seconds."""
+    j = _line(_run(["--gpus", "1", "--self-launch", "--vit-depth", "2", "--steps", "4", "--warmup", "1", "--batch", "8",
+                    "--no-cpu-baseline", "--no-extras"], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}))
+    assert j["n_gpus"] == 1 and j["config"]["ranks"] == 1 and j["config"]["backend"] == "nccl"
+    assert j["config"]["allgather_outputs"] is True and j["gathered_records_ok"] is True
+    assert j["roofline"]["frac"] > 0 and "src:" in j["build"]
+
+
+@pytest.mark.gpu
+def test_rccl_world1_chain_equals_direct_call(built_lib, cuda_dev):
+    """broadcast -> finalize -> forward -> async packed all-gather -> unpack on the nccl backend (world size 1) is bit-for-bit
+    the direct engine call."""
+    import torch
+    import torch.distributed as dist
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd import weights as W, dist as D
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    from tokenhmr_amd.engine import Engine
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda_dev)
+    try:
+        cfg = HMRConfig(vit_depth=2, dec_depth=2)
+        eng = Engine(cfg, max_batch=6, device=cuda_dev)
+        eng.load_state(W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0))
+        eng.load_smpl(make_synthetic_smpl(cfg, 0))
+        torch.cuda.synchronize()
+        D.broadcast_weights(eng, src=0)
+        torch.cuda.synchronize()
+        eng.finalize()
+        img = torch.randn(6, 3, 256, 256, generator=torch.Generator().manual_seed(5)).to(cuda_dev)
+        direct = {k: v.clone() for k, v in eng.forward(img).items()}
+        runner = D.ShardedRunner(lambda x: eng.forward(x), gather=True)
+        out = runner(img)
+        h = D.all_gather_records(D.pack_records(eng.forward(img)), 6, async_op=True)
+        piped = D.unpack_records(h.wait())
+        torch.cuda.synchronize()
+        for k in out:
+            assert torch.equal(out[k], direct[k]) and torch.equal(piped[k], direct[k]), k
+    finally:
+        dist.destroy_process_group()

@@ -22,8 +22,11 @@ def _free_port():
 
 
 def _fake_forward(img):
-    """Deterministic per-crop 'engine': every output is a pure function of the crop alone."""
+    """Deterministic per-crop 'engine': every output is a pure function of the crop alone.  Like the real engine
+    (check_ready, csrc/engine.hip) it refuses an empty batch."""
     B = img.shape[0]
+    if B < 1:
+        raise ValueError("batch 0 outside [1, max_batch]")
     key = img.reshape(B, -1)[:, :8].sum(dim=1)
     def f(n, k):
         return (key[:, None] * (torch.arange(n, dtype=torch.float32)[None] + k)).contiguous()
@@ -53,8 +56,10 @@ def _worker(rank, world, port, total, q):
         ref = D.unpack_records(D.pack_records(_fake_forward(img)))
         ok = all(torch.equal(out[k], ref[k]) for k in ref)
         # pipelined form used by bench.py: two gathers issued back to back, joined later, in order
-        h1 = D.all_gather_records(D.pack_records(_fake_forward(img[s:e])), total, async_op=True)
-        h2 = D.all_gather_records(D.pack_records(_fake_forward(2.0 * img[s:e])), total, async_op=True)
+        def rec(x):     # a rank whose shard is empty contributes a zero-row block (what ShardedRunner does)
+            return D.pack_records(_fake_forward(x)) if x.shape[0] else torch.zeros(0, D.RECORD_WORDS)
+        h1 = D.all_gather_records(rec(img[s:e]), total, async_op=True)
+        h2 = D.all_gather_records(rec(2.0 * img[s:e]), total, async_op=True)
         o1, o2 = D.unpack_records(h1.wait()), D.unpack_records(h2.wait())
         ref2 = D.unpack_records(D.pack_records(_fake_forward(2.0 * img)))
         ok = ok and all(torch.equal(o1[k], ref[k]) for k in ref) and all(torch.equal(o2[k], ref2[k]) for k in ref2)
@@ -87,6 +92,14 @@ def test_two_ranks_ragged_split():
     res = _run(7)       # shards of 4 and 3 crops: padded all-gather must drop the pad row
     assert [r[1] for r in res] == [(0, 4), (4, 7)]
     assert all(r[2] for r in res) and all(r[3] == 7 for r in res)
+
+
+def test_fewer_crops_than_ranks():
+    """total < world (one detection in a frame, two ranks): rank 1's shard is empty.  It must skip the forward (the engine
+    rejects B = 0) yet still enter the all-gather, or rank 0 hangs until the collective times out."""
+    res = _run(1)
+    assert [r[1] for r in res] == [(0, 1), (1, 1)]
+    assert all(r[2] for r in res) and all(r[3] == 1 for r in res)
 
 
 def test_single_process_is_identity():

@@ -3,8 +3,8 @@ inputs and (b) the committed golden tensors produced by the reference's own modu
 
 Tolerances (fp32 kernels vs a CPU fp32 oracle, differences are summation order only):
   ViT features 2e-3 abs (values O(1-10) after 32 residual blocks), token_out 1e-3, logits 1e-3,
-  token indices exactly equal wherever the oracle's top-2 logit gap > 1e-2 (and the mismatch
-  fraction is reported), rotmats 1e-4, vertices / joints 1e-4 m (0.1 mm), kp2d 1e-3.
+  token indices exactly equal wherever the reference's top-2 logit gap > 1e-3 (the ABSOLUTE mismatch count is
+  printed; test_b64_tokens_vs_reference_golden puts the claim on 10,240 depth-32 tokens), rotmats 1e-4, vertices / joints 1e-4 m (0.1 mm), kp2d 1e-3.
 """
 import os
 
@@ -57,12 +57,12 @@ def _check_against(out, ref, gap, tag):
     rep["joints"] = md(out["pred_keypoints_3d"], ref["joints"])
     rep["kp2d"] = md(out["pred_keypoints_2d"], ref["kp2d"])
     idx_eq = out["token_idx"] == ref["token_idx"]
-    safe = gap > 1e-2
-    rep["idx_mismatch_frac"] = 1.0 - idx_eq.float().mean().item()
-    print(f"[{tag}] " + " ".join(f"{k}={v:.2e}" for k, v in rep.items()))
+    safe = gap > 1e-3
+    rep["idx_mismatches"] = int((~idx_eq).sum())
+    print(f"[{tag}] " + " ".join(f"{k}={v:.2e}" for k, v in rep.items()) + f" of {idx_eq.numel()} tokens")
     assert rep["vit"] < 2e-3 and rep["token_out"] < 1e-3 and rep["logits"] < 1e-3, rep
-    assert idx_eq[safe].all(), "token index differs where the top-2 logit gap > 1e-2"
-    assert rep["idx_mismatch_frac"] < 0.02, rep
+    assert idx_eq[safe].all(), "token index differs where the top-2 logit gap > 1e-3"
+    assert rep["idx_mismatches"] <= int((~safe).sum()), rep
     assert rep["rot"] < 1e-4 and rep["betas"] < 1e-4 and rep["cam"] < 1e-4, rep
     assert rep["verts"] < 1e-4 and rep["joints"] < 1e-4, rep      # 0.1 mm
     assert rep["kp2d"] < 1e-3, rep
@@ -134,11 +134,11 @@ def _check_golden(model, cfg, sd, tok, name, pad_to=None):
         verts=md(out["pred_vertices"][:, ::VERT_STRIDE], T("verts_sample")), joints=md(out["pred_keypoints_3d"], T("joints")),
         kp2d=md(out["pred_keypoints_2d"], T("kp2d")))
     idx_eq = out["token_idx"] == T("token_idx")
-    safe = T("top2_gap") > 1e-2
-    rep["idx_mismatch_frac"] = 1.0 - idx_eq.float().mean().item()
-    print(f"[golden {name}] " + " ".join(f"{k}={v:.2e}" for k, v in rep.items()))
+    safe = T("top2_gap") > 1e-3
+    rep["idx_mismatches"] = int((~idx_eq).sum())
+    print(f"[golden {name}] " + " ".join(f"{k}={v:.2e}" for k, v in rep.items()) + f" of {idx_eq.numel()} tokens")
     assert rep["vit"] < 2e-3 and rep["token_out"] < 1e-3 and rep["logits"] < 1e-3, rep
-    assert idx_eq[safe].all() and rep["idx_mismatch_frac"] < 0.02, rep
+    assert idx_eq[safe].all() and rep["idx_mismatches"] <= int((~safe).sum()), rep
     assert rep["pose6d"] < 1e-4 and rep["rot"] < 1e-4 and rep["betas"] < 1e-4 and rep["cam"] < 1e-4, rep
     assert rep["verts"] < 1e-4 and rep["joints"] < 1e-4 and rep["kp2d"] < 1e-3, rep
     return full, (batch if pad_to else img)
@@ -171,6 +171,45 @@ def test_full_depth_vs_golden(built_lib, cuda_dev):
         assert torch.equal(again[k], full[k]), k                              # deterministic
         assert torch.equal(eight[k], full[k][:8]), k                          # batch-size invariant within the regime
     assert torch.isfinite(full["pred_vertices"]).all() and full["pred_vertices"].shape == (64, 6890, 3)
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_b64_tokens_vs_reference_golden(built_lib, cuda_dev):
+    """BASELINE.json configs[2] at its own size: 64 DISTINCT seeded crops (= bench.py's rank-0 batch) through ViT-H depth 32 +
+    the full head, against tests/golden/full_d32_b64.npz, which oracle/gen_golden.py produced with the reference's own
+    modules: 64 x 160 = 10,240 pose-token indices.  Rule: indices are EQUAL wherever the reference's own top-2 logit gap
+    exceeds 1e-3 (100 of the 10,240 tokens are closer than that, 15 closer than 1e-4, the closest pair is 4.8e-6 apart —
+    below that a different but equally valid fp32 summation order can legitimately flip the argmax); the absolute number
+    of mismatches is printed and bounded by a handful (measured on MI355X: see profiles/ and the bench line's `parity`)."""
+    from tokenhmr_amd.config import RELEASE
+    from tokenhmr_amd.model import TokenHMR
+    from tokenhmr_amd import weights as W
+    g = np.load(os.path.join(GOLDEN_DIR, "full_d32_b64.npz"))
+    vd, dd, B, seed = [int(v) for v in g["meta"]]
+    assert (vd, dd, B) == (32, 6, 64)
+    sd, tok, smpl = _assets(RELEASE, seed)
+    assert abs(W.checksum(sd) - g["weights_checksum"][0]) < 1e-6 * max(1.0, abs(g["weights_checksum"][0]))
+    img = _inputs(B, seed)
+    assert abs(float(img.double().sum()) - g["img_checksum"][0]) < 1e-6
+    model = TokenHMR.from_state(RELEASE, sd, tok, smpl, max_batch=64, device=cuda_dev)
+    out = _to_cpu(model({"img": img.to(cuda_dev)}))
+    idx, ref, gap = out["token_idx"].numpy(), g["token_idx"], g["top2_gap"]
+    mism = idx != ref
+    n_mis, n_safe_mis = int(mism.sum()), int((mism & (gap > 1e-3)).sum())
+    R = torch.cat([out["pred_smpl_params"]["global_orient"], out["pred_smpl_params"]["body_pose"]], 1).numpy()
+    rep = dict(joints=np.abs(out["pred_keypoints_3d"].numpy() - g["joints"]).max(),
+               verts=np.abs(out["pred_vertices"].numpy()[:, ::53] - g["verts_sample"]).max(),
+               rot=np.abs(R - g["rotmat"]).max(), betas=np.abs(out["pred_smpl_params"]["betas"].numpy() - g["betas"]).max(),
+               cam=np.abs(out["pred_cam"].numpy() - g["cam"]).max(), kp2d=np.abs(out["pred_keypoints_2d"].numpy() - g["kp2d"]).max(),
+               probs_max=np.abs(out["cls_logits_softmax"].max(-1).values.numpy() - g["probs_max"]).max())
+    print(f"[golden full_d32_b64] token-index mismatches: {n_mis} of {idx.size} "
+          f"({n_safe_mis} where the reference's top-2 gap > 1e-3; gaps at the mismatches: "
+          f"{sorted(float(x) for x in gap[mism])[:8]}) " + " ".join(f"{k}={v:.2e}" for k, v in rep.items()))
+    assert n_safe_mis == 0, "a token index differs from the reference's where its top-2 logit gap > 1e-3"
+    assert n_mis <= 5, f"{n_mis} of {idx.size} token indices differ (all inside the 1e-3 near-tie band, but more than a handful)"
+    assert rep["joints"] < 1e-4 and rep["verts"] < 1e-4 and rep["rot"] < 1e-4 and rep["betas"] < 1e-4 and rep["cam"] < 1e-4
+    assert rep["kp2d"] < 1e-3 and rep["probs_max"] < 1e-5
     del model
     torch.cuda.empty_cache()
 

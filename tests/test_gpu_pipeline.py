@@ -102,11 +102,19 @@ def test_second_engine_shares_the_weight_arena(built_lib, cuda_dev):
     e1.load_state(W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0))
     e1.load_smpl(make_synthetic_smpl(cfg, 0))
     e1.finalize()
+    img = torch.randn(4, 3, 256, 256, generator=torch.Generator().manual_seed(3)).to(cuda_dev)
+    # the reference result is taken BEFORE the second engine exists: creating / finalising e2 must not touch e1's weights
+    # (round 1 zeroed the read-out rows of a shared arena in thmr_create and this test compared corrupted with corrupted)
+    ref = {k: v.clone() for k, v in e1.forward(img).items()}
+    torch.cuda.synchronize()
+    arena_before = e1.weight_arena.clone()
     e2 = Engine(cfg, max_batch=4, device=cuda_dev, weight_arena=e1.weight_arena)
     e2.finalize(assume_all_loaded=True)
-    img = torch.randn(4, 3, 256, 256, generator=torch.Generator().manual_seed(3)).to(cuda_dev)
-    ref = e1.forward(img)
     torch.cuda.synchronize()
+    assert torch.equal(arena_before, e1.weight_arena), "creating a second engine on a shared arena modified the weights"
+    del arena_before
+    # and the read-outs are not the bias-only values a zeroed read-out matrix would give
+    assert (ref["pred_cam"] - ref["pred_cam"][0]).abs().max() > 0
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     with torch.cuda.stream(s1):
         a = e1.forward(img)

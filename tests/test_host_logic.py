@@ -21,6 +21,15 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert b"gfx950" in built_lib.thmr_build_info()
 
 
+def test_loaded_library_was_built_from_the_current_sources(built_lib):
+    """Stale-binary guard: the library reports the content hash of csrc/ + include/ + compiler flags it was compiled from
+    (thmr_build_info), and that must be the hash of the sources in the tree right now.  (The .so is git-ignored but travels
+    to the GPU box; without this a forgotten rebuild tests yesterday's kernels against today's sources.)"""
+    import __graft_entry__
+    info = built_lib.thmr_build_info().decode()
+    assert f"src:{__graft_entry__.source_hash()}" in info, info
+
+
 def test_library_has_gfx950_code_object(built_lib):
     with open(_cabi.LIB_PATH, "rb") as f:
         blob = f.read()
@@ -233,3 +242,13 @@ def test_gemm_k_loops_carry_no_valu_instruction(built_lib, tmp_path):
         dma = [(op, args) for _, op, args in seg if op.startswith("global_load_lds")]
         assert not valu, (sym, valu[:8])
         assert dma and all(re.search(r"s\[\d+:\d+\]", args) for _, args in dma), (sym, dma[:2])
+        # The M0 assumption of dma16_saddr (gemm_f32.hip): the inline asm writes M0 without being able to declare it, so the
+        # LDS destination of every copy is only right if NOTHING sits between its `s_mov_b32 m0` and the load.  Guard it at the
+        # ISA level: each global_load_lds in the K loop is immediately preceded by `s_mov_b32 m0, sN` + `s_nop` (same basic
+        # block by construction: no branch, label or other M0 writer can be in between), and M0 has no other writer in the loop.
+        for i, (_, op, args) in enumerate(seg):
+            if op.startswith("global_load_lds"):
+                assert i >= 2 and seg[i - 1][1] == "s_nop" and seg[i - 2][1] == "s_mov_b32" and seg[i - 2][2].startswith("m0,"), \
+                    (sym, seg[max(0, i - 3):i + 1])
+        m0_writers = [x for x in seg if re.match(r"m0\b", x[2]) and x[1].startswith("s_")]
+        assert len(m0_writers) == len(dma), (sym, len(m0_writers), len(dma))

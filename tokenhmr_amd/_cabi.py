@@ -30,7 +30,7 @@ class SmplDesc(C.Structure):
     _fields_ = [("v_template", C.c_void_p), ("shapedirs", C.c_void_p), ("posedirs", C.c_void_p),
                 ("J_regressor", C.c_void_p), ("lbs_weights", C.c_void_p), ("J19_regressor", C.c_void_p),
                 ("parents", C.c_void_p), ("extra_verts", C.c_void_p), ("joint_map", C.c_void_p),
-                ("on_device", C.c_int32), ("reserved", C.c_int32)]
+                ("on_device", C.c_int32), ("update_hips", C.c_int32)]
 
 
 OUTPUT_FIELDS = ["pred_cam", "rotmat", "betas", "cls_logits_softmax", "pred_cam_t", "focal_length",

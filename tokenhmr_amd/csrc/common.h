@@ -212,7 +212,7 @@ constexpr int THMR_LBS_KX = 224, THMR_LBS_XF = 224 + 27 * 57;
 int launch_lbs_build_dirs(const float* sd, const float* pd, float* dirsT, hipStream_t s);
 int launch_lbs(const float* rotmat, const float* betas, const float* cam_t, const float* Jt, const float* Jsd,
                const int32_t* parents, const float* vt, const float* dirsT, const float* W, const float* J19,
-               const int32_t* extra, const int32_t* jmap, float* A, float* xf, float* Jtr, float* vposed, float* verts,
+               const int32_t* extra, const int32_t* jmap, const int32_t* update_hips, float* A, float* xf, float* Jtr, float* vposed, float* verts,
                float* joints, float* kp2d, float focal_over_size, int B, hipStream_t s);
 int launch_rodrigues(const float* aa, float* R, int n, hipStream_t s);
 // eval.hip

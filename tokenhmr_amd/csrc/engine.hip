@@ -14,6 +14,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -75,8 +77,10 @@ struct thmr_engine {
     // optional tokenizer ENCODER (EncodeTokens, vanilla_pose_vqvae.py:304-346): 'encoder.encoder.*' tensors
     std::vector<std::string> enc_names;
     std::vector<size_t> enc_convp;   // repacked encoder convs, index by kEnc id
-    size_t o_idx_enc = 0;
+    size_t o_idx_enc = 0, o_flags = 0;
     bool enc_ready = false;
+    int32_t flag_host = 0, hips_host = 0;
+    std::vector<int32_t> idx_host, eidx_host;   // staging for the index tables (must outlive the async copy)
     int vq_len[5] = {160, 125, 90, 55, 21};
     // scratch offsets (floats)
     struct {
@@ -294,6 +298,7 @@ void layout_weights(thmr_engine* e) {
         if (kEnc[i].ks > 1) off = align64(off + (size_t)kEnc[i].co * kEnc[i].cp * kEnc[i].ks);
     }
     e->o_idx_enc = off; off = align64(off + 640);
+    e->o_flags = off;   off = align64(off + 64);     // int32 flag words travelling with the arena (0: encoder present)
     e->wfloats = off;
 }
 
@@ -616,10 +621,37 @@ int lbs(thmr_engine* e, const float* rot, const float* betas, const float* camt,
     if (!verts) verts = e->S(so.verts);
     LAUNCH_OK(launch_lbs(rot, betas, camt, e->warena + e->o_smpl_jt, e->warena + e->o_smpl_jsd, ints,
                          e->warena + e->o_smpl_vt, e->warena + e->o_smpl_dirs, e->warena + e->o_smpl_w,
-                         e->warena + e->o_smpl_j19, ints + 24, ints + 48, e->S(so.A), e->S(so.pf), e->S(so.Jtr),
+                         e->warena + e->o_smpl_j19, ints + 24, ints + 48, ints + 80, e->S(so.A), e->S(so.pf), e->S(so.Jtr),
                          e->S(so.vposed), verts, joints, kp2d, FOCAL / IMG, B, st));
     return 0;
 }
+
+// nn.Upsample nearest index tables of the VQ decoder / tokenizer encoder, evaluated in fp32 exactly like ATen
+// (nearest_neighbor_compute_source_index: min(floor(dst * (float)in / out), in - 1)).  They are part of the weight arena
+// (so a broadcast replicates them) and are written by the engine that LOADED the weights — never by thmr_create, which
+// may be handed another engine's live arena (Engine(weight_arena=...)).
+void build_idx_tables(thmr_engine* e) {
+    e->idx_host.assign(4 * 160, 0);
+    for (int i = 0; i < 4; ++i) {
+        const int tin = e->vq_len[i], tout = e->vq_len[i + 1];
+        const float scale = (float)tin / (float)tout;
+        for (int t = 0; t < tout; ++t) {
+            int sidx = (int)floorf((float)t * scale);
+            e->idx_host[i * 160 + t] = sidx < tin - 1 ? sidx : tin - 1;
+        }
+    }
+    // encoder: nn.Upsample(size=40) from 21 (offset 0), then three nn.Upsample(scale_factor=2)
+    // (ATen uses scale 1/scale_factor = 0.5: src = floor(dst*0.5)): 40->80 (offset 40), 80->160 (120), 160->320 (280)
+    e->eidx_host.assign(640, 0);
+    const float sc = 21.0f / 40.0f;
+    for (int t = 0; t < 40; ++t) { int s0 = (int)floorf((float)t * sc); e->eidx_host[t] = s0 < 20 ? s0 : 20; }
+    int o = 40;
+    for (int tin = 40; tin <= 160; tin *= 2) {
+        for (int t = 0; t < 2 * tin; ++t) { int s0 = (int)floorf((float)t * 0.5f); e->eidx_host[o + t] = s0 < tin - 1 ? s0 : tin - 1; }
+        o += 2 * tin;
+    }
+}
+constexpr int32_t kEncMagic = 0x454e4331;   // 'ENC1': arena flag word 0 = "tokenizer encoder tensors present + repacked"
 
 int check_ready(thmr_engine* e, int B) {
     if (!e) return fail(nullptr, THMR_ERR_INVALID, "null engine");
@@ -634,7 +666,10 @@ int check_ready(thmr_engine* e, int B) {
 extern "C" {
 
 int thmr_abi_version(void) { return THMR_ABI_VERSION; }
-const char* thmr_build_info(void) { return "tokenhmr_hip gfx950 fp32-mfma " __DATE__ " " __TIME__; }
+#ifndef THMR_SRC_HASH
+#define THMR_SRC_HASH "unhashed"      // __graft_entry__.build() passes the content hash of csrc/ + include/ + flags
+#endif
+const char* thmr_build_info(void) { return "tokenhmr_hip gfx950 fp32-mfma src:" THMR_SRC_HASH " " __DATE__ " " __TIME__; }
 
 const char* thmr_last_error(const thmr_engine* e) { return e ? e->err.c_str() : g_last_error.c_str(); }
 
@@ -691,35 +726,6 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
         if (hipMalloc(&e->sarena, e->sfloats * sizeof(float)) != hipSuccess) return bail(THMR_ERR_NOMEM, "hipMalloc(scratch) failed");
         e->own_s = true;
     }
-    // nn.Upsample(size) nearest index tables, evaluated in fp32 exactly like ATen
-    // (nearest_neighbor_compute_source_index: min(floor(dst * (float)in / out), in - 1))
-    std::vector<int32_t> idx(4 * 160, 0);
-    for (int i = 0; i < 4; ++i) {
-        const int tin = e->vq_len[i], tout = e->vq_len[i + 1];
-        const float scale = (float)tin / (float)tout;
-        for (int t = 0; t < tout; ++t) {
-            int sidx = (int)floorf((float)t * scale);
-            idx[i * 160 + t] = sidx < tin - 1 ? sidx : tin - 1;
-        }
-    }
-    if (hipMemcpy(e->warena + e->o_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
-        return bail(THMR_ERR_HIP, "hipMemcpy(idx tables) failed");
-    // encoder resample tables: nn.Upsample(size=40) from 21 (offset 0), then three nn.Upsample(scale_factor=2)
-    // (ATen uses scale 1/scale_factor = 0.5: src = floor(dst*0.5)): 40->80 (offset 40), 80->160 (120), 160->320 (280)
-    std::vector<int32_t> eidx(640, 0);
-    {
-        const float sc = 21.0f / 40.0f;
-        for (int t = 0; t < 40; ++t) { int s0 = (int)floorf((float)t * sc); eidx[t] = s0 < 20 ? s0 : 20; }
-        int o = 40;
-        for (int tin = 40; tin <= 160; tin *= 2) {
-            for (int t = 0; t < 2 * tin; ++t) { int s0 = (int)floorf((float)t * 0.5f); eidx[o + t] = s0 < tin - 1 ? s0 : tin - 1; }
-            o += 2 * tin;
-        }
-    }
-    if (hipMemcpy(e->warena + e->o_idx_enc, eidx.data(), eidx.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
-        return bail(THMR_ERR_HIP, "hipMemcpy(encoder idx tables) failed");
-    // the padding row of the read-out matrix must be finite
-    if (hipMemset(e->warena + e->o_ro_w, 0, 32 * E * sizeof(float)) != hipSuccess) return bail(THMR_ERR_HIP, "hipMemset failed");
     *out = e;
     return 0;
 }
@@ -767,6 +773,8 @@ int thmr_load_smpl(thmr_engine* e, const thmr_smpl_desc* s, void* stream) {
     HIP_OK(hipMemcpyAsync(ints, s->parents, sizeof(int32_t) * 24, k, st));
     HIP_OK(hipMemcpyAsync(ints + 24, s->extra_verts, sizeof(int32_t) * 21, k, st));
     HIP_OK(hipMemcpyAsync(ints + 48, s->joint_map, sizeof(int32_t) * 25, k, st));
+    e->hips_host = s->update_hips ? 1 : 0;      // SMPL(update_hips=...), smpl_wrapper.py:11,33-36; lives in the arena (ints[80])
+    HIP_OK(hipMemcpyAsync(ints + 80, &e->hips_host, sizeof(int32_t), hipMemcpyHostToDevice, st));
     e->smpl_loaded = true;
     e->finalized = false;
     return 0;
@@ -780,6 +788,13 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
             if (!e->slots[n].loaded) return fail(e, THMR_ERR_STATE, "missing tensor '" + n + "' (strict load)");
         if (!e->smpl_loaded) return fail(e, THMR_ERR_STATE, "SMPL constants not loaded (thmr_load_smpl)");
     }
+    if (!assume_all_loaded) {
+        // regions of the arena that are not checkpoint tensors: index tables, the (finite) padding row of the read-out matrix
+        build_idx_tables(e);
+        HIP_OK(hipMemcpyAsync(e->warena + e->o_idx, e->idx_host.data(), e->idx_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(e->warena + e->o_idx_enc, e->eidx_host.data(), e->eidx_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemsetAsync(e->warena + e->o_ro_w + (size_t)31 * E, 0, E * sizeof(float), st));
+    }
     for (int i = 0; i < 9; ++i)
         LAUNCH_OK(launch_conv_repack(e->W(std::string(kConv3[i]) + ".weight"), e->warena + e->convp[i], kConv3Co[i], kConv3Ci[i], 3, st));
     LAUNCH_OK(launch_transpose(e->W("quantizer.codebook"), e->warena + e->o_cbT, 1, NCLS, CODE, st));
@@ -787,13 +802,24 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
     LAUNCH_OK(launch_lbs_jreg(e->warena + e->o_smpl_jr, e->warena + e->o_smpl_vt, e->warena + e->o_smpl_sd,
                               e->warena + e->o_smpl_jt, e->warena + e->o_smpl_jsd, st));
     LAUNCH_OK(launch_lbs_build_dirs(e->warena + e->o_smpl_sd, e->warena + e->o_smpl_pd, e->warena + e->o_smpl_dirs, st));
-    // optional encoder: ready only when every 'encoder.encoder.*' tensor arrived (all-or-nothing)
-    size_t enc_loaded = 0;
-    for (auto& n : e->enc_names) enc_loaded += e->slots[n].loaded ? 1 : 0;
-    if (enc_loaded != 0 && enc_loaded != e->enc_names.size())
-        return fail(e, THMR_ERR_STATE, "tokenizer encoder partially loaded: " + std::to_string(enc_loaded) + " of " +
-                                           std::to_string(e->enc_names.size()) + " tensors");
-    e->enc_ready = enc_loaded == e->enc_names.size();
+    // optional encoder: ready only when every 'encoder.encoder.*' tensor arrived (all-or-nothing).  The fact travels with
+    // the arena as a flag word, so an engine that received the arena by broadcast (or shares it) can encode too.
+    int32_t* flags = reinterpret_cast<int32_t*>(e->warena + e->o_flags);
+    if (!assume_all_loaded) {
+        size_t enc_loaded = 0;
+        for (auto& n : e->enc_names) enc_loaded += e->slots[n].loaded ? 1 : 0;
+        if (enc_loaded != 0 && enc_loaded != e->enc_names.size())
+            return fail(e, THMR_ERR_STATE, "tokenizer encoder partially loaded: " + std::to_string(enc_loaded) + " of " +
+                                               std::to_string(e->enc_names.size()) + " tensors");
+        e->enc_ready = enc_loaded == e->enc_names.size();
+        e->flag_host = e->enc_ready ? kEncMagic : 0;
+        HIP_OK(hipMemcpyAsync(flags, &e->flag_host, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    } else {
+        int32_t f = 0;
+        HIP_OK(hipMemcpyAsync(&f, flags, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        e->enc_ready = f == kEncMagic;
+    }
     if (e->enc_ready)
         for (int i = 0; i < kEncN; ++i)
             if (kEnc[i].ks > 1)
@@ -965,18 +991,28 @@ int thmr_op_gemm(const float* A, int64_t lda, const float* W, const float* bias,
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (variant >= 100 && variant < 120) {
         // small-M ring kernel: 100 + 10*(ring == 8) + log2(ksplit).  The stateless entry point keeps a grow-only partial-sum
-        // workspace per process (the engine uses its own scratch arena instead).
+        // workspace per device and stream (the engine uses its own scratch arena instead).
         const int ring = variant >= 110 ? 8 : 4, ksplit = 1 << (variant % 10);
-        static float* ws = nullptr;
-        static size_t ws_floats = 0;
         if (epi == EPI_BIAS_POS) return fail(e, THMR_ERR_INVALID, "ring GEMM has no pos-embed epilogue");
+        float* ws = nullptr;
+        static std::mutex mu;
+        std::unique_lock<std::mutex> lk(mu, std::defer_lock);   // held across the launches that use the workspace
         if (ksplit > 1) {
+            // grow-only workspace per (DEVICE, STREAM) — launches on one stream are ordered, so they may share a buffer;
+            // different streams never do — guarded by a mutex; the device is synchronised before a buffer is replaced
+            static std::map<std::pair<int, void*>, std::pair<float*, size_t>> pool;
+            int dev = 0;
+            HIP_OK(hipGetDevice(&dev));
+            lk.lock();
+            auto& slot = pool[{dev, stream}];
             const size_t need = (size_t)ksplit * M * N;
-            if (need > ws_floats) {
-                if (ws) { HIP_OK(hipStreamSynchronize(st)); HIP_OK(hipFree(ws)); ws = nullptr; ws_floats = 0; }
-                HIP_OK(hipMalloc(&ws, need * sizeof(float)));
-                ws_floats = need;
+            if (need > slot.second) {
+                if (slot.first) { HIP_OK(hipDeviceSynchronize()); HIP_OK(hipFree(slot.first)); slot = {nullptr, 0}; }
+                float* p = nullptr;
+                HIP_OK(hipMalloc(&p, need * sizeof(float)));
+                slot = {p, need};
             }
+            ws = slot.first;
         }
         LAUNCH_OK(launch_gemm_ring(a, epi, ring, ksplit, ws, st));
         if (ksplit > 1) LAUNCH_OK(launch_splitk_epilogue(a, epi, ws, ksplit, st));
@@ -1054,6 +1090,8 @@ int thmr_smpl_create(const thmr_smpl_desc* d, int32_t max_batch, int32_t device,
               hipMemcpy(ints, d->parents, sizeof(int32_t) * 24, k) == hipSuccess &&
               hipMemcpy(ints + 24, d->extra_verts, sizeof(int32_t) * 21, k) == hipSuccess &&
               hipMemcpy(ints + 48, d->joint_map, sizeof(int32_t) * 25, k) == hipSuccess;
+    const int32_t hips = d->update_hips ? 1 : 0;
+    ok = ok && hipMemcpy(ints + 80, &hips, sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok || launch_lbs_jreg(m->mem + m->o_jr, m->mem + m->o_vt, m->mem + m->o_sd, m->mem + m->o_jt, m->mem + m->o_jsd, nullptr) != 0 ||
         launch_lbs_build_dirs(m->mem + m->o_sd, m->mem + m->o_pd, m->mem + m->o_dirs, nullptr) != 0 ||
         hipDeviceSynchronize() != hipSuccess) {
@@ -1083,7 +1121,7 @@ int thmr_smpl_forward(thmr_smpl* m, const float* pose, int32_t pose2rot, const f
     }
     const int32_t* ints = reinterpret_cast<const int32_t*>(m->mem + m->o_int);
     LAUNCH_OK(launch_lbs(rot, betas, nullptr, m->mem + m->o_jt, m->mem + m->o_jsd, ints, m->mem + m->o_vt, m->mem + m->o_dirs,
-                         m->mem + m->o_w, m->mem + m->o_j19, ints + 24, ints + 48, m->mem + m->o_A, m->mem + m->o_pf,
+                         m->mem + m->o_w, m->mem + m->o_j19, ints + 24, ints + 48, ints + 80, m->mem + m->o_A, m->mem + m->o_pf,
                          m->mem + m->o_Jtr, m->mem + m->o_vposed, verts, joints ? joints : m->mem + m->o_joints, nullptr,
                          FOCAL / IMG, B, st));
     return 0;

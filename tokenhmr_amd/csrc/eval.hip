@@ -100,14 +100,19 @@ __global__ __launch_bounds__(64) void eval_pose_kernel(const float* __restrict__
     if (pelv_out && t < 6) pelv_out[b * 6 + t] = pelv[t / 3][t % 3];
     float err = 0.f;
     if (t < nkp) {
-        const int j = kp[t];
+        int j = kp[t];
+        // an index outside [0, nj) never reads out of bounds: the crop's metrics become NaN instead (the host binding
+        // rejects such lists up front, like the reference's IndexError)
+        const bool bad = j < 0 || j >= nj;
+        if (bad) j = 0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             P[t][i] = pb[j * 3 + i] - pelv[0][i];
             Gt[t][i] = gb[j * gt_stride + i] - pelv[1][i];
         }
         const float dx = P[t][0] - Gt[t][0], dy = P[t][1] - Gt[t][1], dz = P[t][2] - Gt[t][2];
-        err = sqrtf(dx * dx + dy * dy + dz * dz);
+        err = bad ? __builtin_nanf("") : sqrtf(dx * dx + dy * dy + dz * dz);
+        if (bad) P[t][0] = __builtin_nanf("");
     }
     const float s = wave_sum(err);
     if (t == 0) mpjpe[b] = 1000.0f * (s / (float)nkp);

@@ -165,9 +165,10 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__
 // ---- joints: 24 chain joints + 21 vertex picks -> joint_map(25) ++ J19 regressor(19) = 44, + projection ----
 __global__ __launch_bounds__(256) void lbs_joints_kernel(const float* __restrict__ verts, const float* __restrict__ Jtr,
                                                          const float* __restrict__ jpart, const int32_t* __restrict__ extra,
-                                                         const int32_t* __restrict__ jmap, const float* __restrict__ cam_t,
-                                                         float* __restrict__ joints, float* __restrict__ kp2d,
-                                                         float focal_over_size) {
+                                                         const int32_t* __restrict__ jmap,
+                                                         const int32_t* __restrict__ update_hips,
+                                                         const float* __restrict__ cam_t, float* __restrict__ joints,
+                                                         float* __restrict__ kp2d, float focal_over_size) {
     __shared__ float jo[44][3];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* vb = verts + (int64_t)b * NV * 3;
@@ -180,6 +181,14 @@ __global__ __launch_bounds__(256) void lbs_joints_kernel(const float* __restrict
         const int t = tid - 64, j = t / 3, i = t % 3;
         const int src = jmap[j];
         jo[j][i] = (src < NJ) ? Jtr[((int64_t)b * NJ + src) * 3 + i] : vb[extra[src - NJ] * 3 + i];
+    }
+    __syncthreads();
+    // SMPL(update_hips=True), smpl_wrapper.py:33-36, on the 25 mapped joints (before the extra joints are appended):
+    //   j[9,12] = (j[9,12] + 0.25*(j[9,12] - j[12,9])) + 0.5*(j[8] - 0.5*(j[9,12] + j[12,9]))
+    if (*update_hips && tid < 3) {
+        const float a = jo[9][tid], c = jo[12][tid], m = jo[8][tid];
+        jo[9][tid] = (a + 0.25f * (a - c)) + 0.5f * (m - 0.5f * (a + c));
+        jo[12][tid] = (c + 0.25f * (c - a)) + 0.5f * (m - 0.5f * (c + a));
     }
     __syncthreads();
     if (tid < 132 && joints) joints[(int64_t)b * 132 + tid] = jo[tid / 3][tid % 3];
@@ -231,7 +240,8 @@ int launch_lbs_build_dirs(const float* sd, const float* pd, float* dirsT, hipStr
 // scratch: A (B,24,12), xf (B, 224 + 27*57) [operand rows, then J19 partial sums], Jtr (B,24,3), vposed (B,20670)
 int launch_lbs(const float* rotmat, const float* betas, const float* cam_t, const float* Jt, const float* Jsd,
                const int32_t* parents, const float* vt, const float* dirsT, const float* W, const float* J19,
-               const int32_t* extra, const int32_t* jmap, float* A, float* xf, float* Jtr, float* vposed, float* verts,
+               const int32_t* extra, const int32_t* jmap, const int32_t* update_hips, float* A, float* xf, float* Jtr,
+               float* vposed, float* verts,
                float* joints, float* kp2d, float focal_over_size, int B, hipStream_t s) {
     hipLaunchKernelGGL(lbs_prep_kernel, dim3(B), dim3(128), 0, s, rotmat, betas, Jt, Jsd, parents, A, xf, Jtr);
     GemmArgs g{};
@@ -241,7 +251,7 @@ int launch_lbs(const float* rotmat, const float* betas, const float* cam_t, cons
     // the J19 partial sums live behind the (B,224) operand rows in the xf scratch: B * 27 * 57 floats
     float* jpart = xf + (size_t)B * KX;
     hipLaunchKernelGGL(lbs_skin_kernel, dim3(SKB, B), dim3(256), 0, s, vposed, W, A, J19, verts, jpart);
-    hipLaunchKernelGGL(lbs_joints_kernel, dim3(B), dim3(256), 0, s, verts, Jtr, jpart, extra, jmap, cam_t, joints, kp2d,
+    hipLaunchKernelGGL(lbs_joints_kernel, dim3(B), dim3(256), 0, s, verts, Jtr, jpart, extra, jmap, update_hips, cam_t, joints, kp2d,
                        focal_over_size);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -117,8 +117,12 @@ class ShardedRunner:
     def __call__(self, img_global):
         total = img_global.shape[0]
         s, e = self.local_slice(total)
-        o = self.forward_fn(img_global[s:e])
-        rec = pack_records(o)
+        if e > s:
+            rec = pack_records(self.forward_fn(img_global[s:e]))
+        else:
+            # fewer crops than ranks (e.g. 3 detections in a frame on 8 GPUs): this rank has nothing to run — the engine
+            # rejects B < 1 — but it must still enter the collective, with a zero-row record block
+            rec = torch.zeros(0, RECORD_WORDS, dtype=torch.float32, device=img_global.device)
         if not self.gather:
             return unpack_records(rec)
         return unpack_records(all_gather_records(rec, total))

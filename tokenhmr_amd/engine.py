@@ -108,7 +108,9 @@ class Engine:
         for k, s in shapes.items():
             if tuple(ts[k].shape) != s:
                 raise ValueError(f"SMPL '{k}': expected {s}, got {tuple(ts[k].shape)}")
-        d = _cabi.SmplDesc(**{k: ts[k].data_ptr() for k in keys + ikeys}, on_device=0)
+        # SMPL(update_hips=...) of the reference wrapper (smpl_wrapper.py:11,33-36); absent = False like its default
+        d = _cabi.SmplDesc(**{k: ts[k].data_ptr() for k in keys + ikeys}, on_device=0,
+                           update_hips=1 if smpl.get("update_hips", False) else 0)
         with torch.cuda.device(self.device):
             _cabi.check(self.lib.thmr_load_smpl(self.h, C.byref(d), _stream_ptr(self.device)), self.h)
             torch.cuda.current_stream(self.device).synchronize()

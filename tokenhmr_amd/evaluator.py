@@ -27,7 +27,13 @@ def eval_pose_gpu(pred_joints, gt_joints, keypoint_list, pelvis_ind, pelvis_mode
     B, nj = pj.shape[0], pj.shape[1]
     if gj.shape[:2] != (B, nj) or pj.shape[2] != 3 or gj.shape[2] not in (3, 4):
         raise ValueError(f"bad joint shapes {tuple(pj.shape)} / {tuple(gj.shape)}")
-    kp = torch.as_tensor(list(keypoint_list), dtype=torch.int32, device=dev)
+    kpl = [int(k) for k in keypoint_list]
+    if not kpl or min(kpl) < 0 or max(kpl) >= nj:
+        # the reference indexes pred[:, keypoint_list] and raises here (pose_utils.py:225-226); the kernel must never read past nj
+        raise IndexError(f"keypoint_list indices must lie in [0, {nj}) for {nj}-joint inputs, got min {min(kpl, default=None)} max {max(kpl, default=None)}")
+    if not 0 <= int(pelvis_ind) < nj:
+        raise IndexError(f"pelvis_ind {pelvis_ind} outside [0, {nj})")
+    kp = torch.as_tensor(kpl, dtype=torch.int32, device=dev)
     mp = torch.empty(B, device=dev, dtype=torch.float32)
     re = torch.empty(B, device=dev, dtype=torch.float32)
     pelv = torch.empty(B, 6, device=dev, dtype=torch.float32)

@@ -171,5 +171,7 @@ def load_tokenhmr(checkpoint_path="", model_cfg="", dataset_dir="", is_train_sta
     state.setdefault("smpl_head.init_cam", torch.from_numpy(mean["cam"].astype("float32")).unsqueeze(0))
     gender = str(getattr(cfg.SMPL, "GENDER", "neutral")).upper()
     smpl = load_smpl_pkl(os.path.join(cfg.SMPL.MODEL_PATH, f"SMPL_{gender}.pkl"), cfg.SMPL.JOINT_REGRESSOR_EXTRA, hcfg)
+    # tokenhmr.py:84-85 passes every cfg.SMPL key (lower-cased) to SMPL(...): update_hips is one of its keyword arguments
+    smpl["update_hips"] = bool(getattr(cfg.SMPL, "UPDATE_HIPS", getattr(cfg.SMPL, "update_hips", False)))
     model = TokenHMR.from_state(hcfg, state, tok, smpl, max_batch=max_batch, device=device, model_cfg=cfg)
     return model, cfg

@@ -76,9 +76,12 @@ class Cropper:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("Cropper needs a GPU device: the crop kernels have no CPU fallback")
+        # 'cuda' without an index means the CURRENT device (like Engine), not device 0
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
         self.lib = _cabi.load()
         h = C.c_void_p()
-        rc = self.lib.thmr_cropper_create(self.device.index or 0, C.byref(h))
+        rc = self.lib.thmr_cropper_create(idx, C.byref(h))
         if rc != 0:
             raise _cabi.EngineError(f"thmr_cropper_create: {self.lib.thmr_cropper_last_error(None).decode()}")
         self.h = h

@@ -30,7 +30,8 @@ class SMPL:
         ikeys = ["parents", "extra_verts", "joint_map"]
         ts = {k: constants[k].detach().float().contiguous().cpu() for k in keys}
         ts.update({k: constants[k].detach().to(torch.int32).contiguous().cpu() for k in ikeys})
-        d = _cabi.SmplDesc(**{k: ts[k].data_ptr() for k in keys + ikeys}, on_device=0)
+        d = _cabi.SmplDesc(**{k: ts[k].data_ptr() for k in keys + ikeys}, on_device=0,
+                           update_hips=1 if constants.get("update_hips", False) else 0)
         h = C.c_void_p(0)
         _cabi.check(self.lib.thmr_smpl_create(C.byref(d), self.max_batch, idx, C.byref(h)))
         self.h = h
