@@ -139,6 +139,15 @@ int thmr_weight_arena(thmr_engine* e, void** ptr_dev, size_t* bytes);
  * img_dev: (B,3,256,256) fp32 normalised RGB crops.  1 <= B <= max_batch. */
 int thmr_forward(thmr_engine* e, const float* img_dev, int32_t B, const thmr_outputs* out, void* stream);
 
+/* Device-side health of the engine: synchronises `stream` and returns THMR_ERR_HIP if a kernel of this engine reported an
+ * error asynchronously (today: the bounded grid barrier of the persistent decoder kernel timed out instead of hanging the GPU).
+ * thmr_forward itself never synchronises, so callers check this at their own sync points (tests and bench.py do). */
+int thmr_engine_status(thmr_engine* e, void* stream);
+
+/* Diagnostics: with THMR_DEC_TIMELINE=1 in the environment at thmr_finalize_weights, workgroup 0 of the persistent decoder kernel
+ * stamps the 100 MHz wall clock after every step and barrier of the last call; this copies up to max_stamps (<= 240) of them. */
+int thmr_debug_decoder_timeline(thmr_engine* e, uint64_t* stamps_host, int32_t max_stamps, void* stream);
+
 /* Sub-paths (configs 2 of BASELINE.json and unit parity). */
 int thmr_vit_forward(thmr_engine* e, const float* img_dev, int32_t B, float* feats_dev /*(B,192,1280)*/, void* stream);
 int thmr_head_forward(thmr_engine* e, const float* ctx_dev /*(B,192,1280)*/, int32_t B, const thmr_outputs* out, void* stream);

@@ -73,6 +73,7 @@ def test_small_vs_oracle(small):
     cfg, sd, tok, smpl, model = small
     img = _inputs(2)
     out = model({"img": img.to(model.engine.device)})
+    model.engine.status()           # no asynchronous device-side error (bounded grid barrier of the persistent decoder kernel)
     with torch.no_grad():
         orc = O.forward(img, sd, tok, smpl, cfg)
     outc = _to_cpu(out)
@@ -194,6 +195,7 @@ def test_b64_tokens_vs_reference_golden(built_lib, cuda_dev):
     assert abs(float(img.double().sum()) - g["img_checksum"][0]) < 1e-6
     model = TokenHMR.from_state(RELEASE, sd, tok, smpl, max_batch=64, device=cuda_dev)
     out = _to_cpu(model({"img": img.to(cuda_dev)}))
+    model.engine.status()
     idx, ref, gap = out["token_idx"].numpy(), g["token_idx"], g["top2_gap"]
     mism = idx != ref
     n_mis, n_safe_mis = int(mism.sum()), int((mism & (gap > 1e-3)).sum())

@@ -169,3 +169,53 @@ def test_run_eval_loop_matches_manual_loop(built_lib, cuda_dev):
         assert a[k] == m[k], (k, a[k], m[k])                      # same batches -> same bits
         assert abs(b[k] - m[k]) < 1e-3, (k, b[k], m[k])           # other batching: mm-scale metrics agree to 1e-3 mm
     assert np.isfinite(list(m.values())).all() and m["mode_mpjpe"] > 0
+
+
+def test_head_regimes_agree_and_persistent_decoders_coexist(built_lib, cuda_dev):
+    """The head has two regimes (csrc/engine.hip kFusedHeadMaxB): up to 128 crops the persistent decoder kernel + the
+    one-workgroup-per-crop mixer kernel, above it the chain of tiled GEMMs.  (1) Both must agree with the CPU oracle, and a crop
+    must get the same answer (to fp32 summation-order differences) whichever regime its batch falls in.  (2) Two engines that
+    launch their persistent decoder kernels concurrently on two streams at a batch size where EACH asks for every CU (>= 49
+    crops) must both finish (the per-device turnstile chains them) with bit-identical results and no barrier timeout."""
+    from oracle import tokenhmr_oracle as O
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd import weights as W
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    from tokenhmr_amd.engine import Engine
+    cfg = HMRConfig(vit_depth=1, dec_depth=6)
+    sd, tok, smpl = W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0), make_synthetic_smpl(cfg, 0)
+    e1 = Engine(cfg, max_batch=136, device=cuda_dev)
+    e1.load_state(sd, tok)
+    e1.load_smpl(smpl)
+    e1.finalize()
+    img = torch.randn(136, 3, 256, 256, generator=torch.Generator().manual_seed(11))
+    d = img.to(cuda_dev)
+    big = {k: v.clone() for k, v in e1.forward(d, taps=True).items()}            # 136 crops: chain-of-GEMMs regime
+    small = {k: v.clone() for k, v in e1.forward(d[:64], taps=True).items()}     # 64 crops: fused regime
+    e1.status()
+    with torch.no_grad():
+        orc = O.forward(img[:4], sd, tok, smpl, cfg)
+    for o, tag in ((big, "chain"), (small, "fused")):
+        assert (o["token_out"][:4].cpu() - orc["token_out"]).abs().max() < 1e-3, tag
+        assert (o["cls_logits"][:4].cpu() - orc["cls_logits"]).abs().max() < 1e-3, tag
+        assert (o["pred_vertices"][:4].cpu() - orc["pred_vertices"]).abs().max() < 1e-4, tag
+    assert (big["pred_vertices"][:64] - small["pred_vertices"]).abs().max() < 1e-4
+    assert (big["cls_logits_softmax"][:64] - small["cls_logits_softmax"]).abs().max() < 1e-5
+    # (2) two engines, two streams, 64 crops each -> two 256-workgroup persistent kernels in flight
+    e2 = Engine(cfg, max_batch=64, device=cuda_dev, weight_arena=e1.weight_arena)
+    e2.finalize(assume_all_loaded=True)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            a = e1.forward(d[:64])
+        with torch.cuda.stream(s2):
+            b = e2.forward(d[:64])
+        outs.append((a, b))
+    torch.cuda.synchronize()
+    e1.status()
+    e2.status()
+    for a, b in outs:
+        for k in ("pred_vertices", "token_idx", "pred_cam"):
+            assert torch.equal(a[k], small[k]) and torch.equal(b[k], small[k]), k

@@ -88,6 +88,8 @@ def load():
     lib.thmr_finalize_weights.argtypes = [vp, i32, vp]
     lib.thmr_weight_arena.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     lib.thmr_forward.argtypes = [vp, vp, i32, C.POINTER(Outputs), vp]
+    lib.thmr_engine_status.argtypes = [vp, vp]
+    lib.thmr_debug_decoder_timeline.argtypes = [vp, C.POINTER(C.c_uint64), i32, vp]
     lib.thmr_vit_forward.argtypes = [vp, vp, i32, vp, vp]
     lib.thmr_head_forward.argtypes = [vp, vp, i32, C.POINTER(Outputs), vp]
     lib.thmr_lbs_forward.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]

@@ -6,7 +6,7 @@
 // QKV GEMM epilogue (vit.py:116).  Output (B,192,1280) with column h*80+d (vit.py:122 transpose+reshape).
 //
 // gfx950 design: one 256-thread workgroup per (b,h), TWO workgroups per CU.  K and V of the head time-share ONE 66 KB LDS
-// buffer, split into two 96-key halves that are staged by LDS-DMA (global_load_lds: no VGPR round trip, no ds_write) and
+// buffer, split into two 96-key halves that are staged by LDS-DMA (global_load_lds, saddr form: no VGPR round trip, no ds_write, no per-copy VALU) and
 // software-pipelined against the matrix work inside the workgroup:
 //     DMA K[0:96], K[96:192] | S(keys 0..95) | DMA V[0:96] over the dead K half | S(keys 96..191) | DMA V[96:192] |
 //     softmax | P.V(keys 0..95) | P.V(keys 96..191) | store
@@ -19,13 +19,15 @@
 //   S^T = K Q^T  with v_mfma_f32_16x16x4_f32 (A = K rows from LDS via ds_read_b128 + the k-permutation
 //                trick, B = Q fragments held in registers).  The swapped product leaves every query's
 //                192 scores in 4 lanes x 48 registers, so row max/sum are 47 in-lane ops + 2 xor-shuffles.
-//   P = softmax  fp32; exp(x) = v_exp_f32(x * log2 e) (1 ulp) and one reciprocal per row.
+//   P = softmax  fp32; e = v_exp_f32(fma(s, log2 e, -m log2 e)), un-normalised into P.V, one reciprocal per row applied to the outputs.
 //   O^T = V^T P^T  P registers are directly the MFMA B operand (lane group g <-> key 16*kt + 4g + r); V rows come
 //                from LDS with conflict-free ds_read_b32 (row stride 84); each lane ends with 4 consecutive d of one
 //                query, so the output goes out as 16-byte stores.
 // d = 80 = 5 tiles of 16 and 80 = 20 k-steps of 4: the 16x16x4 shape wastes no MFMA work.
 // LDS rows: K stride 88 floats = 22 DMA slots of 16 B (20 data + 2 pad), V stride 84 floats = 21 slots (20 + 1): a wave's DMA
 // instruction fills 64 consecutive slots, i.e. lane l of instruction q carries slot 64q + l = (row, column) by division.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -40,18 +42,40 @@ typedef __attribute__((address_space(1))) const void gbl_void;
 
 // Stage 96 rows x 80 floats (row stride QKV_LD in global memory) into LDS rows of SLOTS*4 floats.  Wave w issues the DMA
 // instructions q = w, w+4, ...: at most (NI+3)/4 each; K halves take 33 instructions (wave 0 issues 9, the others 8), V halves 32.
-template <int SLOTS>
-__device__ __forceinline__ void dma_half(const float* __restrict__ src, float* lds, int wave, int lane) {
-    constexpr int NSLOT = HALF * SLOTS, NI = (NSLOT + 63) / 64;
+// The per-lane source offset of instruction i ((row, column) of LDS slot 64 q + lane, a division by the slots of a padded row)
+// is the same for both halves of K (and of V), so it is computed ONCE into dma_offsets and every copy is then the saddr form of
+// global_load_lds_dwordx4: {wave-uniform 64-bit base, SALU} + {that 32-bit offset} — zero VALU instructions per copy.  The first
+// version recomputed (row, column) and a 64-bit address for each of the 34 copies: 13 VALU instructions each, a third of the
+// kernel's non-MFMA vector work, and on gfx950 VALU time is matrix-pipe time (profiles/r1_mfma_valu_microbench.log).
+template <int SLOTS, int NW>
+struct DmaOff {
+    static constexpr int NSLOT = HALF * SLOTS, NI = (NSLOT + 63) / 64, PER = (NI + NW - 1) / NW;
+    static constexpr int MINPER = NI / NW;       // every wave has at least this many copies of a half in flight
+    uint32_t off[PER];
+};
+template <int SLOTS, int NW>
+__device__ __forceinline__ DmaOff<SLOTS, NW> dma_offsets(int wave, int lane) {
+    DmaOff<SLOTS, NW> d;
 #pragma unroll
-    for (int i = 0; i < (NI + 3) / 4; ++i) {
-        const int q = i * 4 + wave;                  // wave-uniform
-        if (q < NI) {
-            const int sl = q * 64 + lane, row = sl / SLOTS, c = sl - row * SLOTS;
-            if (sl < NSLOT)                          // pad slots re-fetch column 0 (never read)
-                __builtin_amdgcn_global_load_lds((gbl_void*)(src + (int64_t)row * QKV_LD + (c < HD / 4 ? c : 0) * 4),
-                                                 (lds_void*)(lds + q * 256), 16, 0, 0);
-        }
+    for (int i = 0; i < DmaOff<SLOTS, NW>::PER; ++i) {
+        const int sl = min((i * NW + wave) * 64 + lane, DmaOff<SLOTS, NW>::NSLOT - 1);   // past-the-end slots re-fetch the last one
+        const int row = sl / SLOTS, c = sl - row * SLOTS;
+        d.off[i] = ((uint32_t)row * (uint32_t)QKV_LD + (uint32_t)(c < HD / 4 ? c : 0) * 4u) * 4u;   // pad slots re-fetch column 0 (never read)
+    }
+    return d;
+}
+// M0 is written inside the asm (it cannot be declared as a clobber); this file uses no LDS-DMA builtin and nothing else that
+// reads M0, and the copies are invisible to the compiler's vmcnt bookkeeping: every consumer waits with wait_vm_barrier<N>().
+__device__ __forceinline__ void dma16_saddr(const float* base, uint32_t voff, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_base) : "memory");
+}
+template <int SLOTS, int NW>
+__device__ __forceinline__ void dma_half(const float* __restrict__ src, float* lds, int wave, const DmaOff<SLOTS, NW>& d) {
+    const uint32_t l0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)lds;
+#pragma unroll
+    for (int i = 0; i < DmaOff<SLOTS, NW>::PER; ++i) {
+        const int q = i * NW + wave;                 // wave-uniform
+        if (q < DmaOff<SLOTS, NW>::NI) dma16_saddr(src, d.off[i], l0 + (uint32_t)q * 1024u);
     }
 }
 
@@ -61,12 +85,16 @@ __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-// QT = 16-query tiles per wave: 3 -> one workgroup covers all 192 queries of a (crop, head) (batched path); 1 -> three
-// workgroups of 64 queries each, all staging the same K / V (few crops: B*16 workgroups cannot occupy 256 CUs).  Every query
-// is computed by the same instruction sequence either way, so the two variants are bit-identical.
-template <int QT>
-__global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out) {
-    constexpr int QB = 3 / QT;      // query blocks per (crop, head)
+// QT = 16-query tiles per wave, NW = waves per workgroup.  (3, 4): one 256-thread workgroup covers all 192 queries of a
+// (crop, head) (batched path); (1, 4): three workgroups of 64 queries each, all staging the same K / V (few crops: B*16
+// workgroups cannot occupy 256 CUs); (1, 12): one 768-thread workgroup, 12 waves of 16 queries, K / V staged once.  Every query
+// is computed by the same instruction sequence in all of them, so the variants are bit-identical.
+template <int QT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 2) void vit_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out) {
+    constexpr int QB = 12 / (QT * NW);      // query blocks per (crop, head)
+    static_assert(QB * QT * NW == 12, "192 queries = QB workgroups x NW waves x QT tiles of 16");
+    typedef DmaOff<KS / 4, NW> KOff;
+    typedef DmaOff<VS / 4, NW> VOff;
     __shared__ __attribute__((aligned(16))) float smem[NTOK * KS];   // K halves, later overwritten by the V halves
     const int bh = blockIdx.x / QB, qb = blockIdx.x - bh * QB;
     const int b = bh / NH, h = bh % NH;
@@ -77,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
 
     // ---- Q fragments first (oldest VMEM operations of the wave): B operand of S^T = K Q^T.  B[kslot g][j = query l15];
     //      with the k-permutation, register qf[qt][j][t] = Q[q0 + 16 qt + l15][16 j + 4 g + t] ----
-    const int q0 = (qb * 4 + wave) * 16 * QT;
+    const int q0 = (qb * NW + wave) * 16 * QT;
     f32x4 qf[QT][5];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
@@ -85,8 +113,12 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
         for (int j = 0; j < 5; ++j)
             qf[qt][j] = *reinterpret_cast<const f32x4*>(base + (int64_t)(q0 + qt * 16 + l15) * QKV_LD + j * 16 + g * 4);
     // ---- both K halves go out now; the first one is awaited, the second lands under the first half of S ----
-    dma_half<KS / 4>(base + DIM, smem, wave, lane);
-    dma_half<KS / 4>(base + (int64_t)HALF * QKV_LD + DIM, smem + HALF * KS, wave, lane);
+    {
+        const KOff kd = dma_offsets<KS / 4, NW>(wave, lane);
+        dma_half<KS / 4, NW>(base + DIM, smem, wave, kd);
+        dma_half<KS / 4, NW>(base + (int64_t)HALF * QKV_LD + DIM, smem + HALF * KS, wave, kd);
+    }
+    const VOff vd = dma_offsets<VS / 4, NW>(wave, lane);     // 8 registers (NW = 4) that live across the S phases
 
     // ---- S^T tiles: s[qt][kt][r] = S[q0 + 16 qt + l15][16 kt + 4 g + r] ----
     f32x4 s[QT][12];
@@ -115,16 +147,22 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
             ka = kn;
         }
     };
-    wait_vm_barrier<8>();        // Q and K[0:96] have landed (at most this wave's 8 youngest = K[96:192] copies are in flight)
+    wait_vm_barrier<KOff::MINPER>();   // Q and K[0:96] have landed (at most this wave's MINPER youngest = K[96:192] copies are in flight)
     s_half(0);
     wait_vm_barrier<0>();        // K[96:192] landed; every wave is done with the first K half ...
-    dma_half<VS / 4>(base + 2 * DIM, smem, wave, lane);                                        // ... which V[0:96] overwrites
+    dma_half<VS / 4, NW>(base + 2 * DIM, smem, wave, vd);                                        // ... which V[0:96] overwrites
     s_half(1);
-    wait_vm_barrier<8>();        // every wave is done with the second K half (V[0:96] may still be in flight)
-    dma_half<VS / 4>(base + (int64_t)HALF * QKV_LD + 2 * DIM, smem + HALF * VS, wave, lane);
+    wait_vm_barrier<VOff::MINPER>();   // every wave is done with the second K half (V[0:96] may still be in flight)
+    dma_half<VS / 4, NW>(base + (int64_t)HALF * QKV_LD + 2 * DIM, smem + HALF * VS, wave, vd);
 
-    // ---- softmax over the 192 keys of each query (4 lanes x 48 registers per query), under the V copies ----
+    // ---- softmax over the 192 keys of each query (4 lanes x 48 registers per query), under the V copies.
+    //      e_j = 2^(s_j log2e - m log2e) as ONE packed fma per score PAIR (v_pk_fma_f32) + v_exp_f32; the rounding of the
+    //      constant m log2e is common to the whole row and cancels in e / sum.  The probabilities are NOT normalised here:
+    //      P.V accumulates the un-normalised e and the 80 outputs of a query are scaled by 1/sum afterwards — 20 multiplies
+    //      per lane instead of 48, and the row sums are packed adds.  (Round 1: sub, mul, exp, add, mul per score = 1353
+    //      non-MFMA VALU instructions per wave, profiles/r1_pmc_attention.json; VALU time is matrix-pipe time on gfx950.) ----
     constexpr float LOG2E = 1.44269504088896340736f;
+    float inv[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         float m = s[qt][0][0];
@@ -134,22 +172,22 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
             for (int r = 0; r < 4; ++r) m = fmaxf(m, s[qt][kt][r]);
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float sum = 0.f;
+        const f32x2 c2 = splat2(-(m * LOG2E)), l2 = splat2(LOG2E);
+        f32x2 sum2 = splat2(0.f);
 #pragma unroll
         for (int kt = 0; kt < 12; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f((s[qt][kt][r] - m) * LOG2E);
-                s[qt][kt][r] = e;
-                sum += e;
+            for (int h = 0; h < 2; ++h) {
+                const f32x2 t = __builtin_elementwise_fma(f32x2{s[qt][kt][2 * h], s[qt][kt][2 * h + 1]}, l2, c2);
+                const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                s[qt][kt][2 * h] = e.x;
+                s[qt][kt][2 * h + 1] = e.y;
+                sum2 += e;
             }
+        float sum = sum2.x + sum2.y;
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int kt = 0; kt < 12; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[qt][kt][r] *= inv;
+        inv[qt] = 1.0f / sum;
     }
 
     // ---- O^T = V^T P^T: A[i = d l15][kslot g] = V[16 kt + 4 g + r][16 dt + l15], B[kslot g][j = query l15] = P register.
@@ -181,18 +219,19 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
             for (int dt = 0; dt < 5; ++dt) vc[dt] = vn[dt];
         }
     };
-    wait_vm_barrier<8>();        // V[0:96] landed for every wave
+    wait_vm_barrier<VOff::MINPER>();   // V[0:96] landed for every wave
     pv_half(0);
     wait_vm_barrier<0>();        // V[96:192] landed
     pv_half(1);
 
-    // ---- store: D layout of 16x16: col = lane&15 -> query, row = 4*(lane>>4) + reg -> d  (one float4 per tile) ----
+    // ---- normalise + store: D layout of 16x16: col = lane&15 -> query (the lane that holds this query's 1/sum),
+    //      row = 4*(lane>>4) + reg -> d  (one float4 per tile) ----
     float* obase = out + (int64_t)b * NTOK * DIM + h * HD;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int dt = 0; dt < 5; ++dt)
-            *reinterpret_cast<f32x4*>(obase + (int64_t)(q0 + qt * 16 + l15) * DIM + dt * 16 + g * 4) = o[qt][dt];
+            *reinterpret_cast<f32x4*>(obase + (int64_t)(q0 + qt * 16 + l15) * DIM + dt * 16 + g * 4) = o[qt][dt] * inv[qt];
 }
 
 }  // namespace
@@ -200,7 +239,10 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const float* __re
 int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s) {
     if (B <= 0) return -1;
     // while 48*B workgroups of 64 queries still fit the 512 resident slots (2 per CU) they finish sooner than 16*B of 192
-    if (B <= 10) hipLaunchKernelGGL(vit_attention_kernel<1>, dim3(B * NH * 3), dim3(256), 0, s, qkv, out);
-    else hipLaunchKernelGGL(vit_attention_kernel<3>, dim3(B * NH), dim3(256), 0, s, qkv, out);
+    static const int forced = [] { const char* e = getenv("THMR_ATTN_VARIANT"); return e ? atoi(e) : 0; }();   // A/B knob (scripts/)
+    const int variant = forced ? forced : (B <= 10 ? 1 : 3);
+    if (variant == 1) hipLaunchKernelGGL((vit_attention_kernel<1, 4>), dim3(B * NH * 3), dim3(256), 0, s, qkv, out);
+    else if (variant == 12) hipLaunchKernelGGL((vit_attention_kernel<1, 12>), dim3(B * NH), dim3(768), 0, s, qkv, out);   // A/B only: measured no faster (profiles/r2c_attention_variants.log)
+    else hipLaunchKernelGGL((vit_attention_kernel<3, 4>), dim3(B * NH), dim3(256), 0, s, qkv, out);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

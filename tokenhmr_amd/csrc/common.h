@@ -168,6 +168,40 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- the persistent decoder kernel (decoder_fused.hip) ----
+struct DecLayerW {        // one decoder layer (pose_transformer.py:191-201), pointers into the weight arena
+    const float *n0w, *n0b, *wv, *wo1, *bo1;          // PreNorm + self-attention (v slice of to_qkv, to_out)
+    const float *n1w, *n1b, *wq, *wo2, *bo2;          // PreNorm + cross-attention (to_q, to_out); K/V come from the KV GEMM
+    const float *n2w, *n2b, *w1, *b1, *w2, *b2;       // PreNorm + FeedForward
+};
+struct DecParams {
+    DecLayerW L[6];
+    const float *tok_bias, *pos;                      // layer-0 input = bias + pos_embedding (the input token is zero)
+    const float* kv;                                  // (B*192, ldkv): per layer [K (512) | V (512)]
+    const float *ro_w, *ro_b, *mt_w, *mt_b;           // read-outs (31 rows + zero row), mixer_trans.ff.0 (10240 rows)
+    float *dx, *dv, *dq, *dca, *dff, *ro, *mt;        // scratch: (B,1024) (B,512) (B,512) (B,512) (B,1024) (B,32) (B,10240)
+    unsigned* sync;
+    int64_t ldkv;
+    int depth, B;
+    int timeline;                                     // 1: workgroup 0 stamps the wall clock into sync[16..] (diagnostics)
+};
+
+int launch_decoder_fused(const DecParams& p, hipStream_t s);
+
+// ---- the MLP-Mixer stack kernel (mixer_fused.hip) ----
+struct MixerLayerW {
+    const float *ln1w, *ln1b, *wt1, *bt1, *wt2, *bt2, *ln2w, *ln2b, *wc1, *bc1, *wc2, *bc2;
+};
+struct MixerParams {
+    MixerLayerW L[4];
+    const float *tln_w, *tln_b;          // mixer_trans.ff.1 LayerNorm(10240)
+    const float *wn, *bn, *nln_w, *nln_b;   // mixer_norm_layer: Linear(64,64) + LayerNorm(64) + ReLU
+    const float* mt;                     // (B, 10240) mixer_trans Linear output
+    float* out;                          // (B, 160, 64) classifier features -> class_pred_layer
+};
+
+int launch_mixer_fused(const MixerParams& p, int B, hipStream_t s);
+
 // host-side launch helpers (defined in the .hip files); all return 0 / negative
 int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s);          // gemm_f32.hip
 // small-M path: 64x64 tiles, `ring`-deep LDS-DMA ring (4 or 8), optional split-K into part[ksplit][M][N] (epilogue then

@@ -13,6 +13,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -34,6 +35,10 @@ constexpr float VIT_EPS = 1e-6f, LN_EPS = 1e-5f;
 constexpr float FOCAL = 5000.0f, IMG = 256.0f;
 // small-batch ViT path (gemm_ring_kernel): used while M = 192*B <= kSmallM; crossovers measured in profiles/r1_small_gemm_variants.log
 constexpr int kSmallM = 1152, kSplitKMax = 4;     // B <= 6
+// decoder + mixer stack: the persistent decoder kernel and the one-workgroup-per-crop mixer kernel win while the work is
+// latency-bound (B = 1: 0.96 vs 1.01 ms, B = 64: 1.58 vs 1.93 ms per head); from a few hundred crops on the same products are
+// real GEMMs (M = B and M = 160 B rows) and the tiled MFMA kernels win (B = 512: 6.7 vs 7.5 ms) — profiles/r2e_head_fused_vs_chain.log
+constexpr int kFusedHeadMaxB = 128;
 
 thread_local std::string g_last_error;
 
@@ -65,6 +70,10 @@ struct thmr_engine {
     std::unordered_map<std::string, Slot> slots;
     std::vector<std::string> required;
     std::vector<VitBlockW> vitw;      // filled by thmr_finalize_weights
+    DecParams dec{};                  // decoder weight pointers + scratch, resolved once (finalize)
+    MixerParams mix{};                // MLP-Mixer stack weight pointers
+    bool counted = false;             // registered in the per-device engine count (decoder turnstile)
+    bool legacy_head = false;         // THMR_LEGACY_HEAD=1: force the chain-of-GEMMs head at every batch size (A/B only)
     bool smpl_loaded = false, finalized = false;
     std::string err;
     // derived / constant regions (float offsets in weight arena)
@@ -87,7 +96,7 @@ struct thmr_engine {
         size_t x, h, big, part;
         size_t dx, dh, dv, dq, dca, dff, ro;
         size_t mt, cf, cf2, y1, tT, u, yt, y, s, z0, zh, nl, nl2;
-        size_t feat, gat, act0, act1, act2, bpose, tokidx;
+        size_t feat, gat, act0, act1, act2, bpose, tokidx, sync;
         size_t A, pf, Jtr, vposed, rot, betas, cam, camt, verts, joints, pose6d;
         size_t total;
     } so{};
@@ -320,7 +329,7 @@ void layout_scratch(thmr_engine* e) {
     s.feat = take(B * TN * CODE);
     s.gat = take(B * 125 * 3 * VQW);                 // largest gather: T=125, 3*512 (> 160*768)
     s.act0 = take(B * TN * VQW); s.act1 = take(B * TN * VQW); s.act2 = take(B * TN * VQW);
-    s.bpose = take(B * 128); s.tokidx = take(B * TN);
+    s.bpose = take(B * 128); s.tokidx = take(B * TN); s.sync = take(512);
     s.A = take(B * NJ * 12); s.pf = take(B * THMR_LBS_XF); s.Jtr = take(B * NJ * 3); s.vposed = take(B * NV * 3);
     s.rot = take(B * NJ * 9); s.betas = take(B * NB); s.cam = take(B * 3); s.camt = take(B * 3);
     s.verts = take(B * NV * 3); s.joints = take(B * 132); s.pose6d = take(B * 144);
@@ -445,6 +454,8 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
     return 0;
 }
 
+int launch_decoder_serialised(thmr_engine* e, const DecParams& d, hipStream_t st);   // below (decoder turnstile)
+
 // ---------------------------------------------------------------------------------------------- head
 int conv3(thmr_engine* e, int conv_id, const float* in, int Tin, int Tout, const int32_t* src, int dil, int prerelu,
           const float* bias, int epi, const float* resid, float* outp, int B, hipStream_t st) {
@@ -507,6 +518,17 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
     ProfScope ps_head(e, st, THMR_PROF_HEAD, 2.0 * B * (6.0 * 4.2e6 + 116.7e6 + 167.8e6 + 705.0e6), 0);
     float *dx = e->S(so.dx), *dh = e->S(so.dh), *dv = e->S(so.dv), *dq = e->S(so.dq), *dca = e->S(so.dca), *dff = e->S(so.dff);
     const std::string T = "smpl_head.transformer.";
+    const std::string C = "smpl_head.decpose.";
+    float* ro = e->S(so.ro);
+    float *mt = e->S(so.mt), *cf = e->S(so.cf), *cf2 = e->S(so.cf2);
+    const bool fused_head = !e->legacy_head && B <= kFusedHeadMaxB;
+    if (fused_head) {
+        // ONE persistent kernel: layer-0 input, the 6 decoder layers (42 dependent GEMV-class steps), the read-outs and the
+        // classifier's first Linear (decoder_fused.hip)
+        DecParams d = e->dec;
+        d.B = B;
+        LAUNCH_OK(launch_decoder_serialised(e, d, st));
+    } else {
     LAUNCH_OK(launch_decoder_init(e->W(T + "to_token_embedding.bias"), e->W(T + "pos_embedding"), dx, B, E, st));
     for (int l = 0; l < e->dec_depth; ++l) {
         const std::string p = T + "transformer.layers." + std::to_string(l) + ".";
@@ -542,55 +564,57 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
             LAUNCH_OK(launch_gemm_skinny(a, EPI_BIAS_RESID, st));
         }
     }
-    if (out && out->token_out) HIP_OK(hipMemcpyAsync(out->token_out, dx, sizeof(float) * B * E, hipMemcpyDeviceToDevice, st));
-
     // read-outs: one (31,1024) GEMV-class GEMM (token_head.py:99-105)
-    float* ro = e->S(so.ro);
     {
         GemmArgs a = mk(dx, E, e->warena + e->o_ro_w, E, e->warena + e->o_ro_b, nullptr, 0, ro, 32, B, 31, E);
         LAUNCH_OK(launch_gemm_skinny(a, EPI_BIAS, st));
     }
     // token classifier (token_classifier.py:89-104)
-    const std::string C = "smpl_head.decpose.";
-    float *mt = e->S(so.mt), *cf = e->S(so.cf), *cf2 = e->S(so.cf2);
     {
         GemmArgs a = mk(dx, E, e->W(C + "mixer_trans.ff.0.weight"), E, e->W(C + "mixer_trans.ff.0.bias"), nullptr, 0, mt, TN * HID, B, TN * HID, E);
         LAUNCH_OK(launch_gemm_skinny(a, EPI_BIAS, st));
     }
-    LAUNCH_OK(launch_layernorm(mt, e->W(C + "mixer_trans.ff.1.weight"), e->W(C + "mixer_trans.ff.1.bias"), cf, B, TN * HID, LN_EPS, 1, st));
+    }
+    if (out && out->token_out) HIP_OK(hipMemcpyAsync(out->token_out, dx, sizeof(float) * B * E, hipMemcpyDeviceToDevice, st));
     const int R = B * TN;
-    for (int m = 0; m < MIX; ++m) {   // MixerLayer, heads/modules.py:55-63
-        const std::string p = C + "mixer_head." + std::to_string(m) + ".";
-        float *y1 = e->S(so.y1), *tT = e->S(so.tT), *u = e->S(so.u), *yt = e->S(so.yt), *y = e->S(so.y), *s = e->S(so.s),
-              *z0 = e->S(so.z0), *zh = e->S(so.zh);
-        LAUNCH_OK(launch_layernorm(cf, e->W(p + "layernorm1.weight"), e->W(p + "layernorm1.bias"), y1, R, HID, LN_EPS, 0, st));
-        LAUNCH_OK(launch_transpose(y1, tT, B, TN, HID, st));                                   // (B,160,64)->(B,64,160)
-        {
-            GemmArgs a = mk(tT, TN, e->W(p + "MLP_token.ff.0.weight"), TN, e->W(p + "MLP_token.ff.0.bias"), nullptr, 0, u, TOK_INTER, B * HID, TOK_INTER, TN);
-            LAUNCH_OK(launch_gemm(a, EPI_BIAS_GELU, -1, st));
+    float *nl = e->S(so.nl), *nl2 = e->S(so.nl2);
+    if (fused_head) {
+        // ONE kernel, one workgroup per crop: mixer_trans LayerNorm + ReLU, the 4 MixerLayers, mixer_norm_layer (mixer_fused.hip)
+        LAUNCH_OK(launch_mixer_fused(e->mix, B, st));
+    } else {
+        LAUNCH_OK(launch_layernorm(mt, e->W(C + "mixer_trans.ff.1.weight"), e->W(C + "mixer_trans.ff.1.bias"), cf, B, TN * HID, LN_EPS, 1, st));
+        for (int m = 0; m < MIX; ++m) {   // MixerLayer, heads/modules.py:55-63
+            const std::string p = C + "mixer_head." + std::to_string(m) + ".";
+            float *y1 = e->S(so.y1), *tT = e->S(so.tT), *u = e->S(so.u), *yt = e->S(so.yt), *y = e->S(so.y), *s = e->S(so.s),
+                  *z0 = e->S(so.z0), *zh = e->S(so.zh);
+            LAUNCH_OK(launch_layernorm(cf, e->W(p + "layernorm1.weight"), e->W(p + "layernorm1.bias"), y1, R, HID, LN_EPS, 0, st));
+            LAUNCH_OK(launch_transpose(y1, tT, B, TN, HID, st));                                   // (B,160,64)->(B,64,160)
+            {
+                GemmArgs a = mk(tT, TN, e->W(p + "MLP_token.ff.0.weight"), TN, e->W(p + "MLP_token.ff.0.bias"), nullptr, 0, u, TOK_INTER, B * HID, TOK_INTER, TN);
+                LAUNCH_OK(launch_gemm(a, EPI_BIAS_GELU, -1, st));
+            }
+            {
+                GemmArgs a = mk(u, TOK_INTER, e->W(p + "MLP_token.ff.3.weight"), TOK_INTER, e->W(p + "MLP_token.ff.3.bias"), nullptr, 0, yt, TN, B * HID, TN, TOK_INTER);
+                LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
+            }
+            LAUNCH_OK(launch_transpose(yt, y, B, HID, TN, st));                                    // (B,64,160)->(B,160,64)
+            LAUNCH_OK(launch_add_ln64(cf, y, e->W(p + "layernorm2.weight"), e->W(p + "layernorm2.bias"), s, z0, R, LN_EPS, st));
+            {
+                GemmArgs a = mk(z0, HID, e->W(p + "MLP_channel.ff.0.weight"), HID, e->W(p + "MLP_channel.ff.0.bias"), nullptr, 0, zh, HID_INTER, R, HID_INTER, HID);
+                LAUNCH_OK(launch_gemm(a, EPI_BIAS_GELU, -1, st));
+            }
+            {   // out = (x + y) + z
+                GemmArgs a = mk(zh, HID_INTER, e->W(p + "MLP_channel.ff.3.weight"), HID_INTER, e->W(p + "MLP_channel.ff.3.bias"), s, HID, cf2, HID, R, HID, HID_INTER);
+                LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, -1, st));
+            }
+            std::swap(cf, cf2);
         }
         {
-            GemmArgs a = mk(u, TOK_INTER, e->W(p + "MLP_token.ff.3.weight"), TOK_INTER, e->W(p + "MLP_token.ff.3.bias"), nullptr, 0, yt, TN, B * HID, TN, TOK_INTER);
+            GemmArgs a = mk(cf, HID, e->W(C + "mixer_norm_layer.ff.0.weight"), HID, e->W(C + "mixer_norm_layer.ff.0.bias"), nullptr, 0, nl, HID, R, HID, HID);
             LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
         }
-        LAUNCH_OK(launch_transpose(yt, y, B, HID, TN, st));                                    // (B,64,160)->(B,160,64)
-        LAUNCH_OK(launch_add_ln64(cf, y, e->W(p + "layernorm2.weight"), e->W(p + "layernorm2.bias"), s, z0, R, LN_EPS, st));
-        {
-            GemmArgs a = mk(z0, HID, e->W(p + "MLP_channel.ff.0.weight"), HID, e->W(p + "MLP_channel.ff.0.bias"), nullptr, 0, zh, HID_INTER, R, HID_INTER, HID);
-            LAUNCH_OK(launch_gemm(a, EPI_BIAS_GELU, -1, st));
-        }
-        {   // out = (x + y) + z
-            GemmArgs a = mk(zh, HID_INTER, e->W(p + "MLP_channel.ff.3.weight"), HID_INTER, e->W(p + "MLP_channel.ff.3.bias"), s, HID, cf2, HID, R, HID, HID_INTER);
-            LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, -1, st));
-        }
-        std::swap(cf, cf2);
+        LAUNCH_OK(launch_layernorm(nl, e->W(C + "mixer_norm_layer.ff.1.weight"), e->W(C + "mixer_norm_layer.ff.1.bias"), nl2, R, HID, LN_EPS, 1, st));
     }
-    float *nl = e->S(so.nl), *nl2 = e->S(so.nl2);
-    {
-        GemmArgs a = mk(cf, HID, e->W(C + "mixer_norm_layer.ff.0.weight"), HID, e->W(C + "mixer_norm_layer.ff.0.bias"), nullptr, 0, nl, HID, R, HID, HID);
-        LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
-    }
-    LAUNCH_OK(launch_layernorm(nl, e->W(C + "mixer_norm_layer.ff.1.weight"), e->W(C + "mixer_norm_layer.ff.1.bias"), nl2, R, HID, LN_EPS, 1, st));
     // logits / softmax / token index; KV in `big` is dead after the decoder, so logits+probs live there
     float* logits = (out && out->cls_logits) ? out->cls_logits : big;
     float* probs = (out && out->cls_logits_softmax) ? out->cls_logits_softmax : big + (size_t)R * NCLS;
@@ -652,6 +676,40 @@ void build_idx_tables(thmr_engine* e) {
     }
 }
 constexpr int32_t kEncMagic = 0x454e4331;   // 'ENC1': arena flag word 0 = "tokenizer encoder tensors present + repacked"
+
+// The persistent decoder kernel needs ALL its workgroups resident at once (grid barrier) and, from 49 crops on, asks for every
+// CU.  Two of them launched concurrently by two engines on two streams could each grab part of the chip and wait for the rest
+// until the barrier's timeout fires.  So when a process has more than one engine on a device, those launches are chained
+// through one event per device: each waits for the previous one (of any engine) to finish.  One engine (the normal case)
+// never touches the event, and a capturing stream does not either (an event from outside a capture cannot be waited on).
+struct DecoderTurnstile {
+    std::mutex mu;
+    std::map<int, int> engines;          // device -> live engines
+    std::map<int, hipEvent_t> last;      // device -> event recorded after the most recent persistent launch
+};
+DecoderTurnstile& turnstile() {
+    static DecoderTurnstile t;
+    return t;
+}
+
+int launch_decoder_serialised(thmr_engine* e, const DecParams& d, hipStream_t st) {
+    DecoderTurnstile& t = turnstile();
+    std::unique_lock<std::mutex> lk(t.mu);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (t.engines[e->cfg.device] <= 1 || hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        lk.unlock();
+        return launch_decoder_fused(d, st);
+    }
+    auto it = t.last.find(e->cfg.device);
+    if (it == t.last.end()) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return -2;
+        it = t.last.emplace(e->cfg.device, ev).first;
+    } else if (hipStreamWaitEvent(st, it->second, 0) != hipSuccess) return -2;
+    const int r = launch_decoder_fused(d, st);
+    if (hipEventRecord(it->second, st) != hipSuccess) return -2;
+    return r;
+}
 
 int check_ready(thmr_engine* e, int B) {
     if (!e) return fail(nullptr, THMR_ERR_INVALID, "null engine");
@@ -726,12 +784,18 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
         if (hipMalloc(&e->sarena, e->sfloats * sizeof(float)) != hipSuccess) return bail(THMR_ERR_NOMEM, "hipMalloc(scratch) failed");
         e->own_s = true;
     }
+    // grid-barrier words of the persistent decoder kernel (the scratch arena is private to this engine; a caller-provided
+    // one may hold garbage)
+    if (hipMemset(e->sarena + e->so.sync, 0, 512 * sizeof(float)) != hipSuccess) return bail(THMR_ERR_HIP, "hipMemset(sync words) failed");
+    { const char* lg = getenv("THMR_LEGACY_HEAD"); e->legacy_head = lg && lg[0] == '1'; }
+    { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
     *out = e;
     return 0;
 }
 
 void thmr_destroy(thmr_engine* e) {
     if (!e) return;
+    if (e->counted) { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[e->cfg.device] -= 1; }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->own_w && e->warena) (void)hipFree(e->warena);
     if (e->own_s && e->sarena) (void)hipFree(e->sarena);
@@ -837,6 +901,48 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
         w.f1w = e->W(p + "mlp.fc1.weight"); w.f1b = e->W(p + "mlp.fc1.bias");
         w.f2w = e->W(p + "mlp.fc2.weight"); w.f2b = e->W(p + "mlp.fc2.bias");
     }
+    {   // decoder / read-out / mixer_trans pointers of the persistent decoder kernel, resolved once
+        DecParams& d = e->dec;
+        const std::string T = "smpl_head.transformer.";
+        for (int l = 0; l < e->dec_depth; ++l) {
+            const std::string p = T + "transformer.layers." + std::to_string(l) + ".";
+            DecLayerW& w = d.L[l];
+            w.n0w = e->W(p + "0.norm.weight"); w.n0b = e->W(p + "0.norm.bias");
+            w.wv = e->W(p + "0.fn.to_qkv.weight") + (size_t)2 * INNER * E;            // v slice of to_qkv (rows 1024..1535)
+            w.wo1 = e->W(p + "0.fn.to_out.0.weight"); w.bo1 = e->W(p + "0.fn.to_out.0.bias");
+            w.n1w = e->W(p + "1.norm.weight"); w.n1b = e->W(p + "1.norm.bias");
+            w.wq = e->W(p + "1.fn.to_q.weight");
+            w.wo2 = e->W(p + "1.fn.to_out.0.weight"); w.bo2 = e->W(p + "1.fn.to_out.0.bias");
+            w.n2w = e->W(p + "2.norm.weight"); w.n2b = e->W(p + "2.norm.bias");
+            w.w1 = e->W(p + "2.fn.net.0.weight"); w.b1 = e->W(p + "2.fn.net.0.bias");
+            w.w2 = e->W(p + "2.fn.net.3.weight"); w.b2 = e->W(p + "2.fn.net.3.bias");
+        }
+        d.tok_bias = e->W(T + "to_token_embedding.bias"); d.pos = e->W(T + "pos_embedding");
+        d.kv = e->S(e->so.big); d.ldkv = (int64_t)e->dec_depth * 2 * INNER;
+        d.ro_w = e->warena + e->o_ro_w; d.ro_b = e->warena + e->o_ro_b;
+        d.mt_w = e->W("smpl_head.decpose.mixer_trans.ff.0.weight"); d.mt_b = e->W("smpl_head.decpose.mixer_trans.ff.0.bias");
+        d.dx = e->S(e->so.dx); d.dv = e->S(e->so.dv); d.dq = e->S(e->so.dq); d.dca = e->S(e->so.dca); d.dff = e->S(e->so.dff);
+        d.ro = e->S(e->so.ro); d.mt = e->S(e->so.mt);
+        d.sync = reinterpret_cast<unsigned*>(e->S(e->so.sync));
+        d.depth = e->dec_depth; d.B = 0;
+        { const char* tl = getenv("THMR_DEC_TIMELINE"); d.timeline = tl && tl[0] == '1'; }
+        MixerParams& m = e->mix;
+        const std::string C = "smpl_head.decpose.";
+        for (int i = 0; i < MIX; ++i) {
+            const std::string p = C + "mixer_head." + std::to_string(i) + ".";
+            MixerLayerW& w = m.L[i];
+            w.ln1w = e->W(p + "layernorm1.weight"); w.ln1b = e->W(p + "layernorm1.bias");
+            w.wt1 = e->W(p + "MLP_token.ff.0.weight"); w.bt1 = e->W(p + "MLP_token.ff.0.bias");
+            w.wt2 = e->W(p + "MLP_token.ff.3.weight"); w.bt2 = e->W(p + "MLP_token.ff.3.bias");
+            w.ln2w = e->W(p + "layernorm2.weight"); w.ln2b = e->W(p + "layernorm2.bias");
+            w.wc1 = e->W(p + "MLP_channel.ff.0.weight"); w.bc1 = e->W(p + "MLP_channel.ff.0.bias");
+            w.wc2 = e->W(p + "MLP_channel.ff.3.weight"); w.bc2 = e->W(p + "MLP_channel.ff.3.bias");
+        }
+        m.tln_w = e->W(C + "mixer_trans.ff.1.weight"); m.tln_b = e->W(C + "mixer_trans.ff.1.bias");
+        m.wn = e->W(C + "mixer_norm_layer.ff.0.weight"); m.bn = e->W(C + "mixer_norm_layer.ff.0.bias");
+        m.nln_w = e->W(C + "mixer_norm_layer.ff.1.weight"); m.nln_b = e->W(C + "mixer_norm_layer.ff.1.bias");
+        m.mt = e->S(e->so.mt); m.out = e->S(e->so.nl2);
+    }
     e->finalized = true;
     return 0;
 }
@@ -913,6 +1019,24 @@ int thmr_weight_arena(thmr_engine* e, void** ptr_dev, size_t* bytes) {
     if (!e) return fail(e, THMR_ERR_INVALID, "null engine");
     if (ptr_dev) *ptr_dev = e->warena;
     if (bytes) *bytes = e->wfloats * sizeof(float);
+    return 0;
+}
+
+int thmr_engine_status(thmr_engine* e, void* stream) {
+    if (!e) return fail(e, THMR_ERR_INVALID, "null engine");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned words[4] = {0, 0, 0, 0};
+    HIP_OK(hipMemcpyAsync(words, e->sarena + e->so.sync, sizeof(words), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (words[3] != 0) return fail(e, THMR_ERR_HIP, "persistent decoder kernel: grid barrier timed out (were its 64 workgroups prevented from being resident together?)");
+    return 0;
+}
+
+int thmr_debug_decoder_timeline(thmr_engine* e, uint64_t* stamps_host, int32_t max_stamps, void* stream) {
+    if (!e || !stamps_host || max_stamps < 1 || max_stamps > 240) return fail(e, THMR_ERR_INVALID, "bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_OK(hipMemcpyAsync(stamps_host, e->sarena + e->so.sync + 16, sizeof(uint64_t) * max_stamps, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
     return 0;
 }
 

@@ -163,6 +163,11 @@ class Engine:
             _cabi.check(self.lib.thmr_forward(self.h, _ptr(img), B, C.byref(st), _stream_ptr(self.device)), self.h)
         return o
 
+    def status(self):
+        """Synchronises the current stream and raises if a kernel of this engine reported an asynchronous error."""
+        with torch.cuda.device(self.device):
+            _cabi.check(self.lib.thmr_engine_status(self.h, _stream_ptr(self.device)), self.h)
+
     def vit_forward(self, img, out=None):
         img = self._check_img(img)
         B = img.shape[0]
