@@ -237,6 +237,21 @@ int  thmr_cropper_run(thmr_cropper* c, const uint8_t* frame_dev, int32_t H, int3
                       const thmr_crop_desc* crops_host, int32_t n, int32_t patch, int32_t swap_rb, const float* mean_host,
                       const float* std_host, float* out_dev, void* stream);
 
+/* ---- data-parallel collectives for hosts without torch.distributed ----
+ * The reference has no collective on this path (inference is single-device, tokenhmr/eval.py:52-54).  Crops shard with NO data-path
+ * collective; two collectives surround the path: ONE broadcast of the packed weight arena at start-up (only rank `root` read the
+ * checkpoint; follow it with thmr_finalize_weights(assume_all_loaded = 1) on the receivers) and ONE all-gather per batch of the packed
+ * per-crop records.  `nccl_comm` is an ncclComm_t the caller created (ncclCommInitRank) with the RCCL already loaded in the process;
+ * the library resolves ncclBroadcast / ncclAllGather from that copy at first use (it does not link its own).  Asynchronous on `stream`.
+ *   record = [pred_vertices 20670 | pred_keypoints_3d 132 | pred_keypoints_2d 88 | rotmat 216 | betas 10 | pred_cam 3 | pred_cam_t 3 |
+ *             token_idx 160 (int32 bits)] = THMR_RECORD_WORDS 32-bit words per crop (85,128 B). */
+#define THMR_RECORD_WORDS 21282
+int thmr_pack_records(const thmr_outputs* out, int32_t B, float* rec_dev /*(B, THMR_RECORD_WORDS)*/, void* stream);
+int thmr_bcast_weights(thmr_engine* e, void* nccl_comm, int32_t root, void* stream);
+/* every rank contributes `rows` records (pad to the largest shard); recv_dev is (world * rows, THMR_RECORD_WORDS) in rank order */
+int thmr_allgather_records(void* nccl_comm, const float* rec_dev, int32_t rows, float* recv_dev, void* stream);
+const char* thmr_collective_last_error(void);
+
 /* Built-in profiler: HIP events recorded on the launch stream around each kernel class.
  * on = 0 off, 1 every class, 2 only the four ViT GEMM classes (an event pair costs ~2 us of stream time; ~330 pairs per
  * call with on = 1 is ~1 % of a B = 64 step, which is why bench.py times with on = 2). */

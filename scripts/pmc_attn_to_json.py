@@ -1,8 +1,9 @@
-"""Collapse the rocprofv3 --pmc passes of scripts/gpu_attn_pmc.sh into profiles/r1_pmc_attention.json (per launch of
-vit_attention_kernel<3> at B = 64: 1024 workgroups x 4 waves, 12.08 GFLOP)."""
+"""Collapse the rocprofv3 --pmc passes of scripts/gpu_attn_pmc.sh into profiles/<out>.json (per launch of
+vit_attention_kernel<3, 4> at B = 64: 1024 workgroups x 4 waves, 12.08 GFLOP).   python scripts/pmc_attn_to_json.py [out_json]"""
 import csv
 import json
 import os
+import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +15,7 @@ for p in ("sq", "sq2"):
         continue
     seen = set()
     for r in csv.DictReader(open(f)):
-        if "vit_attention_kernel<3>" not in r["Kernel_Name"]:
+        if "vit_attention_kernel<3" not in r["Kernel_Name"]:
             continue
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         if p == "sq" and r["Dispatch_Id"] not in seen:
@@ -23,7 +24,7 @@ for p in ("sq", "sq2"):
 res = {k: sum(v) / len(v) for k, v in acc.items()}
 waves = 1024 * 4
 mfma_per_wave = 1440                     # 16x16x4 fp32, 8 passes = 32 cycles each on one SIMD
-out = {"kernel": "vit_attention_kernel<3>", "B": 64, "workgroups": 1024, "flop_per_launch": 4.0 * 64 * 16 * 192 * 192 * 80,
+out = {"kernel": "vit_attention_kernel<3, 4>", "B": 64, "workgroups": 1024, "flop_per_launch": 4.0 * 64 * 16 * 192 * 192 * 80,
        "profiled_dur_us": sum(dur) / max(len(dur), 1), **res}
 if "SQ_VALU_MFMA_BUSY_CYCLES" in res and "GRBM_GUI_ACTIVE" in res:
     # busy cycles are summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is per-launch wall cycles
@@ -33,5 +34,5 @@ if "SQ_WAIT_ANY" in res and "SQ_WAVE_CYCLES" in res:
     out["wait_any_frac"] = res["SQ_WAIT_ANY"] / res["SQ_WAVE_CYCLES"]
 if "SQ_INSTS_VALU" in res:
     out["valu_insts_per_wave_incl_mfma"] = res["SQ_INSTS_VALU"] / waves
-json.dump(out, open(os.path.join(ROOT, "profiles", "r1_pmc_attention.json"), "w"), indent=1)
+json.dump(out, open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r2_pmc_attention.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

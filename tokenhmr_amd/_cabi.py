@@ -113,12 +113,16 @@ def load():
     lib.thmr_cropper_last_error.argtypes = [vp]
     lib.thmr_cropper_last_error.restype = C.c_char_p
     lib.thmr_cropper_run.argtypes = [vp, vp, i32, i32, i64, C.POINTER(CropDesc), i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, vp]
+    lib.thmr_pack_records.argtypes = [C.POINTER(Outputs), i32, vp, vp]
+    lib.thmr_bcast_weights.argtypes = [vp, vp, i32, vp]
+    lib.thmr_allgather_records.argtypes = [vp, vp, i32, vp, vp]
+    lib.thmr_collective_last_error.restype = C.c_char_p
     lib.thmr_prof_enable.argtypes = [vp, i32]
     lib.thmr_prof_collect.argtypes = [vp, C.POINTER(ProfEntry), i32]
     for name in declared_symbols():
         fn = getattr(lib, name)
         if name not in ("thmr_build_info", "thmr_last_error", "thmr_destroy", "thmr_smpl_destroy", "thmr_cropper_destroy",
-                        "thmr_cropper_last_error"):
+                        "thmr_cropper_last_error", "thmr_collective_last_error"):
             fn.restype = C.c_int
     if lib.thmr_abi_version() != ABI_VERSION:
         raise RuntimeError("libtokenhmr_hip.so ABI version mismatch")

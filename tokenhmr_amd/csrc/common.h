@@ -168,6 +168,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- device-scope (sc1) relaxed atomics: data that crosses workgroups INSIDE a kernel without cache maintenance ----
+__device__ __forceinline__ void st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16 bytes of a device-coherent activation row as two 8-byte device-scope loads
+__device__ __forceinline__ f32x4 ld_dev4(const float* p) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    union { unsigned long long u; f32x2_t f; } a, b;
+    a.u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b.u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return f32x4{a.f.x, a.f.y, b.f.x, b.f.y};
+}
+
 // ---- the persistent decoder kernel (decoder_fused.hip) ----
 struct DecLayerW {        // one decoder layer (pose_transformer.py:191-201), pointers into the weight arena
     const float *n0w, *n0b, *wv, *wo1, *bo1;          // PreNorm + self-attention (v slice of to_qkv, to_out)
@@ -246,8 +258,10 @@ constexpr int THMR_LBS_KX = 224, THMR_LBS_XF = 224 + 27 * 57;
 int launch_lbs_build_dirs(const float* sd, const float* pd, float* dirsT, hipStream_t s);
 int launch_lbs(const float* rotmat, const float* betas, const float* cam_t, const float* Jt, const float* Jsd,
                const int32_t* parents, const float* vt, const float* dirsT, const float* W, const float* J19,
-               const int32_t* extra, const int32_t* jmap, const int32_t* update_hips, float* A, float* xf, float* Jtr, float* vposed, float* verts,
-               float* joints, float* kp2d, float focal_over_size, int B, hipStream_t s);
+               const int32_t* extra, const int32_t* jmap, const int32_t* update_hips, float* A, float* xf, float* Jtr,
+               float* vposed, float* verts, float* joints, float* kp2d, float focal_over_size, int B, float* xv,
+               unsigned* cnt, hipStream_t s);
+// extra scratch of the fused skin + joints kernel: xv (B, 21, 3) picked extra-joint vertices, cnt (B) arrival counters (zeroed ONCE)
 int launch_rodrigues(const float* aa, float* R, int n, hipStream_t s);
 // eval.hip
 int launch_eval_pose(const float* pred, const float* gt, int nj, int gt_stride, const int32_t* kp, int nkp, int pelvis_ind,

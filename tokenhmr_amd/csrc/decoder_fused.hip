@@ -46,17 +46,6 @@ struct GridSync {
     unsigned n;         // barriers passed so far
 };
 
-__device__ __forceinline__ void st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// 16 bytes of a device-coherent activation row as two 8-byte device-scope loads
-__device__ __forceinline__ f32x4 ld_dev4(const float* p) {
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    union { unsigned long long u; f32x2_t f; } a, b;
-    a.u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    b.u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return f32x4{a.f.x, a.f.y, b.f.x, b.f.y};
-}
-
 __device__ __forceinline__ bool grid_barrier(GridSync& gs, int tid, volatile int* s_ok) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's device-scope stores have completed
     __syncthreads();

@@ -97,7 +97,7 @@ struct thmr_engine {
         size_t dx, dh, dv, dq, dca, dff, ro;
         size_t mt, cf, cf2, y1, tT, u, yt, y, s, z0, zh, nl, nl2;
         size_t feat, gat, act0, act1, act2, bpose, tokidx, sync;
-        size_t A, pf, Jtr, vposed, rot, betas, cam, camt, verts, joints, pose6d;
+        size_t A, pf, Jtr, vposed, rot, betas, cam, camt, verts, joints, pose6d, xv, lcnt;
         size_t total;
     } so{};
     // profiler
@@ -333,6 +333,7 @@ void layout_scratch(thmr_engine* e) {
     s.A = take(B * NJ * 12); s.pf = take(B * THMR_LBS_XF); s.Jtr = take(B * NJ * 3); s.vposed = take(B * NV * 3);
     s.rot = take(B * NJ * 9); s.betas = take(B * NB); s.cam = take(B * 3); s.camt = take(B * 3);
     s.verts = take(B * NV * 3); s.joints = take(B * 132); s.pose6d = take(B * 144);
+    s.xv = take(B * 63); s.lcnt = take(B);
     s.total = off;
     e->sfloats = off;
 }
@@ -646,7 +647,8 @@ int lbs(thmr_engine* e, const float* rot, const float* betas, const float* camt,
     LAUNCH_OK(launch_lbs(rot, betas, camt, e->warena + e->o_smpl_jt, e->warena + e->o_smpl_jsd, ints,
                          e->warena + e->o_smpl_vt, e->warena + e->o_smpl_dirs, e->warena + e->o_smpl_w,
                          e->warena + e->o_smpl_j19, ints + 24, ints + 48, ints + 80, e->S(so.A), e->S(so.pf), e->S(so.Jtr),
-                         e->S(so.vposed), verts, joints, kp2d, FOCAL / IMG, B, st));
+                         e->S(so.vposed), verts, joints, kp2d, FOCAL / IMG, B, e->S(so.xv),
+                         reinterpret_cast<unsigned*>(e->S(so.lcnt)), st));
     return 0;
 }
 
@@ -787,6 +789,8 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     // grid-barrier words of the persistent decoder kernel (the scratch arena is private to this engine; a caller-provided
     // one may hold garbage)
     if (hipMemset(e->sarena + e->so.sync, 0, 512 * sizeof(float)) != hipSuccess) return bail(THMR_ERR_HIP, "hipMemset(sync words) failed");
+    // arrival counters of the fused skin + joints kernel (self-resetting; zero before the first call)
+    if (hipMemset(e->sarena + e->so.lcnt, 0, (size_t)e->max_batch * sizeof(float)) != hipSuccess) return bail(THMR_ERR_HIP, "hipMemset(lbs counters) failed");
     { const char* lg = getenv("THMR_LEGACY_HEAD"); e->legacy_head = lg && lg[0] == '1'; }
     { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
     *out = e;
@@ -1181,7 +1185,7 @@ int thmr_op_aa_to_rotmat(const float* aa, float* R, int32_t n, void* stream) {
 struct thmr_smpl {
     float* mem = nullptr;
     int max_batch = 0;
-    size_t o_vt, o_sd, o_pd, o_jr, o_w, o_j19, o_int, o_jt, o_jsd, o_dirs, o_A, o_pf, o_Jtr, o_vposed, o_rot, o_joints, total;
+    size_t o_vt, o_sd, o_pd, o_jr, o_w, o_j19, o_int, o_jt, o_jsd, o_dirs, o_A, o_pf, o_Jtr, o_vposed, o_rot, o_joints, o_xv, o_cnt, total;
 };
 
 int thmr_smpl_create(const thmr_smpl_desc* d, int32_t max_batch, int32_t device, thmr_smpl** out) {
@@ -1203,8 +1207,10 @@ int thmr_smpl_create(const thmr_smpl_desc* d, int32_t max_batch, int32_t device,
     m->o_A = take(B * NJ * 12); m->o_pf = take(B * THMR_LBS_XF); m->o_Jtr = take(B * NJ * 3); m->o_rot = take(B * NJ * 9);
     m->o_vposed = take(B * NV * 3);
     m->o_joints = take(B * 132);
+    m->o_xv = take(B * 63); m->o_cnt = take(B);
     m->total = off;
     if (hipMalloc(&m->mem, off * sizeof(float)) != hipSuccess) { delete m; return fail(e, THMR_ERR_NOMEM, "hipMalloc(smpl) failed"); }
+    if (hipMemset(m->mem + m->o_cnt, 0, B * sizeof(float)) != hipSuccess) { thmr_smpl_destroy(m); return fail(e, THMR_ERR_HIP, "hipMemset(lbs counters) failed"); }
     const hipMemcpyKind k = d->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     auto cp = [&](size_t o, const void* src, size_t bytes) { return hipMemcpy(m->mem + o, src, bytes, k) == hipSuccess; };
     int32_t* ints = reinterpret_cast<int32_t*>(m->mem + m->o_int);
@@ -1247,7 +1253,7 @@ int thmr_smpl_forward(thmr_smpl* m, const float* pose, int32_t pose2rot, const f
     LAUNCH_OK(launch_lbs(rot, betas, nullptr, m->mem + m->o_jt, m->mem + m->o_jsd, ints, m->mem + m->o_vt, m->mem + m->o_dirs,
                          m->mem + m->o_w, m->mem + m->o_j19, ints + 24, ints + 48, ints + 80, m->mem + m->o_A, m->mem + m->o_pf,
                          m->mem + m->o_Jtr, m->mem + m->o_vposed, verts, joints ? joints : m->mem + m->o_joints, nullptr,
-                         FOCAL / IMG, B, st));
+                         FOCAL / IMG, B, m->mem + m->o_xv, reinterpret_cast<unsigned*>(m->mem + m->o_cnt), st));
     return 0;
 }
 

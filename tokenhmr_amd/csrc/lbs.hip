@@ -14,7 +14,8 @@
 //     posedirs.  It runs on the MFMA GEMM (gemm_f32.hip) with the template as the bias epilogue, so the 18.5 MB dirs
 //     stream is read once per 64-row tile of crops at matrix-core speed (the first version did these 6890*621 FMAs per
 //     crop on the VALU out of LDS and took 107 us at B = 64).
-//   * skin kernel: one thread per (crop, vertex): 24 weights x 24 bone matrices (LDS broadcast) -> 3x4 transform.
+//   * skin + joints kernel: one thread per vertex, 8 crops per workgroup pass: 24 weights x 24 bone matrices (LDS broadcast) ->
+//     3x4 transform; the crop's last workgroup finishes its 44 joints (three launches per call: prep, blend GEMM, skin + joints).
 //   * every global access is coalesced: consecutive lanes = consecutive vertices (12 B each) on loads and stores.
 #include "common.h"
 
@@ -117,85 +118,131 @@ __global__ __launch_bounds__(256) void lbs_build_dirs_kernel(const float* __rest
     dirsT[idx] = v;
 }
 
-// ---- skinning: T = sum_j W[v][j] * A[b][j] (3x4), out = T . [v_posed; 1] — one thread per (crop, vertex).
-//      The block also reduces its 256 vertices against the 19 rows of the extra joint regressor (smpl_wrapper.py:38-39)
-//      while the skinned coordinates are still in registers: jpart[b][block][19*3], combined in a fixed order by the joints
-//      kernel (the regressor would otherwise re-read every vertex of every crop with one block per crop). ----
-constexpr int SKB = (NV + 255) / 256;     // skin blocks per crop = 27
-__global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__ vposed, const float* __restrict__ W,
-                                                       const float* __restrict__ A, const float* __restrict__ J19,
-                                                       float* __restrict__ verts, float* __restrict__ jpart) {
-    __shared__ f32x4 AS[NJ * 3];
-    __shared__ float red[4][57];
-    const int b = blockIdx.y, tid = threadIdx.x, v = blockIdx.x * 256 + tid, lane = tid & 63, wave = tid >> 6;
-    if (tid < NJ * 3) AS[tid] = reinterpret_cast<const f32x4*>(A + (int64_t)b * NJ * 12)[tid];
-    __syncthreads();
+// ---- skinning + joints in ONE kernel.
+//   skin:   T = sum_j W[v][j] * A[b][j] (3x4), out = T . [v_posed; 1] — one thread per vertex, a workgroup owns 256 vertices and
+//           walks CG crops, so the vertex's 24 skinning weights (registers) and the 19 x 256 slice of the extra-joint regressor
+//           (LDS) are read ONCE per CG crops instead of once per crop;
+//   J19:    the workgroup's 256 skinned vertices go through LDS and 228 threads each add 64 products in a fixed order
+//           (smpl_wrapper.py:38-39 vertices2joints) — the first version spent 57 wave reductions (342 cross-lane ops) per thread
+//           and crop on this and re-read the regressor for every crop: 35 us of the 63 us stage at 64 crops;
+//   joints: the LAST of a crop's 27 workgroups to finish (device-scope arrival counter) adds the 27 partial sums in block order,
+//           picks the 21 extra vertices (vertex_joint_selector), applies joint_map (smpl_wrapper.py:19-20,32), update_hips
+//           (:33-36), appends the 19 regressed joints and projects (geometry.py:86-124).  What crosses workgroups (partials,
+//           the 21 picked vertices) moves with device-scope stores / loads, so no cache maintenance and no extra launch. ----
+constexpr int SKB = (NV + 255) / 256;     // skin workgroups per crop = 27
+constexpr int CG_MAX = 8;                 // most crops per workgroup pass (chosen per call: enough workgroups first)
+__global__ __launch_bounds__(256) void lbs_skin_joints_kernel(const float* __restrict__ vposed, const float* __restrict__ W,
+                                                              const float* __restrict__ A, const float* __restrict__ J19,
+                                                              const float* __restrict__ Jtr, const int32_t* __restrict__ extra,
+                                                              const int32_t* __restrict__ jmap, const int32_t* __restrict__ update_hips,
+                                                              const float* __restrict__ cam_t, float* __restrict__ verts,
+                                                              float* jpart, float* xv, unsigned* cnt, float* __restrict__ joints,
+                                                              float* __restrict__ kp2d, float focal_over_size, int B, int CG) {
+    __shared__ f32x4 AS[2][NJ * 3];          // bone matrices of the current / next crop
+    __shared__ float J19s[19][257];
+    __shared__ float outs[256 * 3];
+    __shared__ float part[4][57];
+    __shared__ float jo[44][3];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, v = blockIdx.x * 256 + tid;
     const bool vok = v < NV;
     const int vv = vok ? v : NV - 1;
-    const float* p = vposed + ((int64_t)b * NV + vv) * 3;
-    const float x = p[0], y = p[1], z = p[2];
     f32x4 wv[NJ / 4];
 #pragma unroll
     for (int q = 0; q < NJ / 4; ++q) wv[q] = reinterpret_cast<const f32x4*>(W + (int64_t)vv * NJ)[q];
-    f32x4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const float w = wv[j >> 2][j & 3];
-        T0 += w * AS[j * 3 + 0];
-        T1 += w * AS[j * 3 + 1];
-        T2 += w * AS[j * 3 + 2];
+    for (int j = 0; j < 19; ++j) J19s[j][tid] = vok ? J19[(int64_t)j * NV + v] : 0.f;
+    int slot = -1;                        // which of the 21 extra-joint vertices this thread's vertex is, if any
+    for (int k = 0; k < 21; ++k)
+        if (vok && extra[k] == v) slot = k;
+    // software pipeline over the crops of this pass: the posed vertex and the bone matrices of crop c + 1 are requested before
+    // crop c is skinned (a pass is a serial chain per workgroup; without this every crop exposed one full memory round trip)
+    const int b0 = blockIdx.y * CG;
+    float xn = 0.f, yn = 0.f, zn = 0.f;
+    f32x4 an = {0.f, 0.f, 0.f, 0.f};
+    if (b0 < B) {
+        const float* p = vposed + ((int64_t)b0 * NV + vv) * 3;
+        xn = p[0]; yn = p[1]; zn = p[2];
+        if (tid < NJ * 3) AS[0][tid] = reinterpret_cast<const f32x4*>(A + (int64_t)b0 * NJ * 12)[tid];
     }
-    const float ox = T0[0] * x + T0[1] * y + T0[2] * z + T0[3];
-    const float oy = T1[0] * x + T1[1] * y + T1[2] * z + T1[3];
-    const float oz = T2[0] * x + T2[1] * y + T2[2] * z + T2[3];
-    if (vok) {
-        float* o = verts + ((int64_t)b * NV + v) * 3;
-        o[0] = ox; o[1] = oy; o[2] = oz;
-    }
+    for (int c = 0; c < CG; ++c) {
+        const int b = b0 + c;
+        if (b >= B) break;
+        __syncthreads();                  // AS[c & 1] is complete; outs / part / jo of the previous crop are no longer read
+        const float x = xn, y = yn, z = zn;
+        const bool more = c + 1 < CG && b + 1 < B;
+        if (more) {
+            const float* p = vposed + ((int64_t)(b + 1) * NV + vv) * 3;
+            xn = p[0]; yn = p[1]; zn = p[2];
+            if (tid < NJ * 3) an = reinterpret_cast<const f32x4*>(A + (int64_t)(b + 1) * NJ * 12)[tid];
+        }
+        const f32x4* ASc = AS[c & 1];
+        f32x4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0;
 #pragma unroll
-    for (int j = 0; j < 19; ++j) {
-        const float w = vok ? J19[(int64_t)j * NV + v] : 0.f;
-        const float s0 = wave_sum(w * ox), s1 = wave_sum(w * oy), s2 = wave_sum(w * oz);
-        if (lane == 0) { red[wave][j * 3 + 0] = s0; red[wave][j * 3 + 1] = s1; red[wave][j * 3 + 2] = s2; }
-    }
-    __syncthreads();
-    if (tid < 57) jpart[((int64_t)b * SKB + blockIdx.x) * 57 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-}
-
-// ---- joints: 24 chain joints + 21 vertex picks -> joint_map(25) ++ J19 regressor(19) = 44, + projection ----
-__global__ __launch_bounds__(256) void lbs_joints_kernel(const float* __restrict__ verts, const float* __restrict__ Jtr,
-                                                         const float* __restrict__ jpart, const int32_t* __restrict__ extra,
-                                                         const int32_t* __restrict__ jmap,
-                                                         const int32_t* __restrict__ update_hips,
-                                                         const float* __restrict__ cam_t, float* __restrict__ joints,
-                                                         float* __restrict__ kp2d, float focal_over_size) {
-    __shared__ float jo[44][3];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float* vb = verts + (int64_t)b * NV * 3;
-    if (tid < 57) {          // J19 regressor: the skin blocks' partial sums, block 0 .. 26 in order
-        float s = 0.f;
-        for (int k = 0; k < SKB; ++k) s += jpart[((int64_t)b * SKB + k) * 57 + tid];
-        jo[25 + tid / 3][tid % 3] = s;
-    }
-    if (tid >= 64 && tid < 64 + 75) {
-        const int t = tid - 64, j = t / 3, i = t % 3;
-        const int src = jmap[j];
-        jo[j][i] = (src < NJ) ? Jtr[((int64_t)b * NJ + src) * 3 + i] : vb[extra[src - NJ] * 3 + i];
-    }
-    __syncthreads();
-    // SMPL(update_hips=True), smpl_wrapper.py:33-36, on the 25 mapped joints (before the extra joints are appended):
-    //   j[9,12] = (j[9,12] + 0.25*(j[9,12] - j[12,9])) + 0.5*(j[8] - 0.5*(j[9,12] + j[12,9]))
-    if (*update_hips && tid < 3) {
-        const float a = jo[9][tid], c = jo[12][tid], m = jo[8][tid];
-        jo[9][tid] = (a + 0.25f * (a - c)) + 0.5f * (m - 0.5f * (a + c));
-        jo[12][tid] = (c + 0.25f * (c - a)) + 0.5f * (m - 0.5f * (c + a));
-    }
-    __syncthreads();
-    if (tid < 132 && joints) joints[(int64_t)b * 132 + tid] = jo[tid / 3][tid % 3];
-    if (tid < 44 && kp2d && cam_t) {
-        const float px = jo[tid][0] + cam_t[b * 3 + 0], py = jo[tid][1] + cam_t[b * 3 + 1], pz = jo[tid][2] + cam_t[b * 3 + 2];
-        kp2d[((int64_t)b * 44 + tid) * 2 + 0] = (px / pz) * focal_over_size;
-        kp2d[((int64_t)b * 44 + tid) * 2 + 1] = (py / pz) * focal_over_size;
+        for (int j = 0; j < NJ; ++j) {
+            const float w = wv[j >> 2][j & 3];
+            T0 += w * ASc[j * 3 + 0];
+            T1 += w * ASc[j * 3 + 1];
+            T2 += w * ASc[j * 3 + 2];
+        }
+        const float ox = T0[0] * x + T0[1] * y + T0[2] * z + T0[3];
+        const float oy = T1[0] * x + T1[1] * y + T1[2] * z + T1[3];
+        const float oz = T2[0] * x + T2[1] * y + T2[2] * z + T2[3];
+        if (vok) {
+            float* o = verts + ((int64_t)b * NV + v) * 3;
+            o[0] = ox; o[1] = oy; o[2] = oz;
+        }
+        outs[tid * 3 + 0] = vok ? ox : 0.f;
+        outs[tid * 3 + 1] = vok ? oy : 0.f;
+        outs[tid * 3 + 2] = vok ? oz : 0.f;
+        if (slot >= 0) {
+            float* xo = xv + ((int64_t)b * 21 + slot) * 3;
+            st_dev(xo + 0, ox); st_dev(xo + 1, oy); st_dev(xo + 2, oz);
+        }
+        __syncthreads();
+        if (tid < 228) {                  // 57 outputs x 4 quarters of 64 vertices, fixed order
+            const int o = tid % 57, q = tid / 57, j = o / 3, i = o - j * 3;
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int u = 0; u < 64; ++u) sacc = fmaf(J19s[j][q * 64 + u], outs[(q * 64 + u) * 3 + i], sacc);
+            part[q][o] = sacc;
+        }
+        __syncthreads();
+        if (tid < 57) st_dev(jpart + ((int64_t)b * SKB + blockIdx.x) * 57 + tid, ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid]);
+        if (more && tid < NJ * 3) AS[(c + 1) & 1][tid] = an;          // next crop's bone matrices (landed during the regression)
+        // arrival: this workgroup's device-scope stores for crop b have completed before it counts itself in
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(&cnt[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(SKB - 1);
+        __syncthreads();
+        if (s_last) {                     // all 27 workgroups of crop b have arrived: finish the crop
+            if (tid < 57) {               // J19 regressor: the partial sums of workgroups 0 .. 26 in order
+                float sacc = 0.f;
+                for (int k = 0; k < SKB; ++k) sacc += ld_dev(jpart + ((int64_t)b * SKB + k) * 57 + tid);
+                jo[25 + tid / 3][tid % 3] = sacc;
+            }
+            if (tid >= 64 && tid < 64 + 75) {
+                const int t = tid - 64, j = t / 3, i = t % 3;
+                const int src = jmap[j];
+                jo[j][i] = (src < NJ) ? Jtr[((int64_t)b * NJ + src) * 3 + i] : ld_dev(xv + ((int64_t)b * 21 + (src - NJ)) * 3 + i);
+            }
+            __syncthreads();
+            // SMPL(update_hips=True), smpl_wrapper.py:33-36, on the 25 mapped joints (before the extra joints are appended):
+            //   j[9,12] = (j[9,12] + 0.25*(j[9,12] - j[12,9])) + 0.5*(j[8] - 0.5*(j[9,12] + j[12,9]))
+            if (*update_hips && tid < 3) {
+                const float a = jo[9][tid], cc = jo[12][tid], m = jo[8][tid];
+                jo[9][tid] = (a + 0.25f * (a - cc)) + 0.5f * (m - 0.5f * (a + cc));
+                jo[12][tid] = (cc + 0.25f * (cc - a)) + 0.5f * (m - 0.5f * (cc + a));
+            }
+            __syncthreads();
+            if (tid < 132 && joints) joints[(int64_t)b * 132 + tid] = jo[tid / 3][tid % 3];
+            if (tid < 44 && kp2d && cam_t) {
+                const float px = jo[tid][0] + cam_t[b * 3 + 0], py = jo[tid][1] + cam_t[b * 3 + 1], pz = jo[tid][2] + cam_t[b * 3 + 2];
+                kp2d[((int64_t)b * 44 + tid) * 2 + 0] = (px / pz) * focal_over_size;
+                kp2d[((int64_t)b * 44 + tid) * 2 + 1] = (py / pz) * focal_over_size;
+            }
+            if (tid == 0) __hip_atomic_store(&cnt[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+        }
     }
 }
 
@@ -237,12 +284,13 @@ int launch_lbs_build_dirs(const float* sd, const float* pd, float* dirsT, hipStr
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-// scratch: A (B,24,12), xf (B, 224 + 27*57) [operand rows, then J19 partial sums], Jtr (B,24,3), vposed (B,20670)
+// scratch: A (B,24,12), xf (B, 224 + 27*57) [operand rows, then J19 partial sums], Jtr (B,24,3), vposed (B,20670),
+//          xv (B,21,3) picked extra-joint vertices, cnt (B) arrival counters (zero before the first call; the kernel re-zeroes them)
 int launch_lbs(const float* rotmat, const float* betas, const float* cam_t, const float* Jt, const float* Jsd,
                const int32_t* parents, const float* vt, const float* dirsT, const float* W, const float* J19,
                const int32_t* extra, const int32_t* jmap, const int32_t* update_hips, float* A, float* xf, float* Jtr,
-               float* vposed, float* verts,
-               float* joints, float* kp2d, float focal_over_size, int B, hipStream_t s) {
+               float* vposed, float* verts, float* joints, float* kp2d, float focal_over_size, int B, float* xv,
+               unsigned* cnt, hipStream_t s) {
     hipLaunchKernelGGL(lbs_prep_kernel, dim3(B), dim3(128), 0, s, rotmat, betas, Jt, Jsd, parents, A, xf, Jtr);
     GemmArgs g{};
     g.A = xf; g.lda = KX; g.W = dirsT; g.ldw = KX; g.bias = vt; g.resid = nullptr; g.ldr = 0;
@@ -250,8 +298,10 @@ int launch_lbs(const float* rotmat, const float* betas, const float* cam_t, cons
     if (int r = launch_gemm(g, EPI_BIAS, -1, s)) return r;
     // the J19 partial sums live behind the (B,224) operand rows in the xf scratch: B * 27 * 57 floats
     float* jpart = xf + (size_t)B * KX;
-    hipLaunchKernelGGL(lbs_skin_kernel, dim3(SKB, B), dim3(256), 0, s, vposed, W, A, J19, verts, jpart);
-    hipLaunchKernelGGL(lbs_joints_kernel, dim3(B), dim3(256), 0, s, verts, Jtr, jpart, extra, jmap, update_hips, cam_t, joints, kp2d,
-                       focal_over_size);
+    // crops per workgroup pass: reuse of the per-vertex constants only pays once the grid already fills the chip several times
+    // (64 crops: 2 -> 864 workgroups; 256 crops and up: 8)
+    const int cg = B >= 32 * CG_MAX ? CG_MAX : (B >= 32 ? B / 32 : 1);
+    hipLaunchKernelGGL(lbs_skin_joints_kernel, dim3(SKB, (B + cg - 1) / cg), dim3(256), 0, s, vposed, W, A, J19, Jtr, extra, jmap,
+                       update_hips, cam_t, verts, jpart, xv, cnt, joints, kp2d, focal_over_size, B, cg);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

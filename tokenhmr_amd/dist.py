@@ -33,8 +33,22 @@ def shard_sizes(total: int, world: int):
 
 
 def pack_records(o):
-    """dict of per-crop tensors (engine output) -> (B, RECORD_WORDS) float32."""
+    """dict of per-crop tensors (engine output) -> (B, RECORD_WORDS) float32.  On the GPU this is ONE launch of the library's
+    pack kernel (thmr_pack_records, the same call a non-torch host makes); CPU tensors (gloo tests) are concatenated."""
     B = o["pred_cam"].shape[0]
+    if o["pred_cam"].is_cuda:
+        import ctypes as C
+        from . import _cabi
+        lib = _cabi.load()
+        ts = {name: o[name].contiguous() for name, _ in RECORD_FIELDS}
+        st = _cabi.Outputs(**{k: (ts[k].data_ptr() if k in ts else None) for k in _cabi.OUTPUT_FIELDS})
+        dev = o["pred_cam"].device
+        rec = torch.empty(B, RECORD_WORDS, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.thmr_pack_records(C.byref(st), B, C.c_void_p(rec.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise _cabi.EngineError(f"thmr_pack_records: {lib.thmr_collective_last_error().decode()}")
+        return rec
     parts = []
     for name, n in RECORD_FIELDS:
         t = o[name]
