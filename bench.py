@@ -323,6 +323,8 @@ def main():
     step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps)) if ev else []
     eng.prof_enable(False)
     prof = eng.prof_collect()
+    if not cpu_dry:
+        eng.status()            # no asynchronous device-side error in the timed region (bounded grid barrier of the decoder kernel)
     prof_all, breakdown_steps = {}, 0
     if not a.no_extras and not cpu_dry:
         breakdown_steps = min(2, a.steps)
