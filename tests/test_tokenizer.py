@@ -82,4 +82,10 @@ def test_gpu_encode_and_decode(built_lib, cuda_dev):
     with torch.no_grad():
         ref = O.vq_decode(soft, tok, cfg)
     assert (eng.vq_decode(soft).cpu() - ref).abs().max() < 1e-4
+    # an engine that RECEIVED the arena (broadcast, or a shared arena) and only finalised it can encode too: "the encoder tensors
+    # are present" travels with the arena as a flag word (round 1 kept it host-side, so broadcast receivers could not encode)
+    e2 = Engine(cfg, max_batch=8, device=cuda_dev, weight_arena=eng.weight_arena)
+    e2.finalize(assume_all_loaded=True)
+    assert torch.equal(e2.encode_tokens(pose), idx)
+    e2.close()
     eng.close()
