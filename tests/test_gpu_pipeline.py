@@ -219,3 +219,41 @@ def test_head_regimes_agree_and_persistent_decoders_coexist(built_lib, cuda_dev)
     for a, b in outs:
         for k in ("pred_vertices", "token_idx", "pred_cam"):
             assert torch.equal(a[k], small[k]) and torch.equal(b[k], small[k]), k
+
+
+def test_fused_head_equals_chain_head_across_batch_sizes(built_lib, cuda_dev, monkeypatch):
+    """The persistent decoder kernel picks its grid from the batch (64 workgroups up to 16 crops, 128 / 192 / 256 above) and
+    deals (column tile x 16-row sub-tile) items over it; the mixer kernel runs one workgroup per crop.  For batch sizes on both
+    sides of every boundary — 1, 15, 16, 17, 33, 48, 49, 64, 100, 128 (ragged last sub-tiles included) — the fused head must
+    agree with the chain-of-GEMMs head (THMR_LEGACY_HEAD=1: same maths as separate tiled launches, the round-1 path) to fp32
+    summation-order differences, be deterministic, and give a crop the same bits whatever batch it rides in."""
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd import weights as W
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    from tokenhmr_amd.engine import Engine
+    cfg = HMRConfig(vit_depth=1, dec_depth=6)
+    sd, tok, smpl = W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0), make_synthetic_smpl(cfg, 0)
+    fused = Engine(cfg, max_batch=128, device=cuda_dev)
+    fused.load_state(sd, tok)
+    fused.load_smpl(smpl)
+    fused.finalize()
+    monkeypatch.setenv("THMR_LEGACY_HEAD", "1")          # read once, at thmr_create
+    chain = Engine(cfg, max_batch=128, device=cuda_dev, weight_arena=fused.weight_arena)
+    chain.finalize(assume_all_loaded=True)
+    monkeypatch.delenv("THMR_LEGACY_HEAD")
+    ctx = torch.randn(128, 192, 1280, generator=torch.Generator().manual_seed(12)).to(cuda_dev)
+    keys = ("token_out", "cls_logits", "pose6d", "pred_vertices", "pred_cam")
+    ref128 = {k: v.clone() for k, v in fused.head_forward(ctx, taps=True).items()}
+    for B in (1, 15, 16, 17, 33, 48, 49, 64, 100, 128):
+        a = {k: v.clone() for k, v in fused.head_forward(ctx[:B], taps=True).items()}
+        b = fused.head_forward(ctx[:B], taps=True)
+        c = chain.head_forward(ctx[:B], taps=True)
+        for k in keys:
+            assert torch.equal(a[k], b[k]), (B, k)                                   # deterministic
+            assert torch.equal(a[k], ref128[k][:B]), (B, k)                          # batch-invariant within the fused regime
+        assert (a["token_out"] - c["token_out"]).abs().max() < 1e-4, B
+        assert (a["cls_logits"] - c["cls_logits"]).abs().max() < 1e-4, B
+        assert (a["pred_vertices"] - c["pred_vertices"]).abs().max() < 1e-5, B
+        assert (a["token_idx"] != c["token_idx"]).float().mean() < 0.01, B           # only near-tie tokens may differ between regimes
+    fused.status()
+    chain.status()

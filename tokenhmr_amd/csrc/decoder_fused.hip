@@ -9,17 +9,19 @@
 // layer is a chain of 7 such products each of which needs the FULL rows of its predecessor: 42 strictly dependent steps that
 // move 96 MB of weights (12 us of HBM time) and ~3 GFLOP.  Round 1 ran them as ~70 separate launches of 5-30 us each
 // (0.8 ms per 64 crops, profiles/r1_kernel_stats.csv): the time was launch-to-launch latency and per-kernel load latency,
-// not work.  Here 64 workgroups of 8 waves stay resident for the whole decoder and meet at a grid barrier between steps:
-//   * a step = every workgroup owns 16 output columns for ALL crops (64 rows per pass, v_mfma_f32_16x16x4_f32); its 8 waves
-//     split K 8 ways, so a wave's whole share of the weight stream (<= 8 x 16-byte loads per lane) is issued up front and the
-//     step costs ~one memory round trip; the 8 partial tiles are summed through LDS in a FIXED order (deterministic, and a
+// not work.  Here 64 ... 256 workgroups of 8 waves stay resident for the whole decoder and meet at a grid barrier between steps:
+//   * a step's work items are (16-column tile x 16-row sub-tile), dealt over as many workgroups as there are items (what bounds a
+//     step is bytes per CU: ~30 GB/s of misses each); the 8 waves of a workgroup split K 8 ways (v_mfma_f32_16x16x4_f32), so a
+//     wave's whole share of the weight stream (<= 8 x 16-byte loads per lane) and of the activations is requested up front and
+//     the step costs ~one memory round trip; the 8 partial tiles are summed through LDS in a FIXED order (deterministic, and a
 //     crop's result does not depend on the batch it rides in);
-//   * LayerNorm is the prologue of the step that consumes it: row statistics (same two-pass arithmetic and order as
-//     ln_wave_kernel) are recomputed per workgroup from the L2-resident rows and applied to the A fragments in registers;
-//   * cross-attention is one wave per (crop, head): coalesced 256-byte K / V rows, scores in registers, 16-lane reductions;
-//   * the grid barrier is flag based with no cache maintenance; the activations that cross it use device-scope atomics.  It needs all 64 workgroups resident: 64 x 512 threads
-//     with 33 KB LDS fit an eighth of the chip, several such kernels can coexist (two engines on two streams), and the spin
-//     is BOUNDED: on timeout the kernel sets an error word and exits instead of hanging the GPU.
+//   * LayerNorm is the prologue of the step that consumes it and reads its input ONCE: two-pass row statistics from the A
+//     fragments already in registers (per-wave partial sums exchanged through LDS, fixed wave order);
+//   * cross-attention is one wave per (crop, head): coalesced 256-byte K / V rows, 3 scores per lane, 16-lane reductions;
+//   * the grid barrier is flag based with no read-modify-write and no cache maintenance; the activations that cross it use
+//     device-scope atomics.  It needs all workgroups resident: at most one 512-thread workgroup per CU, several such kernels of
+//     different engines are chained by the host (engine.hip launch_decoder_serialised), and the poll is BOUNDED: on timeout the
+//     kernel sets an error word (thmr_engine_status) and exits instead of hanging the GPU.
 #include "common.h"
 
 namespace {
