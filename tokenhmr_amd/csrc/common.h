@@ -196,6 +196,7 @@ struct DecParams {
     int64_t ldkv;
     int depth, B;
     int timeline;                                     // 1: workgroup 0 stamps the wall clock into sync[16..] (diagnostics)
+    int max_blocks;                                   // compute units of the device: at most one workgroup per CU is launched
 };
 
 int launch_decoder_fused(const DecParams& p, hipStream_t s);

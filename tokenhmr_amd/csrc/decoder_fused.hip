@@ -446,7 +446,12 @@ __global__ __launch_bounds__(NWAVE * 64) void decoder_persistent_kernel(DecParam
 int launch_decoder_fused(const DecParams& p, hipStream_t s) {
     if (p.B < 1 || p.depth < 1 || p.depth > 6) return -1;
     // one workgroup per (column tile, 16-row sub-tile) of the widest step, up to one per CU
-    const int nsub = (p.B + 15) / 16, grid = NBLK * (nsub < 4 ? nsub : 4);
+    // (the grid barrier needs every workgroup resident: never more workgroups than the device has CUs; any grid size works,
+    // the steps deal their items round-robin)
+    const int nsub = (p.B + 15) / 16;
+    int grid = NBLK * (nsub < 4 ? nsub : 4);
+    if (p.max_blocks > 0 && grid > p.max_blocks) grid = p.max_blocks;
+    if (grid > 256) grid = 256;                  // workgroup 0 polls one arrival flag per thread pair at most; flags[256]
     hipLaunchKernelGGL(decoder_persistent_kernel, dim3(grid), dim3(NWAVE * 64), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -930,6 +930,11 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
         d.sync = reinterpret_cast<unsigned*>(e->S(e->so.sync));
         d.depth = e->dec_depth; d.B = 0;
         { const char* tl = getenv("THMR_DEC_TIMELINE"); d.timeline = tl && tl[0] == '1'; }
+        {
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device) != hipSuccess || cus < 1) cus = 64;
+            d.max_blocks = cus;
+        }
         MixerParams& m = e->mix;
         const std::string C = "smpl_head.decpose.";
         for (int i = 0; i < MIX; ++i) {
