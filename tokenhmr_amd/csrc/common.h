@@ -31,6 +31,16 @@ struct GemmArgs {
     int M, N, K;
     float qscale;
     int qcols;
+    // optional: ALSO write the result as the im2col operand of the Conv1d(k = 3, padding = dilation) that consumes it, so the
+    // VQ decoder needs no gather launches (vanilla_pose_vqvae.py:135-154: nearest resample -> Conv1d; resnet.py:55-68).
+    //   rows of C are (crop b, position ts), ts < cs_tin; the consumer works on cs_tout resampled positions tp, tp = cs_inv[ts]
+    //   (-1: this position is dropped by the resample; cs_inv == nullptr: identity); element (b, tp, n) is tap dk of gathered
+    //   row t = tp - (dk - 1) * cs_dil:  cs_out[(b * cs_tout + t) * 3N + dk * N + n] = f(v), f = ReLU if cs_relu (pre-activation
+    //   ResConv1DBlock); the taps that fall outside [0, cs_tout) are written as zeros by the row that owns them.
+    //   C may be nullptr when only the gathered copy is needed.
+    float* cs_out;
+    const int32_t* cs_inv;
+    int cs_tin, cs_tout, cs_dil, cs_relu;
 };
 
 // Branch-free fp32 erf, < 1.5 ulp over the whole line (tests/test_gpu_ops.py::test_gelu_epilogue_ulp): two minimax

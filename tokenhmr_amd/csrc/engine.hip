@@ -79,7 +79,7 @@ struct thmr_engine {
     // derived / constant regions (float offsets in weight arena)
     size_t o_kv_all = 0, o_ro_w = 0, o_ro_b = 0;
     size_t o_convp[7] = {0};      // repacked k=3 convs: 0,3,6,9,12, res0.conv1, res1.conv1, 14.1, 15 -> see conv_names
-    size_t o_cbT = 0, o_cnorm = 0, o_idx = 0;   // idx tables as int32 within the float arena
+    size_t o_cbT = 0, o_cnorm = 0, o_idx = 0, o_inv = 0;   // idx / inverse idx tables as int32 within the float arena
     size_t o_smpl_vt = 0, o_smpl_sd = 0, o_smpl_pd = 0, o_smpl_jr = 0, o_smpl_w = 0, o_smpl_j19 = 0, o_smpl_int = 0,
            o_smpl_jt = 0, o_smpl_jsd = 0, o_smpl_dirs = 0;
     std::vector<size_t> convp;    // repacked conv offsets, index by conv id
@@ -89,14 +89,14 @@ struct thmr_engine {
     size_t o_idx_enc = 0, o_flags = 0;
     bool enc_ready = false;
     int32_t flag_host = 0, hips_host = 0;
-    std::vector<int32_t> idx_host, eidx_host;   // staging for the index tables (must outlive the async copy)
+    std::vector<int32_t> idx_host, eidx_host, inv_host;   // staging for the index tables (must outlive the async copy)
     int vq_len[5] = {160, 125, 90, 55, 21};
     // scratch offsets (floats)
     struct {
         size_t x, h, big, part;
         size_t dx, dh, dv, dq, dca, dff, ro;
         size_t mt, cf, cf2, y1, tT, u, yt, y, s, z0, zh, nl, nl2;
-        size_t feat, gat, act0, act1, act2, bpose, tokidx, sync;
+        size_t feat, gat, gat2, act0, act1, act2, bpose, tokidx, sync;
         size_t A, pf, Jtr, vposed, rot, betas, cam, camt, verts, joints, pose6d, xv, lcnt;
         size_t total;
     } so{};
@@ -280,6 +280,7 @@ void layout_weights(thmr_engine* e) {
     e->o_cbT = off;   off = align64(off + (size_t)NCLS * CODE);
     e->o_cnorm = off; off = align64(off + NCLS);
     e->o_idx = off;   off = align64(off + 4 * 160);
+    e->o_inv = off;   off = align64(off + 4 * 160);
     // SMPL constants
     e->o_smpl_vt = off;  off = align64(off + (size_t)NV * 3);
     e->o_smpl_sd = off;  off = align64(off + (size_t)NV * 30);
@@ -327,7 +328,8 @@ void layout_scratch(thmr_engine* e) {
     s.y = take(B * TN * HID); s.s = take(B * TN * HID); s.z0 = take(B * TN * HID); s.zh = take(B * TN * HID_INTER);
     s.nl = take(B * TN * HID); s.nl2 = take(B * TN * HID);
     s.feat = take(B * TN * CODE);
-    s.gat = take(B * 125 * 3 * VQW);                 // largest gather: T=125, 3*512 (> 160*768)
+    s.gat = take(B * 125 * 3 * VQW);                 // largest conv operand: T=125, 3*512 (> 160*768)
+    s.gat2 = take(B * 125 * 3 * VQW);                // the GEMM of conv i writes the operand of conv i+1: two buffers alternate
     s.act0 = take(B * TN * VQW); s.act1 = take(B * TN * VQW); s.act2 = take(B * TN * VQW);
     s.bpose = take(B * 128); s.tokidx = take(B * TN); s.sync = take(512);
     s.A = take(B * NJ * 12); s.pf = take(B * THMR_LBS_XF); s.Jtr = take(B * NJ * 3); s.vposed = take(B * NV * 3);
@@ -458,51 +460,70 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
 int launch_decoder_serialised(thmr_engine* e, const DecParams& d, hipStream_t st);   // below (decoder turnstile)
 
 // ---------------------------------------------------------------------------------------------- head
-int conv3(thmr_engine* e, int conv_id, const float* in, int Tin, int Tout, const int32_t* src, int dil, int prerelu,
-          const float* bias, int epi, const float* resid, float* outp, int B, hipStream_t st) {
-    const int ci = kConv3Ci[conv_id], co = kConv3Co[conv_id];
-    float* gat = e->S(e->so.gat);
-    LAUNCH_OK(launch_conv3_gather(in, gat, src, B, Tin, Tout, ci, dil, prerelu, st));
-    GemmArgs a = mk(gat, 3 * ci, e->warena + e->convp[conv_id], 3 * ci, bias, resid, co, outp, co, B * Tout, co, 3 * ci);
-    LAUNCH_OK(launch_gemm(a, epi, -1, st));
-    return 0;
-}
-
 // DecodeTokens.forward (tokenization/models/vanilla_pose_vqvae.py:294-297): soft codebook lookup
 // (quantize_cnn.py:92-93 dequantize_logits) + PoseSPDecoderV1 (:135-154).  probs (B,160,2048) -> bpose (B,21,6).
+// 12 GEMMs and nothing else: every Conv1d(k = 3) is a GEMM over an im2col operand (B*T, 3*C) that the PREVIOUS GEMM's epilogue
+// wrote (GemmArgs::cs_*: nearest-resample + taps + zero padding + the ResConv pre-activation ReLU), so no gather launch exists.
 int vq_decode(thmr_engine* e, const float* probs, int B, float* bpose, hipStream_t st) {
     auto& so = e->so;
-    const int R = B * TN;
-    // soft codebook lookup: probs @ codebook (quantize_cnn.py:92-93) as a GEMM against codebook^T
-    float* feat = e->S(so.feat);
-    {
-        GemmArgs a = mk(probs, NCLS, e->warena + e->o_cbT, NCLS, nullptr, nullptr, 0, feat, CODE, R, CODE, NCLS);
+    float* G[2] = {e->S(so.gat), e->S(so.gat2)};          // conv operands, alternating
+    float *x0 = e->S(so.act0), *x1 = e->S(so.act1), *hid = e->S(so.act2);
+    const int32_t* inv = reinterpret_cast<const int32_t*>(e->warena + e->o_inv);
+    const std::string d = "decoder.decoder.";
+    // what the consumer conv needs from its producer
+    auto scatter = [&](GemmArgs& a, float* dst, const int32_t* table, int tin, int tout, int dil, int relu) {
+        a.cs_out = dst; a.cs_inv = table; a.cs_tin = tin; a.cs_tout = tout; a.cs_dil = dil; a.cs_relu = relu;
+    };
+    // the conv itself: operand (B*T, 3*ci) x repacked weight (co, 3*ci)
+    auto conv = [&](int id, const float* opnd, int T, const float* bias, float* plain) {
+        const int ci = kConv3Ci[id], co = kConv3Co[id];
+        return mk(opnd, 3 * ci, e->warena + e->convp[id], 3 * ci, bias, nullptr, 0, plain, co, B * T, co, 3 * ci);
+    };
+    {   // soft codebook lookup: probs @ codebook as a GEMM against codebook^T -> operand of decoder.0 (T = 160, C = 256)
+        GemmArgs a = mk(probs, NCLS, e->warena + e->o_cbT, NCLS, nullptr, nullptr, 0, nullptr, CODE, B * TN, CODE, NCLS);
+        scatter(a, G[0], nullptr, 160, 160, 1, 0);
         LAUNCH_OK(launch_gemm(a, EPI_NONE, -1, st));
     }
-    // VQ decoder (vanilla_pose_vqvae.py:135-154), channels-last (B,T,C)
-    float *a0 = e->S(so.act0), *a1 = e->S(so.act1), *a2 = e->S(so.act2);
-    const int32_t* idxt = reinterpret_cast<const int32_t*>(e->warena + e->o_idx);
-    const std::string d = "decoder.decoder.";
-    if (int r = conv3(e, 0, feat, 160, 160, nullptr, 1, 0, e->W(d + "0.bias"), EPI_BIAS_RELU, nullptr, a0, B, st)) return r;
+    int cur = 0;
+    {   // decoder.0: Conv1d(256 -> 512) + ReLU at T = 160 -> operand of decoder.3 on the 160 -> 125 resample
+        GemmArgs a = conv(0, G[cur], 160, e->W(d + "0.bias"), nullptr);
+        scatter(a, G[cur ^ 1], inv + 0 * 160, 160, e->vq_len[1], 1, 0);
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS_RELU, -1, st));
+        cur ^= 1;
+    }
     const char* up_bias[] = {"3.bias", "6.bias", "9.bias", "12.bias"};
-    float* cur = a0;
-    float* nxt = a1;
-    for (int i = 0; i < 4; ++i) {
-        if (int r = conv3(e, 1 + i, cur, e->vq_len[i], e->vq_len[i + 1], idxt + i * 160, 1, 0, e->W(d + up_bias[i]),
-                          EPI_BIAS_RELU, nullptr, nxt, B, st)) return r;
-        std::swap(cur, nxt);
+    for (int i = 0; i < 4; ++i) {   // decoder.3/6/9/12: nn.Upsample(size) (a down-sampling here) + Conv1d(512 -> 512) + ReLU
+        const int T = e->vq_len[i + 1];
+        GemmArgs a = conv(1 + i, G[cur], T, e->W(d + up_bias[i]), i == 3 ? x0 : nullptr);
+        if (i < 3) scatter(a, G[cur ^ 1], inv + (i + 1) * 160, T, e->vq_len[i + 2], 1, 0);
+        else scatter(a, G[cur ^ 1], nullptr, VQJ, VQJ, 3, 1);      // -> ResConv1DBlock 0 (dilation 3, pre-activation ReLU); x0 kept as its residual
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS_RELU, -1, st));
+        cur ^= 1;
     }
     const int Tq = VQJ;
-    for (int blk = 0; blk < 2; ++blk) {   // ResConv1DBlock, resnet.py:49-69 (dilation 3 then 1)
+    float* res = x0;
+    float* nres = x1;
+    for (int blk = 0; blk < 2; ++blk) {   // ResConv1DBlock, resnet.py:49-69: x + conv2(relu(conv1(relu(x)))), dilation 3 then 1
         const std::string p = d + "14.0.model." + std::to_string(blk) + ".";
-        const int dil = blk == 0 ? 3 : 1;
-        if (int r = conv3(e, 5 + blk, cur, Tq, Tq, nullptr, dil, 1, e->W(p + "conv1.bias"), EPI_BIAS_RELU, nullptr, a2, B, st)) return r;
-        GemmArgs a = mk(a2, VQW, e->W(p + "conv2.weight"), VQW, e->W(p + "conv2.bias"), cur, VQW, nxt, VQW, B * Tq, VQW, VQW);
+        {
+            GemmArgs a = conv(5 + blk, G[cur], Tq, e->W(p + "conv1.bias"), hid);
+            LAUNCH_OK(launch_gemm(a, EPI_BIAS_RELU, -1, st));
+        }
+        GemmArgs a = mk(hid, VQW, e->W(p + "conv2.weight"), VQW, e->W(p + "conv2.bias"), res, VQW, blk == 0 ? nres : nullptr, VQW, B * Tq, VQW, VQW);
+        // block 0 feeds block 1's conv1 (pre-activation ReLU) and stays its residual; block 1 feeds decoder.14.1 (no activation)
+        scatter(a, G[cur ^ 1], nullptr, Tq, Tq, 1, blk == 0 ? 1 : 0);
         LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, -1, st));
-        std::swap(cur, nxt);
+        cur ^= 1;
+        std::swap(res, nres);
     }
-    if (int r = conv3(e, 7, cur, Tq, Tq, nullptr, 1, 0, e->W(d + "14.1.bias"), EPI_BIAS, nullptr, nxt, B, st)) return r;
-    if (int r = conv3(e, 8, nxt, Tq, Tq, nullptr, 1, 0, e->W(d + "15.bias"), EPI_BIAS, nullptr, bpose, B, st)) return r;
+    {   // decoder.14.1: Conv1d(512 -> 512) -> operand of decoder.15
+        GemmArgs a = conv(7, G[cur], Tq, e->W(d + "14.1.bias"), nullptr);
+        scatter(a, G[cur ^ 1], nullptr, Tq, Tq, 1, 0);
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
+        cur ^= 1;
+    }
+    GemmArgs a = conv(8, G[cur], Tq, e->W(d + "15.bias"), bpose);    // decoder.15: Conv1d(512 -> 6): the 21 x 6D body pose
+    LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
     return 0;
 }
 
@@ -666,6 +687,11 @@ void build_idx_tables(thmr_engine* e) {
             e->idx_host[i * 160 + t] = sidx < tin - 1 ? sidx : tin - 1;
         }
     }
+    // inverse tables of the decoder's four down-samplings: position ts of the producer -> the resampled position tp that reads it
+    // (src is strictly increasing, so at most one), -1 = dropped.  Used by the GEMM epilogue that writes the next conv's operand.
+    e->inv_host.assign(4 * 160, -1);
+    for (int i = 0; i < 4; ++i)
+        for (int t = 0; t < e->vq_len[i + 1]; ++t) e->inv_host[i * 160 + e->idx_host[i * 160 + t]] = t;
     // encoder: nn.Upsample(size=40) from 21 (offset 0), then three nn.Upsample(scale_factor=2)
     // (ATen uses scale 1/scale_factor = 0.5: src = floor(dst*0.5)): 40->80 (offset 40), 80->160 (120), 160->320 (280)
     e->eidx_host.assign(640, 0);
@@ -860,6 +886,7 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
         // regions of the arena that are not checkpoint tensors: index tables, the (finite) padding row of the read-out matrix
         build_idx_tables(e);
         HIP_OK(hipMemcpyAsync(e->warena + e->o_idx, e->idx_host.data(), e->idx_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(e->warena + e->o_inv, e->inv_host.data(), e->inv_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         HIP_OK(hipMemcpyAsync(e->warena + e->o_idx_enc, e->eidx_host.data(), e->eidx_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         HIP_OK(hipMemsetAsync(e->warena + e->o_ro_w + (size_t)31 * E, 0, E * sizeof(float), st));
     }

@@ -199,6 +199,41 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, f32x16 (&acc)[TM][
     }
 }
 
+// Epilogue that also scatters the tile into the NEXT Conv1d's im2col operand (GemmArgs::cs_*).  Element-wise and bounds-checked:
+// it only runs on the VQ decoder's small GEMMs (M = 21 ... 160 rows per crop), where it replaces one gather launch per conv.
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void store_tile_scatter(const GemmArgs& a, f32x16 (&acc)[TM][TN], int m0, int n0, int lrow, int lhalf) {
+    const int64_t ld3 = (int64_t)3 * a.N;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + mi * 32 + 4 * lhalf + (e & 3) + 8 * (e >> 2);
+            if (m >= a.M) continue;
+            const int b = m / a.cs_tin, ts = m - b * a.cs_tin;
+            const int tp = a.cs_inv ? a.cs_inv[ts] : ts;
+            float* g = a.cs_out + (int64_t)b * a.cs_tout * ld3;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + ni * 32 + lrow;
+                if (n >= a.N) continue;
+                float bias = 0.f;
+                if constexpr (EPI != EPI_NONE) bias = a.bias[n];
+                const float v = gemm_epilogue<EPI>(a, acc[mi][ni][e], bias, m, n);
+                if (a.C) a.C[(int64_t)m * a.ldc + n] = v;
+                if (tp < 0) continue;
+                const float f = a.cs_relu ? fmaxf(v, 0.f) : v;
+                float* gn = g + n;
+                if (tp + a.cs_dil < a.cs_tout) gn[(int64_t)(tp + a.cs_dil) * ld3] = f;                 // tap 0 of row tp + dil
+                else gn[(int64_t)tp * ld3 + 2 * a.N] = 0.f;                                             // own tap 2 is padding
+                gn[(int64_t)tp * ld3 + a.N] = f;                                                        // tap 1 of row tp
+                if (tp - a.cs_dil >= 0) gn[(int64_t)(tp - a.cs_dil) * ld3 + 2 * a.N] = f;               // tap 2 of row tp - dil
+                else gn[(int64_t)tp * ld3] = 0.f;                                                        // own tap 0 is padding
+            }
+        }
+    }
+}
+
 // DMA = true: global_load_lds staging; DMA = false: register staging
 // ABL (timing-only experiments, results are garbage): bit0 no DMA copies in the loop, bit1 no per-tile barrier,
 // bit2 no LDS fragment reads.  ABL = 0 is the product kernel.
@@ -451,6 +486,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
         for (int kt = 0; kt < nk; ++kt) ktile(kt, kt & 1);
     }
 
+    if constexpr (EPI != EPI_BIAS_POS && EPI != EPI_BIAS_QSCALE) {
+        if (a.cs_out) {                     // wave-uniform
+            store_tile_scatter<TM, TN, EPI>(a, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
+            return;
+        }
+    }
     store_tile<TM, TN, EPI>(a, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
 }
 
@@ -576,6 +617,12 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs a, int tiles_m,
         pa.ldc = a.N;
         store_tile<1, 1, EPI_NONE>(pa, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
     } else {
+        if constexpr (EPI != EPI_BIAS_POS && EPI != EPI_BIAS_QSCALE) {
+            if (a.cs_out) {
+                store_tile_scatter<1, 1, EPI>(a, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
+                return;
+            }
+        }
         store_tile<1, 1, EPI>(a, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
     }
 }
