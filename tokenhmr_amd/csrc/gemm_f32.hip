@@ -71,13 +71,13 @@ __device__ __forceinline__ void dma_wait_barrier() { asm volatile("s_waitcnt vmc
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
-// XCD-aware logical tile id (bijective for any grid size) -> (tile_m, tile_n), grouped GM tile-rows at a time
-__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
-    const int nwg = tiles_m * tiles_n;
+// XCD-aware logical tile id (bijective on [0, nwg) for any launch size nwg, offset by the launch's first tile) -> (tile_m, tile_n),
+// grouped GM tile-rows at a time
+__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int nwg, int base, int& tile_m, int& tile_n) {
     const int bid = blockIdx.x;
     const int xcd = bid & 7, within = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    const int logical = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
     constexpr int GM = 8;
     const int per_group = GM * tiles_n;
     const int group = logical / per_group;
@@ -243,7 +243,7 @@ __device__ __forceinline__ void store_tile_scatter(const GemmArgs& a, f32x16 (&a
 #define THMR_GEMM_BARPOS 0
 #endif
 template <int WM, int WN, int TM, int TN, bool DMA, int EPI, int ABL = 0, int DSP = 0, int BARPOS = THMR_GEMM_BARPOS>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int tiles_m, int tiles_n, int nwg, int tile_base) {
     constexpr int NW = WM * WN;
     constexpr int NT = NW * 64;
     constexpr int BM = WM * TM * 32;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
     float* Bs = smem + 2 * BM * LDK;     // [2][BN][LDK]
 
     int tile_m, tile_n;
-    tile_coords(tiles_m, tiles_n, tile_m, tile_n);
+    tile_coords(tiles_m, tiles_n, nwg, tile_base, tile_m, tile_n);
     const int bm0 = tile_m * BM, bn0 = tile_n * BN;
 
     const int tid = threadIdx.x;
@@ -653,14 +653,33 @@ int launch_ring(const GemmArgs& a, int epi, int ksplit, float* part, hipStream_t
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// The trailing part of a grid that does not fill the 512 resident slots (2 blocks per CU) a whole number of times.  Up to 256
+// trailing tiles are best run ONE per CU (a block that is alone on its CU runs almost twice as fast: 0.5 round), but inside one
+// launch the dispatcher hands them to whichever slots free up first, and the two co-resident blocks of a CU retire together: that
+// CU takes two trailing tiles while another idles (scripts/micro/dispatch_map.hip).  Whether it happens is chaotic — the 768-tile
+// proj grid at 64 crops ran 287 us in every build of round 1 and 375 us (2 full rounds) after an unrelated change to the epilogue
+// code of round 2 (profiles/r2k_proj_tail_dispatch.log), the bimodal B = 16 fc1 of round 1 is the same thing.  So such a tail is
+// launched SEPARATELY with 16 KB of (unused) dynamic LDS on top of the kernel's 72 KB: two of those blocks cannot share a CU, the
+// dispatcher must spread them one per CU.  Same tiles, same arithmetic, results unchanged.
+constexpr int kSlots = 512, kTailLds = 16 * 1024;
+
 template <int WM, int WN, int TM, int TN, bool DMA>
 int launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-    dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
-#define THMR_GEMM_CASE(E)                                                                                      \
-    case E:                                                                                                    \
-        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, DMA, E>), grid, block, 0, s, a, tiles_m, tiles_n); \
+    const int tiles = tiles_m * tiles_n;
+    // separate tail launch only for the 128-row LDS-DMA tiles whose static LDS (> 64 KB) + 16 KB exceeds half a CU
+    constexpr bool kCanIsolate = DMA && 2 * (BM + BN) * LDK * 4 + kTailLds > 80 * 1024;
+    const int tail = tiles % kSlots;
+    const bool isolate = kCanIsolate && tiles > kSlots && tail > 0 && tail <= kSlots / 2;
+    const int main_tiles = isolate ? tiles - tail : tiles;
+    dim3 block(WM * WN * 64);
+#define THMR_GEMM_CASE(E)                                                                                                               \
+    case E:                                                                                                                             \
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, DMA, E>), dim3(main_tiles), block, 0, s, a, tiles_m, tiles_n, main_tiles, 0); \
+        if (isolate)                                                                                                                    \
+            hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, DMA, E>), dim3(tail), block, kTailLds, s, a, tiles_m, tiles_n, tail,      \
+                               main_tiles);                                                                                             \
         break;
     switch (epi) {
         THMR_GEMM_CASE(EPI_NONE)
@@ -680,7 +699,7 @@ int launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
 template <int ABL, int DS = 0, int BARPOS = 0>
 int launch_abl(const GemmArgs& a, hipStream_t s) {
     const int tiles_m = (a.M + 127) / 128, tiles_n = (a.N + 159) / 160;
-    hipLaunchKernelGGL((gemm_f32_kernel<4, 1, 1, 5, true, EPI_NONE, ABL, DS, BARPOS>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_f32_kernel<4, 1, 1, 5, true, EPI_NONE, ABL, DS, BARPOS>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_m, tiles_n, tiles_m * tiles_n, 0);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 #endif
