@@ -252,3 +252,39 @@ def test_gemm_k_loops_carry_no_valu_instruction(built_lib, tmp_path):
                     (sym, seg[max(0, i - 3):i + 1])
         m0_writers = [x for x in seg if re.match(r"m0\b", x[2]) and x[1].startswith("s_")]
         assert len(m0_writers) == len(dma), (sym, len(m0_writers), len(dma))
+
+
+def test_attention_lds_dma_copies_keep_their_m0(built_lib, tmp_path):
+    """The attention kernel issues its K / V copies through the same inline-assembly saddr LDS-DMA as the GEMM (attention.hip
+    dma16_saddr): M0 is written inside the asm and cannot be declared, so — on every toolchain bump — check at the ISA level that each
+    global_load_lds of every attention instantiation is immediately preceded by its own `s_mov_b32 m0` + `s_nop`, that the copies are
+    the saddr form (uniform 64-bit base in SGPRs), and that nothing else in the kernel writes M0."""
+    import glob
+    import re
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    obj = os.path.join(os.path.dirname(_cabi.LIB_PATH), "attention.o")
+    if not (os.path.exists(objdump) and os.path.exists(obj)):
+        pytest.skip("llvm-objdump or the attention object file is not available")
+    work = str(tmp_path / "attention.o")
+    shutil.copy(obj, work)
+    subprocess.run([objdump, "-d", "--offloading", work], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=str(tmp_path), check=False)
+    cos = glob.glob(work + "*gfx950*")
+    assert cos, "no gfx950 code object inside attention.o"
+    text = subprocess.run([objdump, "-d", cos[0]], capture_output=True, text=True, check=True).stdout.split("\n")
+    starts = [i for i, l in enumerate(text) if re.match(r"^[0-9a-f]+ <.*vit_attention_kernel", l)]
+    assert len(starts) >= 2
+    for st in starts:
+        end = next(i for i in range(st, len(text)) if "s_endpgm" in text[i])
+        ins = []
+        for l in text[st:end + 1]:
+            m = re.match(r"\s+(\S+)\s+(.*?)\s*//", l)
+            if m:
+                ins.append((m.group(1), m.group(2)))
+        dma = [i for i, (op, _) in enumerate(ins) if op.startswith("global_load_lds")]
+        assert len(dma) >= 8, (text[st], len(dma))
+        for i in dma:
+            assert ins[i - 1][0] == "s_nop" and ins[i - 2][0] == "s_mov_b32" and ins[i - 2][1].startswith("m0,"), ins[i - 3:i + 1]
+            assert re.search(r"s\[\d+:\d+\]", ins[i][1]), ins[i]
+        assert sum(1 for op, a in ins if op.startswith("s_") and re.match(r"m0\b", a)) == len(dma)

@@ -72,6 +72,11 @@ struct thmr_engine {
     std::vector<VitBlockW> vitw;      // filled by thmr_finalize_weights
     DecParams dec{};                  // decoder weight pointers + scratch, resolved once (finalize)
     MixerParams mix{};                // MLP-Mixer stack weight pointers
+    struct HotW {                     // every other weight the default path touches, resolved once (no name hashing per call)
+        const float *pe_w, *pe_b, *pos, *lastn_w, *lastn_b, *cls_w, *cls_b, *init_pose, *init_betas, *init_cam;
+        const float* conv_b[9];       // biases of the nine k = 3 convs of the VQ decoder, execution order (kConv3)
+        const float *res_w[2], *res_b[2];   // the two 1x1 convs of the ResConv blocks
+    } hot{};
     bool counted = false;             // registered in the per-device engine count (decoder turnstile)
     bool legacy_head = false;         // THMR_LEGACY_HEAD=1: force the chain-of-GEMMs head at every batch size (A/B only)
     bool smpl_loaded = false, finalized = false;
@@ -385,8 +390,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         ProfScope ps(e, st, THMR_PROF_PATCH, 2.0 * M * 768.0 * DIM,
                      4.0 * (B * 3.0 * 256 * 192 + (double)M * DIM + 768.0 * DIM));
         LAUNCH_OK(launch_im2col_patch(img, big, B, st));
-        GemmArgs a = mk(big, 768, e->W("backbone.patch_embed.proj.weight"), 768, e->W("backbone.patch_embed.proj.bias"),
-                        e->W("backbone.pos_embed"), 0, x, DIM, M, DIM, 768);
+        GemmArgs a = mk(big, 768, e->hot.pe_w, 768, e->hot.pe_b, e->hot.pos, 0, x, DIM, M, DIM, 768);
         LAUNCH_OK(launch_gemm(a, EPI_BIAS_POS, -1, st));
     }
     const float qscale = 1.0f / sqrtf(80.0f);   // head_dim ** -0.5  (vit.py:101)
@@ -423,8 +427,8 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         ProfScope ps(e, st, THMR_PROF_LN, 0, 8.0 * M * DIM);
         LAUNCH_OK(launch_layernorm(x, e->vitw[0].n1w, e->vitw[0].n1b, h, M, DIM, VIT_EPS, 0, st));
     }
-    const float* lastn_w = e->W("backbone.last_norm.weight");
-    const float* lastn_b = e->W("backbone.last_norm.bias");
+    const float* lastn_w = e->hot.lastn_w;
+    const float* lastn_b = e->hot.lastn_b;
     for (int i = 0; i < e->vit_depth; ++i) {
         const VitBlockW& w = e->vitw[i];
         const bool last = i + 1 == e->vit_depth;
@@ -469,7 +473,6 @@ int vq_decode(thmr_engine* e, const float* probs, int B, float* bpose, hipStream
     float* G[2] = {e->S(so.gat), e->S(so.gat2)};          // conv operands, alternating
     float *x0 = e->S(so.act0), *x1 = e->S(so.act1), *hid = e->S(so.act2);
     const int32_t* inv = reinterpret_cast<const int32_t*>(e->warena + e->o_inv);
-    const std::string d = "decoder.decoder.";
     // what the consumer conv needs from its producer
     auto scatter = [&](GemmArgs& a, float* dst, const int32_t* table, int tin, int tout, int dil, int relu) {
         a.cs_out = dst; a.cs_inv = table; a.cs_tin = tin; a.cs_tout = tout; a.cs_dil = dil; a.cs_relu = relu;
@@ -486,15 +489,14 @@ int vq_decode(thmr_engine* e, const float* probs, int B, float* bpose, hipStream
     }
     int cur = 0;
     {   // decoder.0: Conv1d(256 -> 512) + ReLU at T = 160 -> operand of decoder.3 on the 160 -> 125 resample
-        GemmArgs a = conv(0, G[cur], 160, e->W(d + "0.bias"), nullptr);
+        GemmArgs a = conv(0, G[cur], 160, e->hot.conv_b[0], nullptr);
         scatter(a, G[cur ^ 1], inv + 0 * 160, 160, e->vq_len[1], 1, 0);
         LAUNCH_OK(launch_gemm(a, EPI_BIAS_RELU, -1, st));
         cur ^= 1;
     }
-    const char* up_bias[] = {"3.bias", "6.bias", "9.bias", "12.bias"};
     for (int i = 0; i < 4; ++i) {   // decoder.3/6/9/12: nn.Upsample(size) (a down-sampling here) + Conv1d(512 -> 512) + ReLU
         const int T = e->vq_len[i + 1];
-        GemmArgs a = conv(1 + i, G[cur], T, e->W(d + up_bias[i]), i == 3 ? x0 : nullptr);
+        GemmArgs a = conv(1 + i, G[cur], T, e->hot.conv_b[1 + i], i == 3 ? x0 : nullptr);
         if (i < 3) scatter(a, G[cur ^ 1], inv + (i + 1) * 160, T, e->vq_len[i + 2], 1, 0);
         else scatter(a, G[cur ^ 1], nullptr, VQJ, VQJ, 3, 1);      // -> ResConv1DBlock 0 (dilation 3, pre-activation ReLU); x0 kept as its residual
         LAUNCH_OK(launch_gemm(a, EPI_BIAS_RELU, -1, st));
@@ -504,12 +506,11 @@ int vq_decode(thmr_engine* e, const float* probs, int B, float* bpose, hipStream
     float* res = x0;
     float* nres = x1;
     for (int blk = 0; blk < 2; ++blk) {   // ResConv1DBlock, resnet.py:49-69: x + conv2(relu(conv1(relu(x)))), dilation 3 then 1
-        const std::string p = d + "14.0.model." + std::to_string(blk) + ".";
         {
-            GemmArgs a = conv(5 + blk, G[cur], Tq, e->W(p + "conv1.bias"), hid);
+            GemmArgs a = conv(5 + blk, G[cur], Tq, e->hot.conv_b[5 + blk], hid);
             LAUNCH_OK(launch_gemm(a, EPI_BIAS_RELU, -1, st));
         }
-        GemmArgs a = mk(hid, VQW, e->W(p + "conv2.weight"), VQW, e->W(p + "conv2.bias"), res, VQW, blk == 0 ? nres : nullptr, VQW, B * Tq, VQW, VQW);
+        GemmArgs a = mk(hid, VQW, e->hot.res_w[blk], VQW, e->hot.res_b[blk], res, VQW, blk == 0 ? nres : nullptr, VQW, B * Tq, VQW, VQW);
         // block 0 feeds block 1's conv1 (pre-activation ReLU) and stays its residual; block 1 feeds decoder.14.1 (no activation)
         scatter(a, G[cur ^ 1], nullptr, Tq, Tq, 1, blk == 0 ? 1 : 0);
         LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, -1, st));
@@ -517,12 +518,12 @@ int vq_decode(thmr_engine* e, const float* probs, int B, float* bpose, hipStream
         std::swap(res, nres);
     }
     {   // decoder.14.1: Conv1d(512 -> 512) -> operand of decoder.15
-        GemmArgs a = conv(7, G[cur], Tq, e->W(d + "14.1.bias"), nullptr);
+        GemmArgs a = conv(7, G[cur], Tq, e->hot.conv_b[7], nullptr);
         scatter(a, G[cur ^ 1], nullptr, Tq, Tq, 1, 0);
         LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
         cur ^= 1;
     }
-    GemmArgs a = conv(8, G[cur], Tq, e->W(d + "15.bias"), bpose);    // decoder.15: Conv1d(512 -> 6): the 21 x 6D body pose
+    GemmArgs a = conv(8, G[cur], Tq, e->hot.conv_b[8], bpose);    // decoder.15: Conv1d(512 -> 6): the 21 x 6D body pose
     LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
     return 0;
 }
@@ -642,7 +643,7 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
     float* probs = (out && out->cls_logits_softmax) ? out->cls_logits_softmax : big + (size_t)R * NCLS;
     int32_t* tokidx = (out && out->token_idx) ? out->token_idx : reinterpret_cast<int32_t*>(e->S(so.tokidx));
     {
-        GemmArgs a = mk(nl2, HID, e->W(C + "class_pred_layer.weight"), HID, e->W(C + "class_pred_layer.bias"), nullptr, 0, logits, NCLS, R, NCLS, HID);
+        GemmArgs a = mk(nl2, HID, e->hot.cls_w, HID, e->hot.cls_b, nullptr, 0, logits, NCLS, R, NCLS, HID);
         LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
     }
     LAUNCH_OK(launch_softmax_argmax2048(logits, probs, tokidx, R, st));
@@ -653,8 +654,8 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
     float* betas = (out && out->betas) ? out->betas : e->S(so.betas);
     float* cam = (out && out->pred_cam) ? out->pred_cam : e->S(so.cam);
     float* camt = (out && out->pred_cam_t) ? out->pred_cam_t : e->S(so.camt);
-    LAUNCH_OK(launch_assemble(ro, 32, bpose, e->W("smpl_head.init_body_pose"), e->W("smpl_head.init_betas"),
-                              e->W("smpl_head.init_cam"), out ? out->pose6d : nullptr, rot, betas, cam, camt,
+    LAUNCH_OK(launch_assemble(ro, 32, bpose, e->hot.init_pose, e->hot.init_betas, e->hot.init_cam,
+                              out ? out->pose6d : nullptr, rot, betas, cam, camt,
                               out ? out->focal_length : nullptr, FOCAL, IMG, B, st));
     return 0;
 }
@@ -978,6 +979,17 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
         m.wn = e->W(C + "mixer_norm_layer.ff.0.weight"); m.bn = e->W(C + "mixer_norm_layer.ff.0.bias");
         m.nln_w = e->W(C + "mixer_norm_layer.ff.1.weight"); m.nln_b = e->W(C + "mixer_norm_layer.ff.1.bias");
         m.mt = e->S(e->so.mt); m.out = e->S(e->so.nl2);
+        auto& h = e->hot;
+        h.pe_w = e->W("backbone.patch_embed.proj.weight"); h.pe_b = e->W("backbone.patch_embed.proj.bias");
+        h.pos = e->W("backbone.pos_embed");
+        h.lastn_w = e->W("backbone.last_norm.weight"); h.lastn_b = e->W("backbone.last_norm.bias");
+        h.cls_w = e->W(C + "class_pred_layer.weight"); h.cls_b = e->W(C + "class_pred_layer.bias");
+        h.init_pose = e->W("smpl_head.init_body_pose"); h.init_betas = e->W("smpl_head.init_betas"); h.init_cam = e->W("smpl_head.init_cam");
+        for (int i = 0; i < 9; ++i) h.conv_b[i] = e->W(std::string(kConv3[i]) + ".bias");
+        for (int b = 0; b < 2; ++b) {
+            const std::string p = "decoder.decoder.14.0.model." + std::to_string(b) + ".";
+            h.res_w[b] = e->W(p + "conv2.weight"); h.res_b[b] = e->W(p + "conv2.bias");
+        }
     }
     e->finalized = true;
     return 0;
