@@ -204,6 +204,27 @@ def test_vit_attention_peaked(built_lib, cuda_dev):
     assert err_hip <= max(4 * err_cpu, 2e-5), (err_hip, err_cpu)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [33, 40, 100])
+def test_vit_attention_persistent_matches_the_64_query_variant(built_lib, cuda_dev, B):
+    """More than 512 (crop, head) items run on the persistent kernel (512 workgroups walking 2 ... 4 items each, the next item's K
+    fetched under the current P.V, a different LDS image: 84-float rows filled three rows per copy).  Every query must come out bit
+    for bit as from the 64-query variant that serves B <= 10 — B = 33 gives a grid where only some workgroups have a second item,
+    B = 100 up to four items per workgroup — and repeat runs must agree (missed wait / barrier)."""
+    from tokenhmr_amd import ops
+    qkv = _rand(B, 192, 3840, seed=100 + B)
+    qkv[:, :, :1280] *= 80 ** -0.5
+    d = qkv.to(cuda_dev)
+    out = ops.vit_attention(d)
+    for s0 in range(0, B, 10):
+        assert torch.equal(ops.vit_attention(d[s0:s0 + 10].contiguous()), out[s0:s0 + 10]), s0
+    for _ in range(5):
+        assert torch.equal(ops.vit_attention(d), out)
+    t = qkv[-2:].reshape(2, 192, 3, 16, 80).permute(2, 0, 3, 1, 4).double()
+    ref = ((t[0] @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]).transpose(1, 2).reshape(2, 192, 1280)
+    assert (out[-2:].cpu().double() - ref).abs().max() < 5e-6
+
+
 def test_rot6d(built_lib, cuda_dev):
     from tokenhmr_amd import ops
     from oracle import tokenhmr_oracle as O

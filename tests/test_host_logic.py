@@ -273,8 +273,8 @@ def test_attention_lds_dma_copies_keep_their_m0(built_lib, tmp_path):
     cos = glob.glob(work + "*gfx950*")
     assert cos, "no gfx950 code object inside attention.o"
     text = subprocess.run([objdump, "-d", cos[0]], capture_output=True, text=True, check=True).stdout.split("\n")
-    starts = [i for i, l in enumerate(text) if re.match(r"^[0-9a-f]+ <.*vit_attention_kernel", l)]
-    assert len(starts) >= 2
+    starts = [i for i, l in enumerate(text) if re.match(r"^[0-9a-f]+ <.*vit_attention_(persistent_)?kernel", l)]
+    assert len(starts) >= 3 and any("persistent" in text[i] for i in starts)
     for st in starts:
         end = next(i for i in range(st, len(text)) if "s_endpgm" in text[i])
         ins = []

@@ -85,23 +85,60 @@ __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// Diagnostics (scripts/micro/attn_timeline.hip only; the product instantiations use DBG = 0 and compile to the same code as before):
+//   DBG & 1: wave 0 of every workgroup stamps s_memrealtime (100 MHz) at the phase boundaries and records HW_ID / XCC_ID
+//   DBG & 4: the round-1 block order (logical index = blockIdx.x, heads of a crop spread over the eight XCDs)
+//   DBG & 2: the workgroup that holds the odd threadgroup slot of its CU (HW_ID.TG_ID & 1) starts `delay_ticks` later when it belongs
+//            to the first `first_round` workgroups of the grid (de-phasing experiment)
+struct AttnDbg {
+    unsigned long long* tl;     // [grid][16]
+    int delay_ticks, first_round;
+};
+#define THMR_ATTN_STAMP(i)                                  \
+    if constexpr ((DBG & 1) != 0) {                           \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        stamp[i] = wall_clock64();                          \
+        __builtin_amdgcn_sched_barrier(0);                  \
+    }
+
 // QT = 16-query tiles per wave, NW = waves per workgroup.  (3, 4): one 256-thread workgroup covers all 192 queries of a
 // (crop, head) (batched path); (1, 4): three workgroups of 64 queries each, all staging the same K / V (few crops: B*16
 // workgroups cannot occupy 256 CUs); (1, 12): one 768-thread workgroup, 12 waves of 16 queries, K / V staged once.  Every query
 // is computed by the same instruction sequence in all of them, so the variants are bit-identical.
-template <int QT, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 2) void vit_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out) {
+template <int QT, int NW, int DBG = 0>
+__global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 2) void vit_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, AttnDbg dbg) {
     constexpr int QB = 12 / (QT * NW);      // query blocks per (crop, head)
     static_assert(QB * QT * NW == 12, "192 queries = QB workgroups x NW waves x QT tiles of 16");
     typedef DmaOff<KS / 4, NW> KOff;
     typedef DmaOff<VS / 4, NW> VOff;
     __shared__ __attribute__((aligned(16))) float smem[NTOK * KS];   // K halves, later overwritten by the V halves
-    const int bh = blockIdx.x / QB, qb = blockIdx.x - bh * QB;
+    // XCD-aware order: workgroup b runs on XCD b % 8 (observed placement, used for speed only), so the logical index walks each XCD's
+    // share of the grid contiguously: the 16 heads of a crop run on ONE XCD at about the same time.  A head's rows are 320-byte
+    // pieces at a 15,360-byte stride that straddle 128-byte lines shared with the neighbouring heads; spread over eight L2s every
+    // boundary line was fetched twice and HBM saw scattered 320-byte bursts (profiles/r2n_attn_timeline.log: the first MFMA of a
+    // workgroup waited 11 us for Q + K[0:96]).  Together, the heads of a crop stream whole 15 KB token rows through one L2.
+    int logical;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, within = blockIdx.x >> 3, q = nwg >> 3, r = nwg & 7;
+        logical = (DBG & 4) ? (int)blockIdx.x : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int bh = logical / QB, qb = logical - bh * QB;
     const int b = bh / NH, h = bh % NH;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
     const float* base = qkv + (int64_t)b * NTOK * QKV_LD + h * HD;
+    unsigned long long stamp[(DBG & 1) ? 12 : 1];
+    unsigned hw_id = 0;
+    if constexpr (DBG != 0) hw_id = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+    THMR_ATTN_STAMP(0)
+    if constexpr ((DBG & 2) != 0) {
+        if ((int)blockIdx.x < dbg.first_round && ((hw_id >> 16) & 1u) != 0) {       // wave-uniform
+            const unsigned long long t0 = wall_clock64();
+            while ((long long)(wall_clock64() - t0) < (long long)dbg.delay_ticks) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    THMR_ATTN_STAMP(1)
 
     // ---- Q fragments first (oldest VMEM operations of the wave): B operand of S^T = K Q^T.  B[kslot g][j = query l15];
     //      with the k-permutation, register qf[qt][j][t] = Q[q0 + 16 qt + l15][16 j + 4 g + t] ----
@@ -148,12 +185,17 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 2) void vit_attention_kerne
         }
     };
     wait_vm_barrier<KOff::MINPER>();   // Q and K[0:96] have landed (at most this wave's MINPER youngest = K[96:192] copies are in flight)
+    THMR_ATTN_STAMP(2)
     s_half(0);
+    THMR_ATTN_STAMP(3)
     wait_vm_barrier<0>();        // K[96:192] landed; every wave is done with the first K half ...
     dma_half<VS / 4, NW>(base + 2 * DIM, smem, wave, vd);                                        // ... which V[0:96] overwrites
+    THMR_ATTN_STAMP(4)
     s_half(1);
+    THMR_ATTN_STAMP(5)
     wait_vm_barrier<VOff::MINPER>();   // every wave is done with the second K half (V[0:96] may still be in flight)
     dma_half<VS / 4, NW>(base + (int64_t)HALF * QKV_LD + 2 * DIM, smem + HALF * VS, wave, vd);
+    THMR_ATTN_STAMP(6)
 
     // ---- softmax over the 192 keys of each query (4 lanes x 48 registers per query), under the V copies.
     //      e_j = 2^(s_j log2e - m log2e) as ONE packed fma per score PAIR (v_pk_fma_f32) + v_exp_f32; the rounding of the
@@ -219,10 +261,15 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 2) void vit_attention_kerne
             for (int dt = 0; dt < 5; ++dt) vc[dt] = vn[dt];
         }
     };
+    THMR_ATTN_STAMP(7)
     wait_vm_barrier<VOff::MINPER>();   // V[0:96] landed for every wave
+    THMR_ATTN_STAMP(8)
     pv_half(0);
+    THMR_ATTN_STAMP(9)
     wait_vm_barrier<0>();        // V[96:192] landed
+    THMR_ATTN_STAMP(10)
     pv_half(1);
+    THMR_ATTN_STAMP(11)
 
     // ---- normalise + store: D layout of 16x16: col = lane&15 -> query (the lane that holds this query's 1/sum),
     //      row = 4*(lane>>4) + reg -> d  (one float4 per tile) ----
@@ -232,6 +279,240 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 2) void vit_attention_kerne
 #pragma unroll
         for (int dt = 0; dt < 5; ++dt)
             *reinterpret_cast<f32x4*>(obase + (int64_t)(q0 + qt * 16 + l15) * DIM + dt * 16 + g * 4) = o[qt][dt] * inv[qt];
+    if constexpr ((DBG & 1) != 0) {
+        if (tid == 0) {
+            unsigned long long* t = dbg.tl + (size_t)blockIdx.x * 16;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) t[i] = stamp[i];
+            t[12] = wall_clock64();
+            t[13] = hw_id;
+            t[14] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));        // HW_REG_XCC_ID
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent form of vit_attention_kernel<3, 4> for grids of more than 512 (crop, head) items (B > 32): 512 workgroups (two
+// per CU) each walk their items, and the NEXT item's operands are fetched under the CURRENT item's P.V phase:
+//     ... | P.V(keys 0..95) | DMA K'[0:96] over the dead V half | P.V(keys 96..191) | DMA K'[96:192] | normalise + store |
+//     Q' -> registers | S'(keys 0..95) | ...
+// Why: at B = 64 the plain kernel's grid is two rounds of 512 workgroups, and every workgroup waited ~10 us for Q + K[0:96]
+// before its first MFMA (profiles/r2n_attn_timeline.log) — 66 MB requested by 512 workgroups at once; 20 of the kernel's
+// 29 us above its MFMA floor.  Here only a workgroup's FIRST item pays that.  Per query the instruction sequence is the one of
+// vit_attention_kernel, so results are bit-identical (scripts/micro/attn_timeline.hip checks it).
+// Q' is loaded by inline assembly: beside LDS-DMA copies that the compiler cannot see, its own vmcnt bookkeeping for ordinary
+// loads would wait for the K'[96:192] copies issued after them.  All VMEM completion is therefore counted by hand; per wave and
+// item, in issue order: V[0:96] x8, V[96:192] x8, K'[0:96] x8|9, Q' x15, K'[96:192] x8|9, output stores x15 (in-order return).
+constexpr int kAttnDephaseUs = 0;     // start-up delay of the odd threadgroup slot's workgroup (see the kernel)
+__device__ __forceinline__ void barrier_only() { asm volatile("s_barrier" ::: "memory"); }
+
+template <int DBG = 0>
+__global__ __launch_bounds__(256, 2) void vit_attention_persistent_kernel(const float* __restrict__ qkv, float* __restrict__ out, int nitems, AttnDbg dbg) {
+    constexpr int QT = 3, NW = 4;
+    // LDS image (K halves, later the V halves): rows of PS = 84 floats = 21 slots of 16 B (20 data + 1 pad) — conflict-free both for the
+    // ds_read_b128 of K fragments (16 consecutive rows start at 16 distinct multiples of 4 banks) and the ds_read_b32 of V.  One
+    // LDS-DMA wave instruction fills 64 consecutive slots = exactly three rows + the first slot of the fourth, so EVERY copy of K and
+    // V uses the same per-lane source offset (lane -> row lane / 21, column lane % 21; lane 63 fetches what the next instruction's
+    // lane 0 fetches again) and only the wave-uniform base moves: one offset register instead of the 17 of vit_attention_kernel.
+    // A half = 32 instructions (8 per wave, wave w issues 8 w ... 8 w + 7); slot 2016 after each half is a dump slot for the last
+    // instruction's lane 63, which is clamped to the instruction's first row (it must not read past the tensor).
+    constexpr int PS = 84, HSLOTS = HALF * (PS / 4) + 1;      // slots per half incl. the dump slot
+    constexpr int CPW = 8;                                    // copies per wave and half
+    __shared__ __attribute__((aligned(16))) float smem[2 * HSLOTS * 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    // items of XCD x: [x * per_xcd, (x + 1) * per_xcd) (nitems = 16 B is a multiple of 8); this workgroup takes every wpx-th of them
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3, wpx = gridDim.x >> 3, per_xcd = nitems >> 3;
+    int it = within;                                    // index within the XCD's share
+    if (it >= per_xcd) return;
+    auto item_base = [&](int i) {
+        const int bh = xcd * per_xcd + i;
+        return qkv + (int64_t)(bh / NH) * NTOK * QKV_LD + (bh % NH) * HD;
+    };
+    const float* base = item_base(it);
+    unsigned long long stamp[(DBG & 1) ? 12 : 1];
+    const unsigned hw_id = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+    THMR_ATTN_STAMP(0)
+    // De-phasing: the two workgroups of a CU would otherwise walk their items in lockstep (same phase at the same time: both in
+    // softmax / store / waiting for Q' with the matrix pipe idle, then both in S or P.V at half speed each).  The one on the CU's odd
+    // threadgroup slot (HW_ID.TG_ID; the co-resident pair always differs in it, scripts/micro/attn_timeline.hip) starts
+    // dbg.delay_ticks (10 ns each) late, so one's vector / memory phases fall under the other's MFMA phases; it also halves the
+    // burst of Q + K requests at kernel start.  A placement assumption used for speed only: results do not depend on it.
+    if (dbg.delay_ticks > 0 && ((hw_id >> 16) & 1u) != 0) {          // wave-uniform
+        const unsigned long long t0 = wall_clock64();
+        while ((long long)(wall_clock64() - t0) < (long long)dbg.delay_ticks) __builtin_amdgcn_s_sleep(16);
+    }
+    THMR_ATTN_STAMP(1)
+
+    const int q0 = wave * 16 * QT;
+    f32x4 qf[QT][5];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            qf[qt][j] = *reinterpret_cast<const f32x4*>(base + (int64_t)(q0 + qt * 16 + l15) * QKV_LD + j * 16 + g * 4);
+    uint32_t doff, doff_last;
+    {
+        const int r = lane / (PS / 4), c = lane - r * (PS / 4);
+        doff = ((uint32_t)r * (uint32_t)QKV_LD + (uint32_t)(c < HD / 4 ? c : 0) * 4u) * 4u;
+        doff_last = lane == 63 ? 0u : doff;
+    }
+    // 96 rows starting at src (row stride QKV_LD) -> half hf of the LDS image
+    auto dma_rows = [&](const float* src, int hf) {
+        const uint32_t l0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)smem + (uint32_t)(hf * HSLOTS + wave * CPW * 63) * 16u;
+        const float* s0 = src + (int64_t)(wave * CPW * 3) * QKV_LD;
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            if (i == CPW - 1 && wave == NW - 1) dma16_saddr(s0 + (int64_t)(i * 3) * QKV_LD, doff_last, l0 + (uint32_t)i * 1008u);
+            else dma16_saddr(s0 + (int64_t)(i * 3) * QKV_LD, doff, l0 + (uint32_t)i * 1008u);
+        }
+    };
+    dma_rows(base + DIM, 0);
+    dma_rows(base + (int64_t)HALF * QKV_LD + DIM, 1);
+
+    constexpr float LOG2E = 1.44269504088896340736f;
+    wait_vm_barrier<CPW>();   // first item: Q and K[0:96] landed
+    for (;;) {
+        const bool has_next = it + wpx < per_xcd;                    // wave-uniform
+        const float* nbase = has_next ? item_base(it + wpx) : base;
+        THMR_ATTN_STAMP(2)
+        f32x4 s[QT][12];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 12; ++kt) s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto s_half = [&](int hf) {
+            f32x4 ka = *reinterpret_cast<const f32x4*>(&smem[hf * HSLOTS * 4 + l15 * PS + g * 4]);
+#pragma unroll
+            for (int i = 0; i < 30; ++i) {
+                const int kt = hf * 6 + i / 5, j = i % 5;
+                f32x4 kn = ka;
+                if (i + 1 < 30)
+                    kn = *reinterpret_cast<const f32x4*>(&smem[hf * HSLOTS * 4 + (((i + 1) / 5) * 16 + l15) * PS + ((i + 1) % 5) * 16 + g * 4]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[t], qf[qt][j][t], s[qt][kt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                ka = kn;
+            }
+        };
+        s_half(0);
+        THMR_ATTN_STAMP(3)
+        wait_vm_barrier<0>();          // K[96:192] landed (and the previous item's stores); every wave is done with the first K half
+        dma_rows(base + 2 * DIM, 0);
+        THMR_ATTN_STAMP(4)
+        s_half(1);
+        THMR_ATTN_STAMP(5)
+        barrier_only();                // every wave is done with the second K half
+        dma_rows(base + (int64_t)HALF * QKV_LD + 2 * DIM, 1);
+        THMR_ATTN_STAMP(6)
+
+        float inv[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float m = s[qt][0][0];
+#pragma unroll
+            for (int kt = 0; kt < 12; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, s[qt][kt][r]);
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const f32x2 c2 = splat2(-(m * LOG2E)), l2 = splat2(LOG2E);
+            f32x2 sum2 = splat2(0.f);
+#pragma unroll
+            for (int kt = 0; kt < 12; ++kt)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x2 t = __builtin_elementwise_fma(f32x2{s[qt][kt][2 * h], s[qt][kt][2 * h + 1]}, l2, c2);
+                    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                    s[qt][kt][2 * h] = e.x;
+                    s[qt][kt][2 * h + 1] = e.y;
+                    sum2 += e;
+                }
+            float sum = sum2.x + sum2.y;
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            inv[qt] = 1.0f / sum;
+        }
+
+        f32x4 o[QT][5];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < 5; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto pv_half = [&](int hf) {
+            float vc[5], vn[5];
+#pragma unroll
+            for (int dt = 0; dt < 5; ++dt) vc[dt] = smem[hf * HSLOTS * 4 + (g * 4) * PS + l15 + dt * 16];
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                const int kt = hf * 6 + i / 4, r = i % 4;
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt)
+                    vn[dt] = (i + 1 < 24) ? smem[hf * HSLOTS * 4 + (((i + 1) / 4) * 16 + g * 4 + (i + 1) % 4) * PS + l15 + dt * 16] : 0.f;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc[dt], s[qt][kt][r], o[qt][dt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt) vc[dt] = vn[dt];
+            }
+        };
+        THMR_ATTN_STAMP(7)
+        wait_vm_barrier<CPW>();   // V[0:96] landed for every wave
+        THMR_ATTN_STAMP(8)
+        pv_half(0);
+        THMR_ATTN_STAMP(9)
+        wait_vm_barrier<0>();              // V[96:192] landed; every wave is done with the first V half ...
+        if (has_next) dma_rows(nbase + DIM, 0);       // ... which the next item's K[0:96] overwrites
+        THMR_ATTN_STAMP(10)
+        pv_half(1);
+        THMR_ATTN_STAMP(11)
+        barrier_only();                    // every wave is done with the second V half
+        if (has_next) dma_rows(nbase + (int64_t)HALF * QKV_LD + DIM, 1);
+        {
+            const int bh = xcd * per_xcd + it;
+            float* obase = out + (int64_t)(bh / NH) * NTOK * DIM + (bh % NH) * HD;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt)
+                    *reinterpret_cast<f32x4*>(obase + (int64_t)(q0 + qt * 16 + l15) * DIM + dt * 16 + g * 4) = o[qt][dt] * inv[qt];
+        }
+        if constexpr ((DBG & 1) != 0) {
+            if (tid == 0 && it == within) {          // timeline of the first item only
+                unsigned long long* t = dbg.tl + (size_t)blockIdx.x * 16;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) t[i] = stamp[i];
+                t[12] = wall_clock64();
+                t[13] = hw_id;
+                t[14] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
+            }
+        }
+        if (!has_next) break;
+        asm volatile("" ::: "memory");      // the stores stay above the loads
+        // The next item's Q rows are fetched AFTER the stores, into the registers the output accumulators just left: their latency
+        // (~2 us) is exposed, but K'[0:96] — the larger part of what the first MFMA needs — is on chip already.  Fetching Q' earlier
+        // (under P.V, or before the stores) was built twice: the fragments then have to live beside the accumulators AND end up
+        // where the scores are not, which hipcc can only do with 60 + 144 + 60 registers and 38-44 spills.
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                qf[qt][j] = *reinterpret_cast<const f32x4*>(nbase + (int64_t)(q0 + qt * 16 + l15) * QKV_LD + j * 16 + g * 4);
+        asm volatile("" ::: "memory");
+        wait_vm_barrier<30>();             // this wave's K'[0:96] and K'[96:192] copies landed: only the 15 stores and the 15 Q' loads are younger
+        it += wpx;
+        base = nbase;
+    }
 }
 
 }  // namespace
@@ -240,9 +521,17 @@ int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s) {
     if (B <= 0) return -1;
     // while 48*B workgroups of 64 queries still fit the 512 resident slots (2 per CU) they finish sooner than 16*B of 192
     static const int forced = [] { const char* e = getenv("THMR_ATTN_VARIANT"); return e ? atoi(e) : 0; }();   // A/B knob (scripts/)
-    const int variant = forced ? forced : (B <= 10 ? 1 : 3);
-    if (variant == 1) hipLaunchKernelGGL((vit_attention_kernel<1, 4>), dim3(B * NH * 3), dim3(256), 0, s, qkv, out);
-    else if (variant == 12) hipLaunchKernelGGL((vit_attention_kernel<1, 12>), dim3(B * NH), dim3(768), 0, s, qkv, out);   // A/B only: measured no faster (profiles/r2c_attention_variants.log)
-    else hipLaunchKernelGGL((vit_attention_kernel<3, 4>), dim3(B * NH), dim3(256), 0, s, qkv, out);
+    // more than one round of 512 resident workgroups: the persistent form (5) fetches the next item under the current one
+    const int variant = forced ? forced : (B <= 10 ? 1 : (B * NH > 512 ? 5 : 3));
+    const AttnDbg nodbg{nullptr, 0, 0};
+    if (variant == 5) {
+        static const int dephase_us = [] { const char* e = getenv("THMR_ATTN_DEPHASE_US"); return e ? atoi(e) : kAttnDephaseUs; }();   // A/B knob
+        const AttnDbg dph{nullptr, dephase_us * 100, 0};
+        hipLaunchKernelGGL((vit_attention_persistent_kernel<0>), dim3(min(B * NH, 512)), dim3(256), 0, s, qkv, out, B * NH, dph);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    if (variant == 1) hipLaunchKernelGGL((vit_attention_kernel<1, 4>), dim3(B * NH * 3), dim3(256), 0, s, qkv, out, nodbg);
+    else if (variant == 12) hipLaunchKernelGGL((vit_attention_kernel<1, 12>), dim3(B * NH), dim3(768), 0, s, qkv, out, nodbg);   // A/B only: measured no faster (profiles/r2c_attention_variants.log)
+    else hipLaunchKernelGGL((vit_attention_kernel<3, 4>), dim3(B * NH), dim3(256), 0, s, qkv, out, nodbg);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

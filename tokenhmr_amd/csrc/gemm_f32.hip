@@ -242,7 +242,11 @@ __device__ __forceinline__ void store_tile_scatter(const GemmArgs& a, f32x16 (&a
 #ifndef THMR_GEMM_BARPOS
 #define THMR_GEMM_BARPOS 0
 #endif
-template <int WM, int WN, int TM, int TN, bool DMA, int EPI, int ABL = 0, int DSP = 0, int BARPOS = THMR_GEMM_BARPOS>
+// DPH (experiment, scripts/micro/gemm_dephase.hip): the block on the odd threadgroup slot of its CU starts g_gemm_dephase_ticks
+// (10 ns each) late when it belongs to the first 512 blocks of the grid, so that the two co-resident blocks of a CU do not run their
+// prologues / epilogues at the same time.
+__device__ int g_gemm_dephase_ticks;
+template <int WM, int WN, int TM, int TN, bool DMA, int EPI, int ABL = 0, int DSP = 0, int BARPOS = THMR_GEMM_BARPOS, int DPH = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int tiles_m, int tiles_n, int nwg, int tile_base) {
     constexpr int NW = WM * WN;
     constexpr int NT = NW * 64;
@@ -259,6 +263,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
     int tile_m, tile_n;
     tile_coords(tiles_m, tiles_n, nwg, tile_base, tile_m, tile_n);
     const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+    if constexpr (DPH != 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, TG_ID = bits 16..19
+        if (blockIdx.x < 512 && tile_base == 0 && ((hw >> 16) & 1u) != 0) {
+            const unsigned long long t0 = wall_clock64();
+            const int dt = g_gemm_dephase_ticks;
+            while ((long long)(wall_clock64() - t0) < (long long)dt) __builtin_amdgcn_s_sleep(32);
+        }
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -513,7 +525,9 @@ __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int ST, int EPI, bool PARTIAL>
+// ABL (timing-only experiments of scripts/micro/ring_ablation.hip, garbage results): bit0 no copies inside the K loop, bit1 no
+// per-tile wait + barrier, bit2 no LDS fragment reads.  ABL = 0 is the product kernel.
+template <int ST, int EPI, bool PARTIAL, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs a, int tiles_m, int groups, int ksplit, float* part) {
     constexpr int BM = 64, BN = 64, NP = 4;       // NP = DMA wave-instructions per wave per K tile (2 for A, 2 for W)
     static_assert((ST & (ST - 1)) == 0 && ST >= 4, "ring depth must be a power of two >= 4");
@@ -547,9 +561,14 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs a, int tiles_m,
         Aoff[p] = ((uint32_t)(min(bm0 + row, a.M - 1) - bm0) * (uint32_t)a.lda + (uint32_t)cs * 4u) * 4u;
         Woff[p] = ((uint32_t)(min(bn0 + row, a.N - 1) - bn0) * (uint32_t)a.ldw + (uint32_t)cs * 4u) * 4u;
     }
+    // ABL bit3 (experiment): column tile tile_n starts its K sweep at K tile (tile_n mod nk) and wraps around, so that concurrently
+    // running blocks do not all fetch the same 128-byte column of A / W rows (row stride K * 4 B) at the same time
+    const int krot = (ABL & 8) ? tile_n % nk : 0;
     auto dma_tile = [&](int kt, auto stc) {      // K tile kt -> ring slot stc (= kt % ST, an integral constant)
         const int st = stc;
-        const int64_t k0b = (int64_t)kt * (BK * 4);
+        int kk = kt + krot;
+        if (kk >= nk) kk -= nk;
+        const int64_t k0b = (int64_t)kk * (BK * 4);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             dma16_saddr(Abase + k0b, Aoff[p], lds_addr(As + (st * BM + (wave + 4 * p) * 8) * LDK));
@@ -566,6 +585,10 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs a, int tiles_m,
     f32x4 af[2], bf[2];
     auto read_frags = [&](auto stc, int j, int slot) {
         const int st = stc;
+        if constexpr ((ABL & 4) != 0) {
+            asm volatile("" : "+v"(af[slot]), "+v"(bf[slot]));
+            return;
+        }
         af[slot] = *reinterpret_cast<const f32x4*>(As + (st * BM + wm0 + lrow) * LDK + koff[j]);
         bf[slot] = *reinterpret_cast<const f32x4*>(Bs + (st * BN + wn0 + lrow) * LDK + koff[j]);
     };
@@ -596,8 +619,12 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs a, int tiles_m,
         if (!last) {
             // tile kt+1 landed (in-order completion: at most the ST-3 younger tiles may still be in flight); after the
             // barrier every wave is past tile kt-1, whose ring slot receives tile kt+ST-1
-            if (kt + ST - 2 < nk) wait_vm_barrier<(ST - 3) * NP>(); else wait_vm_barrier<0>();
-            if (kt + ST - 1 < nk) dma_tile(kt + ST - 1, IntC<(S + ST - 1) % ST>{});
+            if constexpr ((ABL & 2) == 0) {
+                if (kt + ST - 2 < nk) wait_vm_barrier<(ST - 3) * NP>(); else wait_vm_barrier<0>();
+            }
+            if constexpr ((ABL & 1) == 0) {
+                if (kt + ST - 1 < nk) dma_tile(kt + ST - 1, IntC<(S + ST - 1) % ST>{});
+            }
         }
         group(0, [&] { read_frags(stc, 3, 1); });
         group(1, [&] { if (!last) read_frags(IntC<(S + 1) % ST>{}, 0, 0); });
