@@ -32,7 +32,7 @@ for B in ([] if os.environ.get("SKIP_PATH") else Bs):
 VARS = os.environ.get("GEMM_VARIANTS", "auto,64x64,128x128,128x160,ring4,ring8,ring4/k2,ring8/k2,ring4/k4,ring8/k4,ring4/k8,ring8/k8").split(",")
 SH = {"qkv": (3840, 1280, "bias_qscale"), "proj": (1280, 1280, "bias_resid"), "fc1": (5120, 1280, "bias_gelu"), "fc2": (1280, 5120, "bias_resid")}
 g = torch.Generator().manual_seed(0)
-for B in Bs:
+for B in ([] if os.environ.get("SKIP_GEMM") else Bs):
     M = 192 * B
     for name, (n, k, epi) in SH.items():
         a = torch.randn(M, k, generator=g).to(dev)

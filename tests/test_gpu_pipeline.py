@@ -223,8 +223,10 @@ def test_head_regimes_agree_and_persistent_decoders_coexist(built_lib, cuda_dev)
 
 def test_fused_head_equals_chain_head_across_batch_sizes(built_lib, cuda_dev, monkeypatch):
     """The persistent decoder kernel picks its grid from the batch (64 workgroups up to 16 crops, 128 / 192 / 256 above) and
-    deals (column tile x 16-row sub-tile) items over it; the mixer kernel runs one workgroup per crop.  For batch sizes on both
-    sides of every boundary — 1, 15, 16, 17, 33, 48, 49, 64, 100, 128 (ragged last sub-tiles included) — the fused head must
+    deals (column tile x 16-row sub-tile) items over it; the mixer stack runs inside that kernel, ten workgroups per crop, up to 25
+    crops and as its own kernel, one workgroup per crop, above (bit-identical by construction: both call mixer_device.h).  For
+    batch sizes on both sides of every boundary — 1, 2, 6, 7, 15, 16, 17, 25, 26, 33, 48, 49, 64, 100, 128 (ragged last sub-tiles
+    included) — the fused head must
     agree with the chain-of-GEMMs head (THMR_LEGACY_HEAD=1: same maths as separate tiled launches, the round-1 path) to fp32
     summation-order differences, be deterministic, and give a crop the same bits whatever batch it rides in."""
     from tokenhmr_amd.config import HMRConfig
@@ -244,7 +246,7 @@ def test_fused_head_equals_chain_head_across_batch_sizes(built_lib, cuda_dev, mo
     ctx = torch.randn(128, 192, 1280, generator=torch.Generator().manual_seed(12)).to(cuda_dev)
     keys = ("token_out", "cls_logits", "pose6d", "pred_vertices", "pred_cam")
     ref128 = {k: v.clone() for k, v in fused.head_forward(ctx, taps=True).items()}
-    for B in (1, 15, 16, 17, 33, 48, 49, 64, 100, 128):
+    for B in (1, 2, 6, 7, 15, 16, 17, 25, 26, 33, 48, 49, 64, 100, 128):
         a = {k: v.clone() for k, v in fused.head_forward(ctx[:B], taps=True).items()}
         b = fused.head_forward(ctx[:B], taps=True)
         c = chain.head_forward(ctx[:B], taps=True)

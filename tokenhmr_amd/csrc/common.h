@@ -190,6 +190,19 @@ __device__ __forceinline__ f32x4 ld_dev4(const float* p) {
     return f32x4{a.f.x, a.f.y, b.f.x, b.f.y};
 }
 
+// ---- parameters of the MLP-Mixer stack (mixer_fused.hip; also the distributed tail of the persistent decoder kernel) ----
+struct MixerLayerW {
+    const float *ln1w, *ln1b, *wt1, *bt1, *wt2, *bt2, *ln2w, *ln2b, *wc1, *bc1, *wc2, *bc2;
+};
+struct MixerParams {
+    MixerLayerW L[4];
+    const float *tln_w, *tln_b;          // mixer_trans.ff.1 LayerNorm(10240)
+    const float *wn, *bn, *nln_w, *nln_b;   // mixer_norm_layer: Linear(64,64) + LayerNorm(64) + ReLU
+    const float* mt;                     // (B, 10240) mixer_trans Linear output
+    float* out;                          // (B, 160, 64) classifier features -> class_pred_layer
+};
+
+
 // ---- the persistent decoder kernel (decoder_fused.hip) ----
 struct DecLayerW {        // one decoder layer (pose_transformer.py:191-201), pointers into the weight arena
     const float *n0w, *n0b, *wv, *wo1, *bo1;          // PreNorm + self-attention (v slice of to_qkv, to_out)
@@ -207,22 +220,17 @@ struct DecParams {
     int depth, B;
     int timeline;                                     // 1: workgroup 0 stamps the wall clock into sync[16..] (diagnostics)
     int max_blocks;                                   // compute units of the device: at most one workgroup per CU is launched
+    // Distributed MLP-Mixer tail (decoder_fused.hip mixer_cluster_stage): with mixer_cluster != 0 the kernel also runs the mixer
+    // stack, ten workgroups per crop (one 16-token tile each), and the separate mixer_stack_kernel launch is skipped.  Needs
+    // 10 * B <= grid <= CUs.  mixy: two (B, 160, 64) exchange buffers for the LayerNorm-ed rows (alternating per layer).
+    MixerParams mx;
+    float* mixy[2];
+    int mixer_cluster;
 };
 
 int launch_decoder_fused(const DecParams& p, hipStream_t s);
 
-// ---- the MLP-Mixer stack kernel (mixer_fused.hip) ----
-struct MixerLayerW {
-    const float *ln1w, *ln1b, *wt1, *bt1, *wt2, *bt2, *ln2w, *ln2b, *wc1, *bc1, *wc2, *bc2;
-};
-struct MixerParams {
-    MixerLayerW L[4];
-    const float *tln_w, *tln_b;          // mixer_trans.ff.1 LayerNorm(10240)
-    const float *wn, *bn, *nln_w, *nln_b;   // mixer_norm_layer: Linear(64,64) + LayerNorm(64) + ReLU
-    const float* mt;                     // (B, 10240) mixer_trans Linear output
-    float* out;                          // (B, 160, 64) classifier features -> class_pred_layer
-};
-
+// ---- the MLP-Mixer stack kernel (mixer_fused.hip; parameter structs above DecParams) ----
 int launch_mixer_fused(const MixerParams& p, int B, hipStream_t s);
 
 // host-side launch helpers (defined in the .hip files); all return 0 / negative

@@ -22,7 +22,7 @@
 //     device-scope atomics.  It needs all workgroups resident: at most one 512-thread workgroup per CU, several such kernels of
 //     different engines are chained by the host (engine.hip launch_decoder_serialised), and the poll is BOUNDED: on timeout the
 //     kernel sets an error word (thmr_engine_status) and exits instead of hanging the GPU.
-#include "common.h"
+#include "mixer_device.h"
 
 namespace {
 
@@ -201,7 +201,7 @@ __device__ __forceinline__ void gemv_stage(const float* __restrict__ A, int lda,
 // reduction.  vt < n_ro: read-out tile (W0, 31 valid rows + a zero row, ld 32), else mixer_trans tile vt - n_ro (W1).
 __device__ __forceinline__ void gemv_multi(const float* __restrict__ A, const float* __restrict__ W0, const float* __restrict__ b0, float* C0,
                                            const float* __restrict__ W1, const float* __restrict__ b1, float* C1, int n_ro, int n_all, int B,
-                                           float (*red)[64][4], int tid) {
+                                           float (*red)[64][4], int tid, bool dev_c1) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, g = lane >> 4;
     const int kbeg = wave * (E / NWAVE);
     const int nsub = (B + 15) >> 4, G = gridDim.x;
@@ -252,7 +252,10 @@ __device__ __forceinline__ void gemv_multi(const float* __restrict__ A, const fl
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int m = m0 + g * 4 + r;
-                        if (m < B) C[(int64_t)m * ldc + n] = v[r] + bv;
+                        if (m < B) {
+                            if (!ro && dev_c1) st_dev(&C[(int64_t)m * ldc + n], v[r] + bv);      // consumed by other workgroups of THIS kernel
+                            else C[(int64_t)m * ldc + n] = v[r] + bv;
+                        }
                     }
                 }
             }
@@ -365,7 +368,68 @@ __device__ __forceinline__ void cross_attn_stage(const DecParams& p, int layer, 
     }
 }
 
+// ---- the MLP-Mixer stack, distributed: ten workgroups per crop, one 16-token tile each ---------------------------------------
+// token_classifier.py:92-101.  mixer_stack_kernel (one workgroup per crop) leaves all but B compute units idle and takes 0.30 ms
+// whatever the batch: at one crop a quarter of the head, 7 % of the whole call.  Here workgroup w < 10 B owns token tile w % 10 of
+// crop w / 10 from mixer_trans' LayerNorm to mixer_norm_layer:
+//   * per-token work (LayerNorm1 / 2, channel mixing, mixer_norm_layer) stays inside the owner;
+//   * token mixing needs every token of the crop: the owners publish their LayerNorm1 rows (device-scope stores), ONE grid barrier
+//     per layer, every workgroup gathers the crop's 160 rows into its LDS and recomputes the small hidden activation u (64 x 64,
+//     640 MFMAs) redundantly instead of exchanging it, then finishes z only for its own tokens;
+//   * the crop statistics of mixer_trans' LayerNorm(10240) are recomputed by every owner with the thread mapping of
+//     mixer_stack_kernel.
+// Every value is produced by the functions of mixer_device.h on the same operands in the same order as in mixer_stack_kernel:
+// results are bit-identical to it (tests/test_gpu_model.py), so the choice of form never shows in a crop's result.
+__device__ __forceinline__ bool mixer_cluster_stage(const DecParams& p, GridSync& gs, int tid, volatile int* s_ok, float* Y, float* U, float* Xl,
+                                                    float* redbuf) {
+    using namespace mixer;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, g = lane >> 4;
+    const int wg = blockIdx.x;
+    const bool active = wg < 10 * p.B;                       // workgroup-uniform
+    const int b = wg / 10, t0 = (wg - b * 10) * 16;
+    if (active) {
+        f32x4 o[5];
+        trans_ln<true>(p.mt + (int64_t)b * (T * H), p.mx.tln_w, p.mx.tln_b, redbuf, tid, lane, wave, o);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int e0 = (i * NT + tid) * 4, t = e0 >> 6, h = e0 & 63;
+            if (t >= t0 && t < t0 + 16) *reinterpret_cast<f32x4*>(&Xl[(t - t0) * LD + h]) = o[i];
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+        const MixerLayerW& w = p.mx.L[l];
+        float* yg = p.mixy[l & 1] + (int64_t)b * (T * H);
+        if (active) {                                        // y = LayerNorm1(x) for the own rows -> exchange buffer
+            const float gamma = w.ln1w[lane], beta = w.ln1b[lane];
+            for (int r = wave; r < 16; r += NW) st_dev(yg + (t0 + r) * H + lane, ln_row_value(Xl[r * LD + lane], gamma, beta));
+        }
+        if (!grid_barrier(gs, tid, s_ok)) return false;
+        if (active) {
+            for (int idx = tid; idx < T * H / 4; idx += NT) {    // the crop's 160 LayerNorm-ed rows -> LDS
+                const int t = idx >> 4, h = (idx & 15) * 4;
+                *reinterpret_cast<f32x4*>(&Y[t * LD + h]) = ld_dev4(yg + idx * 4);
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int tile = wave; tile < 16; tile += NW) token_mix1_tile(Y, U, w, tile, l15, g);
+            __syncthreads();
+            if (wave < 4) token_mix2_tile(U, Xl, Y + t0 * LD, w, wave * 16, t0, l15, g);       // s = x + z for the own tokens
+            __syncthreads();
+            channel_mix_tile_8waves(Y + t0 * LD, Xl, U, w, wave, lane, l15, g);     // u is dead: its LDS holds zh
+        }
+    }
+    if (active && wave == 0) norm_layer_tile(Xl, p.mx.out + ((int64_t)b * T + t0) * H, p.mx, l15, g);
+    return true;
+}
+
 __global__ __launch_bounds__(NWAVE * 64) void decoder_persistent_kernel(DecParams p) {
+    __shared__ __attribute__((aligned(16))) float mixY[mixer::T * mixer::LD];      // distributed mixer tail: the crop's LayerNorm-ed rows / s
+    __shared__ __attribute__((aligned(16))) float mixU[mixer::H * mixer::LD];      // token-mixing hidden activation
+    __shared__ __attribute__((aligned(16))) float mixX[16 * mixer::LD];            // residual rows of the own token tile
+    __shared__ float mixred[mixer::NW];
+    static_assert(mixer::NW == NWAVE, "the distributed mixer tail uses the decoder kernel's 8 waves");
     __shared__ __attribute__((aligned(16))) float red[NWAVE][64][4];         // 8 KB: K-slice partial tiles (also the attention weights)
     __shared__ RowStat rowstat;
     __shared__ unsigned s_base;
@@ -427,7 +491,12 @@ __global__ __launch_bounds__(NWAVE * 64) void decoder_persistent_kernel(DecParam
     if (ok) {
         // consumers of the decoder output: the four read-outs as one (31 + zero row, 1024) matrix (token_head.py:99-105) and
         // the classifier's first Linear 1024 -> 160*64 (token_classifier.py:71-73); 2 + 640 column tiles dealt to the workgroups
-        gemv_multi(p.dx, p.ro_w, p.ro_b, p.ro, p.mt_w, p.mt_b, p.mt, 2, 2 + 640, B, red, tid);
+        gemv_multi(p.dx, p.ro_w, p.ro_b, p.ro, p.mt_w, p.mt_b, p.mt, 2, 2 + 640, B, red, tid, p.mixer_cluster != 0);
+    }
+    THMR_STAMP();
+    if (ok && p.mixer_cluster != 0) {
+        ok = grid_barrier(gs, tid, &s_ok);                   // mixer_trans' Linear output complete
+        if (ok) ok = mixer_cluster_stage(p, gs, tid, &s_ok, mixY, mixU, mixX, mixred);
     }
     THMR_STAMP();
     // exit protocol: the LAST workgroup to leave publishes the last epoch as the next kernel's generation
@@ -450,8 +519,10 @@ int launch_decoder_fused(const DecParams& p, hipStream_t s) {
     // the steps deal their items round-robin)
     const int nsub = (p.B + 15) / 16;
     int grid = NBLK * (nsub < 4 ? nsub : 4);
+    if (p.mixer_cluster != 0 && grid < 10 * p.B) grid = 10 * p.B;      // the distributed mixer tail: one workgroup per (crop, 16-token tile)
     if (p.max_blocks > 0 && grid > p.max_blocks) grid = p.max_blocks;
     if (grid > 256) grid = 256;                  // workgroup 0 polls one arrival flag per thread pair at most; flags[256]
+    if (p.mixer_cluster != 0 && grid < 10 * p.B) return -1;             // the caller decides with decoder_mixer_cluster_fits()
     hipLaunchKernelGGL(decoder_persistent_kernel, dim3(grid), dim3(NWAVE * 64), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -79,6 +79,7 @@ struct thmr_engine {
     } hot{};
     bool counted = false;             // registered in the per-device engine count (decoder turnstile)
     bool legacy_head = false;         // THMR_LEGACY_HEAD=1: force the chain-of-GEMMs head at every batch size (A/B only)
+    bool mixer_cluster = true;        // THMR_MIXER_CLUSTER=0: always run the mixer stack as its own one-workgroup-per-crop kernel (A/B only)
     bool smpl_loaded = false, finalized = false;
     std::string err;
     // derived / constant regions (float offsets in weight arena)
@@ -545,11 +546,18 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
     float* ro = e->S(so.ro);
     float *mt = e->S(so.mt), *cf = e->S(so.cf), *cf2 = e->S(so.cf2);
     const bool fused_head = !e->legacy_head && B <= kFusedHeadMaxB;
+    bool mixer_in_decoder = false;
     if (fused_head) {
         // ONE persistent kernel: layer-0 input, the 6 decoder layers (42 dependent GEMV-class steps), the read-outs and the
         // classifier's first Linear (decoder_fused.hip)
         DecParams d = e->dec;
         d.B = B;
+        // up to 25 crops the MLP-Mixer stack runs inside the same kernel, ten workgroups per crop (decoder_fused.hip
+        // mixer_cluster_stage; bit-identical to mixer_stack_kernel, which serves the larger batches one workgroup per crop)
+        mixer_in_decoder = e->mixer_cluster && 10 * B <= (d.max_blocks < 256 ? d.max_blocks : 256);
+        d.mixer_cluster = mixer_in_decoder ? 1 : 0;
+        d.mx = e->mix;
+        d.mixy[0] = cf; d.mixy[1] = cf2;
         LAUNCH_OK(launch_decoder_serialised(e, d, st));
     } else {
     LAUNCH_OK(launch_decoder_init(e->W(T + "to_token_embedding.bias"), e->W(T + "pos_embedding"), dx, B, E, st));
@@ -603,7 +611,7 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
     float *nl = e->S(so.nl), *nl2 = e->S(so.nl2);
     if (fused_head) {
         // ONE kernel, one workgroup per crop: mixer_trans LayerNorm + ReLU, the 4 MixerLayers, mixer_norm_layer (mixer_fused.hip)
-        LAUNCH_OK(launch_mixer_fused(e->mix, B, st));
+        if (!mixer_in_decoder) LAUNCH_OK(launch_mixer_fused(e->mix, B, st));
     } else {
         LAUNCH_OK(launch_layernorm(mt, e->W(C + "mixer_trans.ff.1.weight"), e->W(C + "mixer_trans.ff.1.bias"), cf, B, TN * HID, LN_EPS, 1, st));
         for (int m = 0; m < MIX; ++m) {   // MixerLayer, heads/modules.py:55-63
@@ -819,6 +827,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     // arrival counters of the fused skin + joints kernel (self-resetting; zero before the first call)
     if (hipMemset(e->sarena + e->so.lcnt, 0, (size_t)e->max_batch * sizeof(float)) != hipSuccess) return bail(THMR_ERR_HIP, "hipMemset(lbs counters) failed");
     { const char* lg = getenv("THMR_LEGACY_HEAD"); e->legacy_head = lg && lg[0] == '1'; }
+    { const char* mc = getenv("THMR_MIXER_CLUSTER"); e->mixer_cluster = !(mc && mc[0] == '0'); }
     { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
     *out = e;
     return 0;
