@@ -101,6 +101,35 @@ def test_gemm_ring_deterministic_and_qscale(built_lib, cuda_dev):
     assert torch.equal(ops.gemm(a, w, b, variant="ring8", **kw), ref)
 
 
+TINY_SHAPES = [(21, 512, 1536), (160, 512, 768), (160, 256, 2048), (126, 6, 1536), (960, 512, 1536), (55, 512, 512), (37, 31, 256)]
+
+
+@pytest.mark.parametrize("shape", TINY_SHAPES)
+def test_gemm_tiny_variant(built_lib, cuda_dev, shape):
+    """The tiny-M kernel of the head's small-batch regime (32x32 tiles, K split over the 8 waves of a workgroup, partial tiles added
+    in wave order): every epilogue it serves against fp64, ragged M / N edges (21 rows, 6 columns), determinism, and — the property
+    the regime relies on — a row's result does not depend on how many rows share the launch."""
+    from tokenhmr_amd import ops
+    M, N, K = shape
+    a, w, b, r = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(N, seed=3), _rand(M, N, seed=4)
+    da, dw, db, dr = a.to(cuda_dev), w.to(cuda_dev), b.to(cuda_dev), r.to(cuda_dev)
+    for epi in ("none", "bias", "bias_relu", "bias_resid", "bias_gelu"):
+        out = ops.gemm(da, dw, None if epi == "none" else db, dr if epi == "bias_resid" else None, epi=epi, variant="tiny")
+        ref = _gemm_ref(a, w, b, r, epi, 1.0, 0)
+        assert torch.allclose(out.cpu(), ref, atol=3e-5, rtol=1e-5), (epi, (out.cpu() - ref).abs().max())
+        assert torch.equal(out, ops.gemm(da, dw, None if epi == "none" else db, dr if epi == "bias_resid" else None, epi=epi, variant="tiny"))
+    full = ops.gemm(da, dw, db, epi="bias", variant="tiny")
+    for m in (1, 21, min(M, 100)):
+        assert torch.equal(ops.gemm(da[:m].contiguous(), dw, db, epi="bias", variant="tiny"), full[:m]), m
+
+
+def test_gemm_tiny_rejects(built_lib, cuda_dev):
+    from tokenhmr_amd import ops, _cabi
+    a, w = _rand(64, 384, seed=1).to(cuda_dev), _rand(64, 384, seed=2).to(cuda_dev)
+    with pytest.raises(_cabi.EngineError):
+        ops.gemm(a, w, variant="tiny")                # K must be a multiple of 256 (8 waves x 32-deep slices)
+
+
 def test_gemm_ring_rejects(built_lib, cuda_dev):
     from tokenhmr_amd import ops, _cabi
     a, w = _rand(64, 96, seed=1).to(cuda_dev), _rand(64, 96, seed=2).to(cuda_dev)

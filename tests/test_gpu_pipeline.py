@@ -246,13 +246,21 @@ def test_fused_head_equals_chain_head_across_batch_sizes(built_lib, cuda_dev, mo
     ctx = torch.randn(128, 192, 1280, generator=torch.Generator().manual_seed(12)).to(cuda_dev)
     keys = ("token_out", "cls_logits", "pose6d", "pred_vertices", "pred_cam")
     ref128 = {k: v.clone() for k, v in fused.head_forward(ctx, taps=True).items()}
+    ref6 = {k: v.clone() for k, v in fused.head_forward(ctx[:6], taps=True).items()}
+    # up to six crops the VQ decoder's GEMMs run on the tiny-M kernel (another association of the K sum): its own regime.  What comes
+    # BEFORE the VQ decoder (decoder, mixers, logits) is the same arithmetic in both regimes.
+    for k in ("token_out", "cls_logits"):
+        assert torch.equal(ref6[k], ref128[k][:6]), k
+    assert (ref6["pred_vertices"] - ref128["pred_vertices"][:6]).abs().max() < 1e-5
+    assert (ref6["pose6d"] - ref128["pose6d"][:6]).abs().max() < 1e-5
     for B in (1, 2, 6, 7, 15, 16, 17, 25, 26, 33, 48, 49, 64, 100, 128):
         a = {k: v.clone() for k, v in fused.head_forward(ctx[:B], taps=True).items()}
         b = fused.head_forward(ctx[:B], taps=True)
         c = chain.head_forward(ctx[:B], taps=True)
+        ref = ref6 if B <= 6 else ref128
         for k in keys:
             assert torch.equal(a[k], b[k]), (B, k)                                   # deterministic
-            assert torch.equal(a[k], ref128[k][:B]), (B, k)                          # batch-invariant within the fused regime
+            assert torch.equal(a[k], ref[k][:B]), (B, k)                             # batch-invariant within a regime of the fused head
         assert (a["token_out"] - c["token_out"]).abs().max() < 1e-4, B
         assert (a["cls_logits"] - c["cls_logits"]).abs().max() < 1e-4, B
         assert (a["pred_vertices"] - c["pred_vertices"]).abs().max() < 1e-5, B

@@ -80,6 +80,7 @@ struct thmr_engine {
     bool counted = false;             // registered in the per-device engine count (decoder turnstile)
     bool legacy_head = false;         // THMR_LEGACY_HEAD=1: force the chain-of-GEMMs head at every batch size (A/B only)
     bool mixer_cluster = true;        // THMR_MIXER_CLUSTER=0: always run the mixer stack as its own one-workgroup-per-crop kernel (A/B only)
+    bool tiny_gemm = true;            // THMR_TINY_GEMM=0: the VQ decoder's GEMMs stay on the ring kernel in the small-batch regime (A/B only)
     bool smpl_loaded = false, finalized = false;
     std::string err;
     // derived / constant regions (float offsets in weight arena)
@@ -471,6 +472,10 @@ int launch_decoder_serialised(thmr_engine* e, const DecParams& d, hipStream_t st
 // wrote (GemmArgs::cs_*: nearest-resample + taps + zero padding + the ResConv pre-activation ReLU), so no gather launch exists.
 int vq_decode(thmr_engine* e, const float* probs, int B, float* bpose, hipStream_t st) {
     auto& so = e->so;
+    // Up to six crops (the small-batch regime, B <= kSmallM / 192) these M = 21 B ... 160 B row products run on the tiny-M kernel
+    // (32x32 tiles, K split over the 8 waves of a workgroup): as 8-24 ring-kernel workgroups walking the whole K they were 13
+    // dependent launches of 12-32 us, a third of the head at one crop.  One choice for the whole regime: the K association differs.
+    const int tv = (e->tiny_gemm && B * TOK <= kSmallM) ? 11 : -1;
     float* G[2] = {e->S(so.gat), e->S(so.gat2)};          // conv operands, alternating
     float *x0 = e->S(so.act0), *x1 = e->S(so.act1), *hid = e->S(so.act2);
     const int32_t* inv = reinterpret_cast<const int32_t*>(e->warena + e->o_inv);
@@ -486,13 +491,13 @@ int vq_decode(thmr_engine* e, const float* probs, int B, float* bpose, hipStream
     {   // soft codebook lookup: probs @ codebook as a GEMM against codebook^T -> operand of decoder.0 (T = 160, C = 256)
         GemmArgs a = mk(probs, NCLS, e->warena + e->o_cbT, NCLS, nullptr, nullptr, 0, nullptr, CODE, B * TN, CODE, NCLS);
         scatter(a, G[0], nullptr, 160, 160, 1, 0);
-        LAUNCH_OK(launch_gemm(a, EPI_NONE, -1, st));
+        LAUNCH_OK(launch_gemm(a, EPI_NONE, tv, st));
     }
     int cur = 0;
     {   // decoder.0: Conv1d(256 -> 512) + ReLU at T = 160 -> operand of decoder.3 on the 160 -> 125 resample
         GemmArgs a = conv(0, G[cur], 160, e->hot.conv_b[0], nullptr);
         scatter(a, G[cur ^ 1], inv + 0 * 160, 160, e->vq_len[1], 1, 0);
-        LAUNCH_OK(launch_gemm(a, EPI_BIAS_RELU, -1, st));
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS_RELU, tv, st));
         cur ^= 1;
     }
     for (int i = 0; i < 4; ++i) {   // decoder.3/6/9/12: nn.Upsample(size) (a down-sampling here) + Conv1d(512 -> 512) + ReLU
@@ -500,7 +505,7 @@ int vq_decode(thmr_engine* e, const float* probs, int B, float* bpose, hipStream
         GemmArgs a = conv(1 + i, G[cur], T, e->hot.conv_b[1 + i], i == 3 ? x0 : nullptr);
         if (i < 3) scatter(a, G[cur ^ 1], inv + (i + 1) * 160, T, e->vq_len[i + 2], 1, 0);
         else scatter(a, G[cur ^ 1], nullptr, VQJ, VQJ, 3, 1);      // -> ResConv1DBlock 0 (dilation 3, pre-activation ReLU); x0 kept as its residual
-        LAUNCH_OK(launch_gemm(a, EPI_BIAS_RELU, -1, st));
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS_RELU, tv, st));
         cur ^= 1;
     }
     const int Tq = VQJ;
@@ -509,23 +514,23 @@ int vq_decode(thmr_engine* e, const float* probs, int B, float* bpose, hipStream
     for (int blk = 0; blk < 2; ++blk) {   // ResConv1DBlock, resnet.py:49-69: x + conv2(relu(conv1(relu(x)))), dilation 3 then 1
         {
             GemmArgs a = conv(5 + blk, G[cur], Tq, e->hot.conv_b[5 + blk], hid);
-            LAUNCH_OK(launch_gemm(a, EPI_BIAS_RELU, -1, st));
+            LAUNCH_OK(launch_gemm(a, EPI_BIAS_RELU, tv, st));
         }
         GemmArgs a = mk(hid, VQW, e->hot.res_w[blk], VQW, e->hot.res_b[blk], res, VQW, blk == 0 ? nres : nullptr, VQW, B * Tq, VQW, VQW);
         // block 0 feeds block 1's conv1 (pre-activation ReLU) and stays its residual; block 1 feeds decoder.14.1 (no activation)
         scatter(a, G[cur ^ 1], nullptr, Tq, Tq, 1, blk == 0 ? 1 : 0);
-        LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, -1, st));
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS_RESID, tv, st));
         cur ^= 1;
         std::swap(res, nres);
     }
     {   // decoder.14.1: Conv1d(512 -> 512) -> operand of decoder.15
         GemmArgs a = conv(7, G[cur], Tq, e->hot.conv_b[7], nullptr);
         scatter(a, G[cur ^ 1], nullptr, Tq, Tq, 1, 0);
-        LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
+        LAUNCH_OK(launch_gemm(a, EPI_BIAS, tv, st));
         cur ^= 1;
     }
     GemmArgs a = conv(8, G[cur], Tq, e->hot.conv_b[8], bpose);    // decoder.15: Conv1d(512 -> 6): the 21 x 6D body pose
-    LAUNCH_OK(launch_gemm(a, EPI_BIAS, -1, st));
+    LAUNCH_OK(launch_gemm(a, EPI_BIAS, tv, st));
     return 0;
 }
 
@@ -828,6 +833,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     if (hipMemset(e->sarena + e->so.lcnt, 0, (size_t)e->max_batch * sizeof(float)) != hipSuccess) return bail(THMR_ERR_HIP, "hipMemset(lbs counters) failed");
     { const char* lg = getenv("THMR_LEGACY_HEAD"); e->legacy_head = lg && lg[0] == '1'; }
     { const char* mc = getenv("THMR_MIXER_CLUSTER"); e->mixer_cluster = !(mc && mc[0] == '0'); }
+    { const char* tg = getenv("THMR_TINY_GEMM"); e->tiny_gemm = !(tg && tg[0] == '0'); }
     { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
     *out = e;
     return 0;

@@ -680,6 +680,89 @@ int launch_ring(const GemmArgs& a, int epi, int ksplit, float* part, hipStream_t
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Tiny-M GEMM for the head's dependent chain at up to six crops (soft codebook lookup + the VQ decoder's Conv1d GEMMs: M = 21 ... 160
+// rows per crop, N = 256 / 512, K = 512 ... 2048).  The ring kernel above gives such a product 8-24 workgroups that each walk the
+// WHOLE K: 24-64 K tiles at ~0.5 us = 12-32 us per launch, 13 launches in a row = a third of the head at one crop
+// (profiles/r2s_head_b1_kernel_stats.csv).  Here a workgroup owns a 32x32 tile and its EIGHT waves split K eight ways:
+//   * no LDS staging: wave w's K slice is used by nobody else, so its A / W fragments go global -> VGPR (one 16-byte load per lane =
+//     4 consecutive k of one row: exactly the k-permuted MFMA operand), four k-groups ahead;
+//   * the eight partial tiles are added through LDS in wave order (fixed association: deterministic, independent of M);
+//   * wave 0 applies the same epilogues as the big kernels, including the im2col scatter for the next Conv1d.
+// A K slice is K / 8 (a multiple of 32).  The association of the K sum differs from the other kernels', so the engine uses this
+// kernel for a given layer at EVERY batch size of the small-batch regime (B <= 6) or not at all.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_tiny_kernel(GemmArgs a, int tiles_n) {
+    constexpr int NWV = 8, PF = 4;
+    __shared__ __attribute__((aligned(16))) float red[NWV][16][64];     // [wave][accumulator register][lane]
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * 32, n0 = tile_n * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int kper = a.K / NWV, ngrp = kper / 8;                        // 8-deep k-groups of this wave's slice; ngrp % PF == 0
+    const float* ap = a.A + (int64_t)min(m0 + lrow, a.M - 1) * a.lda + wave * kper + 4 * lhalf;
+    const float* wp = a.W + (int64_t)min(n0 + lrow, a.N - 1) * a.ldw + wave * kper + 4 * lhalf;
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
+    f32x4 af[PF], bf[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        af[j] = *reinterpret_cast<const f32x4*>(ap + j * 8);
+        bf[j] = *reinterpret_cast<const f32x4*>(wp + j * 8);
+    }
+#pragma unroll 1
+    for (int g0 = 0; g0 < ngrp; g0 += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][t], bf[j][t], acc[0][0], 0, 0, 0);
+            const int gn = min(g0 + j + PF, ngrp - 1);                  // past the end: re-fetch the last group (never used)
+            af[j] = *reinterpret_cast<const f32x4*>(ap + gn * 8);
+            bf[j] = *reinterpret_cast<const f32x4*>(wp + gn * 8);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wave][e][lane] = acc[0][0][e];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float v = red[0][e][lane];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) v += red[w][e][lane];
+        acc[0][0][e] = v;
+    }
+    if constexpr (EPI != EPI_BIAS_POS && EPI != EPI_BIAS_QSCALE) {
+        if (a.cs_out) {
+            store_tile_scatter<1, 1, EPI>(a, acc, m0, n0, lrow, lhalf);
+            return;
+        }
+    }
+    store_tile<1, 1, EPI>(a, acc, m0, n0, lrow, lhalf);
+}
+
+int launch_tiny(const GemmArgs& a, int epi, hipStream_t s) {
+    if (a.K % 256 != 0) return -1;
+    const int tiles_m = (a.M + 31) / 32, tiles_n = (a.N + 31) / 32;
+    dim3 grid(tiles_m * tiles_n), block(512);
+#define THMR_TINY_CASE(E)                                                              \
+    case E:                                                                            \
+        hipLaunchKernelGGL((gemm_tiny_kernel<E>), grid, block, 0, s, a, tiles_n);      \
+        break;
+    switch (epi) {
+        THMR_TINY_CASE(EPI_NONE)
+        THMR_TINY_CASE(EPI_BIAS)
+        THMR_TINY_CASE(EPI_BIAS_GELU)
+        THMR_TINY_CASE(EPI_BIAS_RELU)
+        THMR_TINY_CASE(EPI_BIAS_RESID)
+        default: return -1;
+    }
+#undef THMR_TINY_CASE
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // The trailing part of a grid that does not fill the 512 resident slots (2 blocks per CU) a whole number of times.  Up to 256
 // trailing tiles are best run ONE per CU (a block that is alone on its CU runs almost twice as fast: 0.5 round), but inside one
 // launch the dispatcher hands them to whichever slots free up first, and the two co-resident blocks of a CU retire together: that
@@ -735,7 +818,7 @@ int launch_abl(const GemmArgs& a, hipStream_t s) {
 
 // variant: 0 = 128x128 REG (2x2 waves of 64x64)   1 = 128x160 REG (4x1 waves of 32x160)
 //          7 = 128x128 DMA                         8 = 128x160 DMA            9 = 64x64 DMA (2x2 waves of 32x32)
-//         10 = 128x96 DMA (4x1 waves of 32x96)
+//         10 = 128x96 DMA (4x1 waves of 32x96)          11 = 32x32 tiny-M kernel (K split over 8 waves, no LDS staging)
 //         -1 = DMA, tile picked by a cost model over 256 CUs   (2 is the skinny kernel, see thmr_op_gemm)
 int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % BK) != 0) return -1;
@@ -757,10 +840,11 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         if (c7 < best) { best = c7; variant = 7; }
         if (c10 < best) { best = c10; variant = 10; }
         if (c9 < best) { best = c9; variant = 9; }
-        // at most one 64x64 block per CU: nothing hides the 2-buffer kernel's per-K-tile memory round trip, so the 4-deep
-        // ring version of the same tile is used (same K order, bit-identical; measured 46 -> ~30 us on the head's B = 1 convs)
+        // at most two 64x64 blocks per CU (the ring's 64 KB of LDS lets two share one): little hides the 2-buffer kernel's
+        // per-K-tile memory round trip, so the 4-deep ring version of the same tile is used (same K order, bit-identical; measured
+        // 46 -> ~30 us on the head's B = 1 convs; the 288-block decoder K/V GEMM of one crop ran 46 us on the 2-buffer kernel)
         const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-        if (variant == 9 && tiles64 <= 256 && epi != EPI_BIAS_POS) return launch_ring<4>(a, epi, 1, nullptr, s);
+        if (variant == 9 && tiles64 <= 512 && epi != EPI_BIAS_POS) return launch_ring<4>(a, epi, 1, nullptr, s);
     }
 #ifdef THMR_GEMM_ABLATION
     switch (variant) {     // 30 + ABL: timing-only ablations of the 128x160 DMA kernel (EPI_NONE)
@@ -779,6 +863,7 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     }
 #endif
     switch (variant) {
+        case 11: return launch_tiny(a, epi, s);                      // 32x32 tiles, K split over the 8 waves of a workgroup
         case 0: return launch_cfg<2, 2, 2, 2, false>(a, epi, s);
         case 1: return launch_cfg<4, 1, 1, 5, false>(a, epi, s);
         case 8: return launch_cfg<4, 1, 1, 5, true>(a, epi, s);
