@@ -243,6 +243,10 @@ def test_fused_head_equals_chain_head_across_batch_sizes(built_lib, cuda_dev, mo
     chain = Engine(cfg, max_batch=128, device=cuda_dev, weight_arena=fused.weight_arena)
     chain.finalize(assume_all_loaded=True)
     monkeypatch.delenv("THMR_LEGACY_HEAD")
+    monkeypatch.setenv("THMR_MIXER_CLUSTER", "0")        # the mixer stack as its own kernel, one workgroup per crop, at every batch size
+    plain = Engine(cfg, max_batch=128, device=cuda_dev, weight_arena=fused.weight_arena)
+    plain.finalize(assume_all_loaded=True)
+    monkeypatch.delenv("THMR_MIXER_CLUSTER")
     ctx = torch.randn(128, 192, 1280, generator=torch.Generator().manual_seed(12)).to(cuda_dev)
     keys = ("token_out", "cls_logits", "pose6d", "pred_vertices", "pred_cam")
     ref128 = {k: v.clone() for k, v in fused.head_forward(ctx, taps=True).items()}
@@ -261,9 +265,14 @@ def test_fused_head_equals_chain_head_across_batch_sizes(built_lib, cuda_dev, mo
         for k in keys:
             assert torch.equal(a[k], b[k]), (B, k)                                   # deterministic
             assert torch.equal(a[k], ref[k][:B]), (B, k)                             # batch-invariant within a regime of the fused head
+        if B in (1, 6, 25, 26, 49, 128):                                             # 10 / 5 / 2 workgroups per crop == one workgroup per crop
+            d = plain.head_forward(ctx[:B], taps=True)
+            for k in keys:
+                assert torch.equal(a[k], d[k]), (B, k)
         assert (a["token_out"] - c["token_out"]).abs().max() < 1e-4, B
         assert (a["cls_logits"] - c["cls_logits"]).abs().max() < 1e-4, B
         assert (a["pred_vertices"] - c["pred_vertices"]).abs().max() < 1e-5, B
         assert (a["token_idx"] != c["token_idx"]).float().mean() < 0.01, B           # only near-tie tokens may differ between regimes
     fused.status()
     chain.status()
+    plain.status()

@@ -220,9 +220,10 @@ struct DecParams {
     int depth, B;
     int timeline;                                     // 1: workgroup 0 stamps the wall clock into sync[16..] (diagnostics)
     int max_blocks;                                   // compute units of the device: at most one workgroup per CU is launched
-    // Distributed MLP-Mixer tail (decoder_fused.hip mixer_cluster_stage): with mixer_cluster != 0 the kernel also runs the mixer
-    // stack, ten workgroups per crop (one 16-token tile each), and the separate mixer_stack_kernel launch is skipped.  Needs
-    // 10 * B <= grid <= CUs.  mixy: two (B, 160, 64) exchange buffers for the LayerNorm-ed rows (alternating per layer).
+    // Distributed MLP-Mixer tail (decoder_fused.hip mixer_cluster_stage): with mixer_cluster = 10 / 5 / 2 the kernel also runs the
+    // mixer stack, that many workgroups per crop (1 / 2 / 5 of the ten 16-token tiles each), and the separate mixer_stack_kernel
+    // launch is skipped; 0 = off.  Needs mixer_cluster * B <= CUs.  mixy: two (B, 160, 64) exchange buffers for the LayerNorm-ed rows
+    // (alternating per layer).
     MixerParams mx;
     float* mixy[2];
     int mixer_cluster;

@@ -370,8 +370,9 @@ __device__ __forceinline__ void cross_attn_stage(const DecParams& p, int layer, 
 
 // ---- the MLP-Mixer stack, distributed: ten workgroups per crop, one 16-token tile each ---------------------------------------
 // token_classifier.py:92-101.  mixer_stack_kernel (one workgroup per crop) leaves all but B compute units idle and takes 0.30 ms
-// whatever the batch: at one crop a quarter of the head, 7 % of the whole call.  Here workgroup w < 10 B owns token tile w % 10 of
-// crop w / 10 from mixer_trans' LayerNorm to mixer_norm_layer:
+// whatever the batch: at one crop a quarter of the head, 7 % of the whole call.  Here a crop is shared by 10 / 5 / 2 workgroups
+// (p.mixer_cluster; up to 25 / 51 / 128 crops on 256 CUs) that own 1 / 2 / 5 of its ten 16-token tiles from mixer_trans'
+// LayerNorm to mixer_norm_layer:
 //   * per-token work (LayerNorm1 / 2, channel mixing, mixer_norm_layer) stays inside the owner;
 //   * token mixing needs every token of the crop: the owners publish their LayerNorm1 rows (device-scope stores), ONE grid barrier
 //     per layer, every workgroup gathers the crop's 160 rows into its LDS and recomputes the small hidden activation u (64 x 64,
@@ -385,15 +386,16 @@ __device__ __forceinline__ bool mixer_cluster_stage(const DecParams& p, GridSync
     using namespace mixer;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, g = lane >> 4;
     const int wg = blockIdx.x;
-    const bool active = wg < 10 * p.B;                       // workgroup-uniform
-    const int b = wg / 10, t0 = (wg - b * 10) * 16;
+    const int per_crop = p.mixer_cluster, tpw = 10 / per_crop;   // workgroups per crop (10, 5 or 2), token tiles per workgroup (1, 2 or 5)
+    const bool active = wg < per_crop * p.B;                 // workgroup-uniform
+    const int b = wg / per_crop, t0 = (wg - b * per_crop) * tpw * 16, nrow = tpw * 16;
     if (active) {
         f32x4 o[5];
         trans_ln<true>(p.mt + (int64_t)b * (T * H), p.mx.tln_w, p.mx.tln_b, redbuf, tid, lane, wave, o);
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int e0 = (i * NT + tid) * 4, t = e0 >> 6, h = e0 & 63;
-            if (t >= t0 && t < t0 + 16) *reinterpret_cast<f32x4*>(&Xl[(t - t0) * LD + h]) = o[i];
+            if (t >= t0 && t < t0 + nrow) *reinterpret_cast<f32x4*>(&Xl[(t - t0) * LD + h]) = o[i];
         }
     }
     __syncthreads();
@@ -403,7 +405,7 @@ __device__ __forceinline__ bool mixer_cluster_stage(const DecParams& p, GridSync
         float* yg = p.mixy[l & 1] + (int64_t)b * (T * H);
         if (active) {                                        // y = LayerNorm1(x) for the own rows -> exchange buffer
             const float gamma = w.ln1w[lane], beta = w.ln1b[lane];
-            for (int r = wave; r < 16; r += NW) st_dev(yg + (t0 + r) * H + lane, ln_row_value(Xl[r * LD + lane], gamma, beta));
+            for (int r = wave; r < nrow; r += NW) st_dev(yg + (t0 + r) * H + lane, ln_row_value(Xl[r * LD + lane], gamma, beta));
         }
         if (!grid_barrier(gs, tid, s_ok)) return false;
         if (active) {
@@ -415,19 +417,26 @@ __device__ __forceinline__ bool mixer_cluster_stage(const DecParams& p, GridSync
 #pragma unroll 1
             for (int tile = wave; tile < 16; tile += NW) token_mix1_tile(Y, U, w, tile, l15, g);
             __syncthreads();
-            if (wave < 4) token_mix2_tile(U, Xl, Y + t0 * LD, w, wave * 16, t0, l15, g);       // s = x + z for the own tokens
+#pragma unroll 1
+            for (int tile = wave; tile < 4 * tpw; tile += NW) {     // s = x + z for the own tokens: (h-tile, own token tile) pairs
+                const int tt = tile >> 2;
+                token_mix2_tile(U, Xl + tt * 16 * LD, Y + (t0 + tt * 16) * LD, w, (tile & 3) * 16, t0 + tt * 16, l15, g);
+            }
             __syncthreads();
-            channel_mix_tile_8waves(Y + t0 * LD, Xl, U, w, wave, lane, l15, g);     // u is dead: its LDS holds zh
+#pragma unroll 1
+            for (int tt = 0; tt < tpw; ++tt)                        // u is dead: its LDS holds zh
+                channel_mix_tile_8waves(Y + (t0 + tt * 16) * LD, Xl + tt * 16 * LD, U, w, wave, lane, l15, g);
         }
     }
-    if (active && wave == 0) norm_layer_tile(Xl, p.mx.out + ((int64_t)b * T + t0) * H, p.mx, l15, g);
+    if (active)
+        for (int tt = wave; tt < tpw; tt += NW) norm_layer_tile(Xl + tt * 16 * LD, p.mx.out + ((int64_t)b * T + t0 + tt * 16) * H, p.mx, l15, g);
     return true;
 }
 
 __global__ __launch_bounds__(NWAVE * 64) void decoder_persistent_kernel(DecParams p) {
     __shared__ __attribute__((aligned(16))) float mixY[mixer::T * mixer::LD];      // distributed mixer tail: the crop's LayerNorm-ed rows / s
     __shared__ __attribute__((aligned(16))) float mixU[mixer::H * mixer::LD];      // token-mixing hidden activation
-    __shared__ __attribute__((aligned(16))) float mixX[16 * mixer::LD];            // residual rows of the own token tile
+    __shared__ __attribute__((aligned(16))) float mixX[80 * mixer::LD];            // residual rows of the own token tiles (up to 5)
     __shared__ float mixred[mixer::NW];
     static_assert(mixer::NW == NWAVE, "the distributed mixer tail uses the decoder kernel's 8 waves");
     __shared__ __attribute__((aligned(16))) float red[NWAVE][64][4];         // 8 KB: K-slice partial tiles (also the attention weights)
@@ -519,10 +528,11 @@ int launch_decoder_fused(const DecParams& p, hipStream_t s) {
     // the steps deal their items round-robin)
     const int nsub = (p.B + 15) / 16;
     int grid = NBLK * (nsub < 4 ? nsub : 4);
-    if (p.mixer_cluster != 0 && grid < 10 * p.B) grid = 10 * p.B;      // the distributed mixer tail: one workgroup per (crop, 16-token tile)
+    if (p.mixer_cluster != 0 && p.mixer_cluster != 10 && p.mixer_cluster != 5 && p.mixer_cluster != 2) return -1;
+    if (grid < p.mixer_cluster * p.B) grid = p.mixer_cluster * p.B;     // the distributed mixer tail: mixer_cluster workgroups per crop
     if (p.max_blocks > 0 && grid > p.max_blocks) grid = p.max_blocks;
     if (grid > 256) grid = 256;                  // workgroup 0 polls one arrival flag per thread pair at most; flags[256]
-    if (p.mixer_cluster != 0 && grid < 10 * p.B) return -1;             // the caller decides with decoder_mixer_cluster_fits()
+    if (grid < p.mixer_cluster * p.B) return -1;                        // the caller picks a split that fits (engine.hip head_forward)
     hipLaunchKernelGGL(decoder_persistent_kernel, dim3(grid), dim3(NWAVE * 64), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

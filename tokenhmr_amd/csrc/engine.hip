@@ -557,10 +557,11 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
         // classifier's first Linear (decoder_fused.hip)
         DecParams d = e->dec;
         d.B = B;
-        // up to 25 crops the MLP-Mixer stack runs inside the same kernel, ten workgroups per crop (decoder_fused.hip
-        // mixer_cluster_stage; bit-identical to mixer_stack_kernel, which serves the larger batches one workgroup per crop)
-        mixer_in_decoder = e->mixer_cluster && 10 * B <= (d.max_blocks < 256 ? d.max_blocks : 256);
-        d.mixer_cluster = mixer_in_decoder ? 1 : 0;
+        // the MLP-Mixer stack runs inside the same kernel, 10 / 5 / 2 workgroups per crop while they fit one per CU (up to 25 / 51 /
+        // 128 crops on 256 CUs; decoder_fused.hip mixer_cluster_stage, bit-identical to mixer_stack_kernel's one workgroup per crop)
+        const int slots = d.max_blocks < 256 ? d.max_blocks : 256;
+        d.mixer_cluster = !e->mixer_cluster ? 0 : 10 * B <= slots ? 10 : 5 * B <= slots ? 5 : 2 * B <= slots ? 2 : 0;
+        mixer_in_decoder = d.mixer_cluster != 0;
         d.mx = e->mix;
         d.mixy[0] = cf; d.mixy[1] = cf2;
         LAUNCH_OK(launch_decoder_serialised(e, d, st));

@@ -757,6 +757,7 @@ int launch_tiny(const GemmArgs& a, int epi, hipStream_t s) {
         THMR_TINY_CASE(EPI_BIAS_GELU)
         THMR_TINY_CASE(EPI_BIAS_RELU)
         THMR_TINY_CASE(EPI_BIAS_RESID)
+        THMR_TINY_CASE(EPI_BIAS_QSCALE)
         default: return -1;
     }
 #undef THMR_TINY_CASE
