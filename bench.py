@@ -370,7 +370,7 @@ def main():
             # HBM traffic of that kernel from PMC counters (separate rocprofv3 --pmc passes, committed under profiles/;
             # FETCH_SIZE doubled per the gfx950 correction) — cannot be collected live inside this process, so it is a
             # RECORDED number and labelled as such
-            for pmc_file in ("r2_pmc_gemm.json", "r1_pmc_gemm.json"):
+            for pmc_file in ("r2x_pmc_gemm.json", "r2_pmc_gemm.json", "r1_pmc_gemm.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                         pmc = json.load(f).get(dom.replace("gemm_", ""))
