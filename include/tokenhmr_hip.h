@@ -173,7 +173,9 @@ int thmr_vq_decode(thmr_engine* e, const float* probs_dev, int32_t B, float* pos
  * 4 resid + (acc+bias), 5 (+bias)*qscale on cols < qcols, 6 +bias +pos_embed (patch embed).  K % 32 == 0; lda/ldc in
  * elements, multiples of 4, < 2^22.  variant: -1 = tile picked by the cost model (what the engine uses); 7 / 8 / 10 / 9 = the
  * 128x128 / 128x160 / 128x96 / 64x64 LDS-DMA tiles; 0 / 1 register-staged 128x128 / 128x160 (A/B only); 2 skinny (M <= 64);
- * 100 + j (110 + j) = 64x64 ring kernel, 4- (8-) deep, split-K 2^j.  Every variant sums K in the same order except split-K. */
+ * 100 + j (110 + j) = 64x64 ring kernel, 4- (8-) deep, split-K 2^j; 11 = tiny-M kernel (32x32 tiles, K split over the 8 waves of a
+ * workgroup; K % 256 == 0; epilogues 0-5; what the engine uses for the VQ decoder up to six crops).  Every variant sums K in the
+ * same order except split-K and the tiny-M kernel. */
 int thmr_op_gemm(const float* A_dev, int64_t lda, const float* W_dev, const float* bias_dev, const float* resid_dev,
                  float* C_dev, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi, float qscale, int32_t qcols,
                  int32_t variant, void* stream);

@@ -34,6 +34,9 @@ def test_library_has_gfx950_code_object(built_lib):
     with open(_cabi.LIB_PATH, "rb") as f:
         blob = f.read()
     assert b"gfx950" in blob and b"gemm_f32_kernel" in blob and b"vit_attention_kernel" in blob
+    # round 2: persistent attention, tiny-M GEMM, the decoder kernel that also runs the mixer stack
+    for sym in (b"vit_attention_persistent_kernel", b"gemm_tiny_kernel", b"gemm_ring_kernel", b"decoder_persistent_kernel", b"mixer_stack_kernel"):
+        assert sym in blob, sym
 
 
 @pytest.mark.parametrize("vd,dd", [(2, 2), (32, 6)])

@@ -22,6 +22,8 @@
 //     device-scope atomics.  It needs all workgroups resident: at most one 512-thread workgroup per CU, several such kernels of
 //     different engines are chained by the host (engine.hip launch_decoder_serialised), and the poll is BOUNDED: on timeout the
 //     kernel sets an error word (thmr_engine_status) and exits instead of hanging the GPU.
+#include <cstdlib>
+
 #include "mixer_device.h"
 
 namespace {
@@ -521,6 +523,7 @@ __global__ __launch_bounds__(NWAVE * 64) void decoder_persistent_kernel(DecParam
 
 }  // namespace
 
+constexpr int kDecMinGrid = 128;    // the final gemv_multi streams 42 MB of mixer_trans weights: 128 workgroups take it 2 % faster than 64 at B <= 16 (profiles/r2y_decoder_min_grid.log)
 int launch_decoder_fused(const DecParams& p, hipStream_t s) {
     if (p.B < 1 || p.depth < 1 || p.depth > 6) return -1;
     // one workgroup per (column tile, 16-row sub-tile) of the widest step, up to one per CU
@@ -528,6 +531,8 @@ int launch_decoder_fused(const DecParams& p, hipStream_t s) {
     // the steps deal their items round-robin)
     const int nsub = (p.B + 15) / 16;
     int grid = NBLK * (nsub < 4 ? nsub : 4);
+    static const int min_grid = [] { const char* e = getenv("THMR_DEC_MIN_GRID"); return e ? atoi(e) : kDecMinGrid; }();   // A/B knob
+    if (grid < min_grid) grid = min_grid;
     if (p.mixer_cluster != 0 && p.mixer_cluster != 10 && p.mixer_cluster != 5 && p.mixer_cluster != 2) return -1;
     if (grid < p.mixer_cluster * p.B) grid = p.mixer_cluster * p.B;     // the distributed mixer tail: mixer_cluster workgroups per crop
     if (p.max_blocks > 0 && grid > p.max_blocks) grid = p.max_blocks;
