@@ -39,6 +39,23 @@ def test_library_has_gfx950_code_object(built_lib):
         assert sym in blob, sym
 
 
+def test_one_hip_runtime_per_process_whatever_the_import_order(built_lib):
+    """The driver's smoke entry is `__graft_entry__.smoke()`, which calls build() — i.e. loads libtokenhmr_hip.so — BEFORE it
+    imports torch.  The library needs libamdhip64.so.7, PyTorch's libraries need "libamdhip64.so" and bring their own copy: loaded in
+    that order the process ends up with two HIP runtimes and thmr_create fails with "hipSetDevice failed" on a GPU box (seen in run Z
+    of round 2; the CPU-side symptom is two libamdhip64 mappings).  _cabi.load() therefore imports torch first.  Checked in a fresh
+    interpreter for both orders."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = "print(len(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l)))"
+    for code in (f"import sys; sys.path.insert(0, {root!r}); import __graft_entry__ as g; g.build(); import torch; {probe}",
+                 f"import sys; sys.path.insert(0, {root!r}); import torch; from tokenhmr_amd import _cabi; _cabi.load(); {probe}"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.strip().splitlines()[-1] == "1", (code, r.stdout, r.stderr[-500:])
+
+
 @pytest.mark.parametrize("vd,dd", [(2, 2), (32, 6)])
 def test_checkpoint_contract_cpp_equals_python(built_lib, vd, dd):
     cfg = HMRConfig(vit_depth=vd, dec_depth=dd)

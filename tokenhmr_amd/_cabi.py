@@ -69,6 +69,16 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    # ONE HIP runtime per process.  libtokenhmr_hip.so needs "libamdhip64.so.7" (resolved to /opt/rocm when nothing of that soname
+    # is loaded yet); PyTorch's libraries need "libamdhip64.so" and find the copy bundled under torch/lib, which the loader does NOT
+    # recognise as the same library when /opt/rocm's is already mapped under the other name — two runtimes, and the second one to
+    # touch the device fails (seen as "hipSetDevice failed" in thmr_create when this module was loaded before `import torch`).
+    # With torch imported first its runtime carries the soname libamdhip64.so.7 and is reused here.  Hosts without PyTorch
+    # (the plain C ABI) are unaffected.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     if missing:
