@@ -234,12 +234,13 @@ def test_vit_attention_peaked(built_lib, cuda_dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [33, 40, 100])
+@pytest.mark.parametrize("B", [11, 16, 28, 32, 33, 40, 100])
 def test_vit_attention_persistent_matches_the_64_query_variant(built_lib, cuda_dev, B):
-    """More than 512 (crop, head) items run on the persistent kernel (512 workgroups walking 2 ... 4 items each, the next item's K
-    fetched under the current P.V, a different LDS image: 84-float rows filled three rows per copy).  Every query must come out bit
-    for bit as from the 64-query variant that serves B <= 10 — B = 33 gives a grid where only some workgroups have a second item,
-    B = 100 up to four items per workgroup — and repeat runs must agree (missed wait / barrier)."""
+    """Batches of 11-16 and from 25 crops on run on the persistent kernel (a different LDS image: 84-float rows filled three rows per
+    copy; up to 32 crops one item per workgroup, above that 512 workgroups walking 2 ... 4 items each with the next item's K fetched
+    under the current P.V).  Every query must come out bit for bit as from the 64-query variant that serves B <= 10 — B = 33 gives a
+    grid where only some workgroups have a second item, B = 100 up to four items per workgroup — and repeat runs must agree (missed
+    wait / barrier)."""
     from tokenhmr_amd import ops
     qkv = _rand(B, 192, 3840, seed=100 + B)
     qkv[:, :, :1280] *= 80 ** -0.5

@@ -521,8 +521,14 @@ int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s) {
     if (B <= 0) return -1;
     // while 48*B workgroups of 64 queries still fit the 512 resident slots (2 per CU) they finish sooner than 16*B of 192
     static const int forced = [] { const char* e = getenv("THMR_ATTN_VARIANT"); return e ? atoi(e) : 0; }();   // A/B knob (scripts/)
-    // more than one round of 512 resident workgroups: the persistent form (5) fetches the next item under the current one
-    const int variant = forced ? forced : (B <= 10 ? 1 : (B * NH > 512 ? 5 : 3));
+    // The variants are bit-identical, so the choice is purely a matter of time (profiles/r2ab_attn_variant_sweep.log, us per launch):
+    //   1 = three 64-query workgroups per (crop, head): wins while its 48 B workgroups fill the 512 resident slots evenly — up to 10
+    //       crops (one round: 23-25 us vs 30-32) and again for 17-24 crops (two rounds: 44-54 us, where 16 B workgroups of 192
+    //       queries put two on some CUs and one on others: 56-58 us);
+    //   5 = the persistent kernel everywhere else; with at most 512 items every workgroup has one item and it is still ~3 % faster
+    //       than the plain 192-query kernel (3): one copy-offset register instead of 17, no spills; above 512 items it fetches the
+    //       next item under the current one.
+    const int variant = forced ? forced : ((B <= 10 || (B >= 17 && B <= 24)) ? 1 : 5);
     const AttnDbg nodbg{nullptr, 0, 0};
     if (variant == 5) {
         static const int dephase_us = [] { const char* e = getenv("THMR_ATTN_DEPHASE_US"); return e ? atoi(e) : kAttnDephaseUs; }();   // A/B knob
