@@ -3,7 +3,7 @@ set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R="${GRAFT_REPO_ROOT:-$PWD}"; cd "$R"
 : > gpurun_out/batch_sweep.log
-for B in 1 2 4 8 16 32 64 128 256; do
+for B in ${SWEEP_B:-1 2 4 8 16 32 64 128 256}; do
   timeout 600 python bench.py --batch $B --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{' | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']

@@ -841,11 +841,12 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         if (c7 < best) { best = c7; variant = 7; }
         if (c10 < best) { best = c10; variant = 10; }
         if (c9 < best) { best = c9; variant = 9; }
-        // at most two 64x64 blocks per CU (the ring's 64 KB of LDS lets two share one): little hides the 2-buffer kernel's
-        // per-K-tile memory round trip, so the 4-deep ring version of the same tile is used (same K order, bit-identical; measured
-        // 46 -> ~30 us on the head's B = 1 convs; the 288-block decoder K/V GEMM of one crop ran 46 us on the 2-buffer kernel)
+        // at most one 64x64 block per CU: nothing hides the 2-buffer kernel's per-K-tile memory round trip, so the 4-deep
+        // ring version of the same tile is used (same K order, bit-identical; measured 46 -> ~30 us on the head's B = 1 convs).
+        // NOT beyond 256 tiles: with two blocks per CU the 2-buffer kernel is the faster one (fc2 at 8 crops, 480 tiles: 176 us
+        // against 229 us on the ring kernel — a threshold of 512 was tried in round 2 and cost B = 8 11 %, profiles/r2ad_batch_sweep.jsonl)
         const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-        if (variant == 9 && tiles64 <= 512 && epi != EPI_BIAS_POS) return launch_ring<4>(a, epi, 1, nullptr, s);
+        if (variant == 9 && tiles64 <= 256 && epi != EPI_BIAS_POS) return launch_ring<4>(a, epi, 1, nullptr, s);
     }
 #ifdef THMR_GEMM_ABLATION
     switch (variant) {     // 30 + ABL: timing-only ablations of the 128x160 DMA kernel (EPI_NONE)
