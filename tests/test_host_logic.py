@@ -308,3 +308,16 @@ def test_attention_lds_dma_copies_keep_their_m0(built_lib, tmp_path):
             assert ins[i - 1][0] == "s_nop" and ins[i - 2][0] == "s_mov_b32" and ins[i - 2][1].startswith("m0,"), ins[i - 3:i + 1]
             assert re.search(r"s\[\d+:\d+\]", ins[i][1]), ins[i]
         assert sum(1 for op, a in ins if op.startswith("s_") and re.match(r"m0\b", a)) == len(dma)
+        if "persistent" in text[st]:
+            # The persistent kernel counts VMEM completion by hand across compiler-visible operations: before the next item starts it
+            # waits with vmcnt(30) for the K' copies, i.e. it RELIES on exactly 15 output stores + 15 Q' loads being the only younger
+            # operations of the wave.  Fewer (a toolchain that merges stores, or spill traffic moved elsewhere) would make the wait too
+            # weak: check the instruction stream between the last copy and that wait, and that the kernel has no scratch traffic.
+            w30 = [i for i, (op, a) in enumerate(ins) if op == "s_waitcnt" and a.replace(" ", "") == "vmcnt(30)"]
+            assert len(w30) == 1, [a for op, a in ins if op == "s_waitcnt" and "vmcnt" in a]
+            last_dma = max(i for i in dma if i < w30[0])
+            between = [op for op, _ in ins[last_dma + 1:w30[0]]]
+            assert between.count("global_store_dwordx4") == 15 and between.count("global_load_dwordx4") == 15, between
+            assert not any(op.startswith(("global_", "buffer_", "scratch_", "flat_")) and op not in ("global_store_dwordx4", "global_load_dwordx4")
+                           for op in between), between
+            assert not any(op.startswith("scratch_") for op, _ in ins), "register spills in the persistent attention kernel"
