@@ -56,3 +56,10 @@ def test_gemm_random_shapes_all_variants(built_lib, cuda_dev, M, N, kt, epi, see
             out = ops.gemm(ad, wd, None if epi == "none" else bd, rd if epi == "bias_resid" else None, epi=epi, qscale=0.25,
                            qcols=qcols, variant=f"ring4/k{ks}")
             assert torch.allclose(out.cpu(), ref, atol=4e-5, rtol=1e-5), (ks, (out.cpu() - ref).abs().max())
+    # tiny-M kernel (K split over the 8 waves of a workgroup): K % 256 == 0; its own association, fixed -> run twice, bit-equal
+    if kt % 8 == 0:
+        kw = dict(epi=epi, qscale=0.25, qcols=qcols, variant="tiny")
+        o1 = ops.gemm(ad, wd, None if epi == "none" else bd, rd if epi == "bias_resid" else None, **kw)
+        o2 = ops.gemm(ad, wd, None if epi == "none" else bd, rd if epi == "bias_resid" else None, **kw)
+        assert torch.allclose(o1.cpu(), ref, atol=4e-5, rtol=1e-5), ("tiny", (o1.cpu() - ref).abs().max())
+        assert torch.equal(o1, o2)
