@@ -293,17 +293,19 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 2) void vit_attention_kerne
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Persistent form of vit_attention_kernel<3, 4> for grids of more than 512 (crop, head) items (B > 32): 512 workgroups (two
-// per CU) each walk their items, and the NEXT item's operands are fetched under the CURRENT item's P.V phase:
+// Persistent form of vit_attention_kernel<3, 4>: at most 512 workgroups (two per CU) each walk their (crop, head) items, and the
+// NEXT item's K is fetched under the CURRENT item's P.V phase:
 //     ... | P.V(keys 0..95) | DMA K'[0:96] over the dead V half | P.V(keys 96..191) | DMA K'[96:192] | normalise + store |
 //     Q' -> registers | S'(keys 0..95) | ...
 // Why: at B = 64 the plain kernel's grid is two rounds of 512 workgroups, and every workgroup waited ~10 us for Q + K[0:96]
 // before its first MFMA (profiles/r2n_attn_timeline.log) — 66 MB requested by 512 workgroups at once; 20 of the kernel's
-// 29 us above its MFMA floor.  Here only a workgroup's FIRST item pays that.  Per query the instruction sequence is the one of
-// vit_attention_kernel, so results are bit-identical (scripts/micro/attn_timeline.hip checks it).
-// Q' is loaded by inline assembly: beside LDS-DMA copies that the compiler cannot see, its own vmcnt bookkeeping for ordinary
-// loads would wait for the K'[96:192] copies issued after them.  All VMEM completion is therefore counted by hand; per wave and
-// item, in issue order: V[0:96] x8, V[96:192] x8, K'[0:96] x8|9, Q' x15, K'[96:192] x8|9, output stores x15 (in-order return).
+// 29 us above its MFMA floor.  Here only a workgroup's FIRST item pays that.  With at most 512 items (one per workgroup) it is
+// still ~3 % faster than the plain kernel — one copy-offset register instead of 17, 240 registers — and serves those grids too
+// (launch_vit_attention).  Per query the instruction sequence is the one of vit_attention_kernel, so results are bit-identical
+// (scripts/micro/attn_timeline.hip and tests/test_gpu_ops.py check it).
+// VMEM operations per wave and item, in issue order (in-order return): V[0:96] x8, V[96:192] x8, K'[0:96] x8, K'[96:192] x8, output
+// stores x15, Q' x15.  The copies are invisible to the compiler and waited for by hand (vmcnt); the stores and Q' are ordinary
+// instructions whose count the hand-written vmcnt(30) relies on (ISA-level guard: tests/test_host_logic.py).
 constexpr int kAttnDephaseUs = 0;     // start-up delay of the odd threadgroup slot's workgroup (see the kernel)
 __device__ __forceinline__ void barrier_only() { asm volatile("s_barrier" ::: "memory"); }
 
