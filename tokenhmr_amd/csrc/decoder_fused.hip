@@ -50,8 +50,12 @@ struct GridSync {
     unsigned n;         // barriers passed so far
 };
 
-__device__ __forceinline__ bool grid_barrier(GridSync& gs, int tid, volatile int* s_ok) {
+// `pf` runs after this wave's stores have drained and before it waits: the place to request what the NEXT stage needs and does not
+// depend on the other workgroups (its weight fragments) — the loads then fly while the barrier is being crossed.
+template <class PF>
+__device__ __forceinline__ bool grid_barrier(GridSync& gs, int tid, volatile int* s_ok, PF&& pf) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's device-scope stores have completed
+    pf();
     __syncthreads();
     gs.n += 1;
     const unsigned epoch = gs.base + gs.n;
@@ -85,6 +89,10 @@ __device__ __forceinline__ bool grid_barrier(GridSync& gs, int tid, volatile int
     }
     __syncthreads();
     return *s_ok != 0;
+}
+
+__device__ __forceinline__ bool grid_barrier(GridSync& gs, int tid, volatile int* s_ok) {
+    return grid_barrier(gs, tid, s_ok, [] {});
 }
 
 // ---- one GEMV-class step: C[m][n] = epi(sum_k A'[m][k] W[n][k]), work item = (16-column tile, 16-row sub-tile) ------------
@@ -137,11 +145,31 @@ __device__ __forceinline__ void layernorm_frags(f32x4 (&xq)[NS], const f32x4 (&g
         for (int t = 0; t < 4; ++t) xq[s][t] = (xq[s][t] - mean) * rstd * gm[s][t] + bt[s][t];
 }
 
+// The W fragments of a workgroup's FIRST item of the next GEMV stage, requested while the grid barrier in front of that stage is
+// crossed (the weights do not depend on it; a step at few crops is one HBM round trip for 64 KB of weights + an L2 round trip for the
+// activations, and the barrier takes about as long as the former).  Same addresses as gemv_stage uses; item = -1: nothing requested.
+struct WPre {
+    f32x4 w[NS];
+    int item;
+};
+__device__ __forceinline__ void prefetch_w(WPre& pre, const float* __restrict__ W, int K, int N, int B, int tid) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, g = lane >> 4;
+    const int ntile = N >> 4, nsub = (B + 15) >> 4;
+    const int kper = K / NWAVE, kbeg = wave * kper, nstep = kper >> 4;
+    const int item = blockIdx.x;
+    pre.item = item < ntile * nsub ? item : -1;
+    if (pre.item < 0) return;
+    const float* wp = W + (int64_t)((item % ntile) * 16 + l15) * K + kbeg + g * 4;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (s < nstep) pre.w[s] = *reinterpret_cast<const f32x4*>(wp + s * 16);
+}
+
 template <bool LN, int EPI>
 __device__ __forceinline__ void gemv_stage(const float* __restrict__ A, int lda, const float* __restrict__ gamma,
                                            const float* __restrict__ beta, const float* __restrict__ W, int K,
                                            const float* __restrict__ bias, const float* resid, float* C, int ldc, int N, int B,
-                                           float (*red)[64][4], RowStat* rs, int tid) {
+                                           float (*red)[64][4], RowStat* rs, int tid, const WPre& pre) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, g = lane >> 4;   // wave: SGPR
     const int ntile = N >> 4, nsub = (B + 15) >> 4;
     const int kper = K / NWAVE, kbeg = wave * kper, nstep = kper >> 4;    // K = 1024 -> 8 steps of 16 k, K = 512 -> 4
@@ -159,10 +187,12 @@ __device__ __forceinline__ void gemv_stage(const float* __restrict__ A, int lda,
         const float* wp = W + (int64_t)(n0 + l15) * K + kbeg + g * 4;
         const float* ap = A + (int64_t)min(m0 + l15, B - 1) * lda + kbeg + g * 4;
         f32x4 wq[NS], xq[NS];
+        const bool have_w = item == pre.item;             // requested under the grid barrier in front of this stage (workgroup-uniform)
 #pragma unroll
         for (int s = 0; s < NS; ++s)
             if (s < nstep) {
-                wq[s] = *reinterpret_cast<const f32x4*>(wp + s * 16);
+                if (have_w) wq[s] = pre.w[s];
+                else wq[s] = *reinterpret_cast<const f32x4*>(wp + s * 16);
                 xq[s] = ld_dev4(ap + s * 16);
             }
         if constexpr (LN) layernorm_frags(xq, gm, bt, rs, wave, l15, g);
@@ -463,40 +493,48 @@ __global__ __launch_bounds__(NWAVE * 64) void decoder_persistent_kernel(DecParam
         st_dev(p.dx + i, p.tok_bias[c] + p.pos[c]);
     }
     THMR_STAMP();
-    ok = grid_barrier(gs, tid, &s_ok);
+    WPre pre;
+    pre.item = -1;
+    ok = grid_barrier(gs, tid, &s_ok, [&] { prefetch_w(pre, p.L[0].wv, E, INNER, B, tid); });
     THMR_STAMP();
     for (int l = 0; ok && l < p.depth; ++l) {
         const DecLayerW& w = p.L[l];
         // self-attention over ONE token: softmax of a single score == 1, so out = to_out(v)   (pose_transformer.py:75-86)
-        gemv_stage<true, 0>(p.dx, E, w.n0w, w.n0b, w.wv, E, nullptr, nullptr, p.dv, INNER, INNER, B, red, &rowstat, tid);
+        gemv_stage<true, 0>(p.dx, E, w.n0w, w.n0b, w.wv, E, nullptr, nullptr, p.dv, INNER, INNER, B, red, &rowstat, tid, pre);
         THMR_STAMP();
-        if (!(ok = grid_barrier(gs, tid, &s_ok))) break;
+        if (!(ok = grid_barrier(gs, tid, &s_ok, [&] { prefetch_w(pre, w.wo1, INNER, E, B, tid); }))) break;
         THMR_STAMP();
-        gemv_stage<false, 4>(p.dv, INNER, nullptr, nullptr, w.wo1, INNER, w.bo1, p.dx, p.dx, E, E, B, red, &rowstat, tid);
+        gemv_stage<false, 4>(p.dv, INNER, nullptr, nullptr, w.wo1, INNER, w.bo1, p.dx, p.dx, E, E, B, red, &rowstat, tid, pre);
         THMR_STAMP();
-        if (!(ok = grid_barrier(gs, tid, &s_ok))) break;
+        if (!(ok = grid_barrier(gs, tid, &s_ok, [&] { prefetch_w(pre, w.wq, E, INNER, B, tid); }))) break;
         THMR_STAMP();
         // cross-attention (pose_transformer.py:111-124); the context is NOT normalised (PreNorm only touches x)
-        gemv_stage<true, 0>(p.dx, E, w.n1w, w.n1b, w.wq, E, nullptr, nullptr, p.dq, INNER, INNER, B, red, &rowstat, tid);
+        gemv_stage<true, 0>(p.dx, E, w.n1w, w.n1b, w.wq, E, nullptr, nullptr, p.dq, INNER, INNER, B, red, &rowstat, tid, pre);
         THMR_STAMP();
+        pre.item = -1;
         if (!(ok = grid_barrier(gs, tid, &s_ok))) break;
         THMR_STAMP();
         cross_attn_stage(p, l, tid, &red[__builtin_amdgcn_readfirstlane(tid >> 6)][0][0]);
         THMR_STAMP();
-        if (!(ok = grid_barrier(gs, tid, &s_ok))) break;
+        if (!(ok = grid_barrier(gs, tid, &s_ok, [&] { prefetch_w(pre, w.wo2, INNER, E, B, tid); }))) break;
         THMR_STAMP();
-        gemv_stage<false, 4>(p.dca, INNER, nullptr, nullptr, w.wo2, INNER, w.bo2, p.dx, p.dx, E, E, B, red, &rowstat, tid);
+        gemv_stage<false, 4>(p.dca, INNER, nullptr, nullptr, w.wo2, INNER, w.bo2, p.dx, p.dx, E, E, B, red, &rowstat, tid, pre);
         THMR_STAMP();
-        if (!(ok = grid_barrier(gs, tid, &s_ok))) break;
+        if (!(ok = grid_barrier(gs, tid, &s_ok, [&] { prefetch_w(pre, w.w1, E, DMLP, B, tid); }))) break;
         THMR_STAMP();
         // feed-forward (pose_transformer.py:40-52)
-        gemv_stage<true, 2>(p.dx, E, w.n2w, w.n2b, w.w1, E, w.b1, nullptr, p.dff, DMLP, DMLP, B, red, &rowstat, tid);
+        gemv_stage<true, 2>(p.dx, E, w.n2w, w.n2b, w.w1, E, w.b1, nullptr, p.dff, DMLP, DMLP, B, red, &rowstat, tid, pre);
         THMR_STAMP();
-        if (!(ok = grid_barrier(gs, tid, &s_ok))) break;
+        if (!(ok = grid_barrier(gs, tid, &s_ok, [&] { prefetch_w(pre, w.w2, DMLP, E, B, tid); }))) break;
         THMR_STAMP();
-        gemv_stage<false, 4>(p.dff, DMLP, nullptr, nullptr, w.w2, DMLP, w.b2, p.dx, p.dx, E, E, B, red, &rowstat, tid);
+        gemv_stage<false, 4>(p.dff, DMLP, nullptr, nullptr, w.w2, DMLP, w.b2, p.dx, p.dx, E, E, B, red, &rowstat, tid, pre);
         THMR_STAMP();
-        if (!(ok = grid_barrier(gs, tid, &s_ok))) break;
+        if (l + 1 < p.depth) {
+            if (!(ok = grid_barrier(gs, tid, &s_ok, [&] { prefetch_w(pre, p.L[l + 1].wv, E, INNER, B, tid); }))) break;
+        } else {
+            pre.item = -1;
+            if (!(ok = grid_barrier(gs, tid, &s_ok))) break;
+        }
         THMR_STAMP();
     }
     if (ok) {
