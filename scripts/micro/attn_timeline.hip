@@ -195,6 +195,29 @@ int main(int argc, char** argv) {
             std::sort(ts.begin(), ts.end());
             printf("persistent, odd slot starts %2d us late: %.1f us per launch (bit-identical %d)\n", dly, ts[ts.size() / 2], (int)same());
         }
+    // (f) persistent kernel with s_setprio(1) around its MFMA phases (the two workgroups of a CU are in different phases)
+    for (int rep = 0; rep < 3; ++rep) {
+        float t[2];
+        for (int v = 0; v < 2; ++v) {
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            std::vector<float> ts;
+            for (int i = 0; i < 15; ++i) {
+                (void)hipEventRecord(e0);
+                if (v == 0) hipLaunchKernelGGL((vit_attention_persistent_kernel<0>), dim3(512), dim3(256), 0, 0, qkv, out, B * NH, nodbg);
+                else hipLaunchKernelGGL((vit_attention_persistent_kernel<8>), dim3(512), dim3(256), 0, 0, qkv, out, B * NH, nodbg);
+                (void)hipEventRecord(e1);
+                (void)hipEventSynchronize(e1);
+                float ms;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (i >= 3) ts.push_back(ms * 1e3f);
+            }
+            std::sort(ts.begin(), ts.end());
+            t[v] = ts[ts.size() / 2];
+        }
+        printf("persistent: plain %.1f us | s_setprio(1) in the MFMA phases %.1f us (bit-identical %d)\n", t[0], t[1], (int)same());
+    }
     {   // timeline of the persistent kernel's FIRST items
         AttnDbg d1p{tl, 0, 0};
         hipLaunchKernelGGL((vit_attention_persistent_kernel<1>), dim3(512), dim3(256), 0, 0, qkv, out, B * NH, d1p);

@@ -403,12 +403,16 @@ __global__ __launch_bounds__(256, 2) void vit_attention_persistent_kernel(const 
                 ka = kn;
             }
         };
+        if constexpr ((DBG & 8) != 0) __builtin_amdgcn_s_setprio(1);
         s_half(0);
+        if constexpr ((DBG & 8) != 0) __builtin_amdgcn_s_setprio(0);
         THMR_ATTN_STAMP(3)
         wait_vm_barrier<0>();          // K[96:192] landed (and the previous item's stores); every wave is done with the first K half
         dma_rows(base + 2 * DIM, 0);
         THMR_ATTN_STAMP(4)
+        if constexpr ((DBG & 8) != 0) __builtin_amdgcn_s_setprio(1);
         s_half(1);
+        if constexpr ((DBG & 8) != 0) __builtin_amdgcn_s_setprio(0);
         THMR_ATTN_STAMP(5)
         barrier_only();                // every wave is done with the second K half
         dma_rows(base + (int64_t)HALF * QKV_LD + 2 * DIM, 1);
@@ -471,12 +475,16 @@ __global__ __launch_bounds__(256, 2) void vit_attention_persistent_kernel(const 
         THMR_ATTN_STAMP(7)
         wait_vm_barrier<CPW>();   // V[0:96] landed for every wave
         THMR_ATTN_STAMP(8)
+        if constexpr ((DBG & 8) != 0) __builtin_amdgcn_s_setprio(1);
         pv_half(0);
+        if constexpr ((DBG & 8) != 0) __builtin_amdgcn_s_setprio(0);
         THMR_ATTN_STAMP(9)
         wait_vm_barrier<0>();              // V[96:192] landed; every wave is done with the first V half ...
         if (has_next) dma_rows(nbase + DIM, 0);       // ... which the next item's K[0:96] overwrites
         THMR_ATTN_STAMP(10)
+        if constexpr ((DBG & 8) != 0) __builtin_amdgcn_s_setprio(1);
         pv_half(1);
+        if constexpr ((DBG & 8) != 0) __builtin_amdgcn_s_setprio(0);
         THMR_ATTN_STAMP(11)
         barrier_only();                    // every wave is done with the second V half
         if (has_next) dma_rows(nbase + (int64_t)HALF * QKV_LD + DIM, 1);
