@@ -29,7 +29,6 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0
 GFLOP_PER_CROP = {"full": 252.10, "vit": 248.01}
-CPU_THREADS = 16                  # fixed thread policy of the CPU baseline (see cpu_baseline)
 
 
 def parse(argv=None):
@@ -38,6 +37,9 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="BASELINE configs[3]: shard ONE global batch of this many crops over the ranks (ragged shards allowed, "
+                         "e.g. 509 over 8) instead of --batch crops per GPU; the line then says scaling = strong")
     ap.add_argument("--workload", choices=["full", "vit"], default="full")
     ap.add_argument("--vit-depth", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -111,42 +113,77 @@ class FakeEngine:
         return {}
 
 
-def cpu_baseline(cfg, sd, tok, smpl, workload):
+def usable_cpus():
+    """Hardware threads this process may actually use: the affinity mask, capped by the cgroup v2 CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(cfg, sd, tok, smpl, workload, budget_s=150.0):
     """The oracle (CPU restatement pinned bit-exact to the reference's own modules) on this host's cores, the way SURVEY.md
-    §8(d) asks: B = 1 (BASELINE.json configs[0]) and B = 8 (best CPU throughput), median of 5 passes each after one warm-up.
-    Thread policy (fixed, documented): torch.set_num_threads(min(16, os.cpu_count())) — on the 2-socket EPYC hosts of the GPU
-    boxes 16 threads is the fastest setting for these GEMM sizes (all 256 hardware threads are ~50x slower), and a fixed count
-    makes the number comparable between boxes.  ~20 s of CPU work."""
+    §8(d) asks: B = 1 (BASELINE.json configs[0]) and B = 8 (best CPU throughput).
+    Thread policy = the best of a RECORDED sweep (round 2 asserted 16): torch.set_num_threads(t) for t in {8, 16, 32, 64, 128}
+    capped by the usable hardware threads (affinity mask and cgroup quota); per t one warm-up + one timed pass over 8 crops,
+    guarded by a one-crop probe (an oversubscribed setting is ~50x slower: it is skipped after the probe, not after 2 minutes);
+    then the median of 5 passes at the best t for B = 8 (`value`) and B = 1 (`value_b1`).  The sweep is in the line."""
     import torch
     from oracle import tokenhmr_oracle as O
-    ncpu = os.cpu_count()
-    threads = min(CPU_THREADS, ncpu)
-    torch.set_num_threads(threads)
+    ncpu, usable = os.cpu_count(), usable_cpus()
     g = torch.Generator().manual_seed(4001)
     img = torch.randn(8, 3, 256, 256, generator=g)
 
     def fn(x):
         return O.forward(x, sd, tok, smpl, cfg) if workload == "full" else O.vit_forward(x, sd, cfg)
 
-    res = {}
+    def timed(x):
+        t0 = time.perf_counter()
+        fn(x)
+        return time.perf_counter() - t0
+
     t_start = time.perf_counter()
+    counts = sorted({min(t, usable) for t in (8, 16, 32, 64, 128)})
+    sweep, best_probe = [], None
     with torch.no_grad():
-        for B in (1, 8):
+        for t in counts:
+            if time.perf_counter() - t_start > budget_s * 0.6:
+                sweep.append({"threads": t, "skipped": "time budget"})
+                continue
+            torch.set_num_threads(t)
+            probe = min(timed(img[:1]), timed(img[:1]))                     # one crop, best of two (first call warms the pool)
+            if best_probe is not None and probe > 3.0 * best_probe:
+                sweep.append({"threads": t, "b1_probe_crops_s": round(1.0 / probe, 3), "skipped": "one-crop probe > 3x slower than the best setting"})
+                continue
+            best_probe = probe if best_probe is None else min(best_probe, probe)
+            timed(img)                                                      # warm-up at B = 8
+            dt = timed(img)
+            sweep.append({"threads": t, "b1_probe_crops_s": round(1.0 / probe, 3), "b8_crops_s": round(8.0 / dt, 3)})
+        ran = [e for e in sweep if "b8_crops_s" in e]
+        threads = max(ran, key=lambda e: e["b8_crops_s"])["threads"]
+        torch.set_num_threads(threads)
+        res = {}
+        for B in (8, 1):
             fn(img[:B])
             ts = []
             for _ in range(5):
-                t0 = time.perf_counter()
-                fn(img[:B])
-                ts.append(time.perf_counter() - t0)
-                if time.perf_counter() - t_start > 90:       # bound the leg on a slow host
+                ts.append(timed(img[:B]))
+                if time.perf_counter() - t_start > budget_s:                # bound the leg on a slow host
                     break
             ts.sort()
             res[B] = (B / ts[len(ts) // 2], len(ts))
     return {"value": round(res[8][0], 3), "unit": "crops/s", "cores": threads, "kind": "port", "host_cpus": ncpu,
+            "usable_cpus": usable, "sweep": sweep,
             "value_b1": round(res[1][0], 3), "value_b8": round(res[8][0], 3),
             "sample": (f"oracle (torch CPU fp32, restatement pinned bit-exact to the reference modules), {workload} path, "
                        f"median of {res[8][1]} passes over 8 crops (value, value_b8) and of {res[1][1]} passes over 1 crop "
-                       f"(value_b1 = BASELINE configs[0]), torch.set_num_threads({threads}) fixed")}
+                       f"(value_b1 = BASELINE configs[0]) at torch.set_num_threads({threads}) = the best of the recorded sweep "
+                       f"over {counts} threads ({usable} usable of {ncpu})")}
 
 
 def parity_vs_golden(o, B, cfg, workload):
@@ -236,8 +273,27 @@ def main():
     from tokenhmr_amd.smpl_assets import make_synthetic_smpl
 
     cfg = HMRConfig(vit_depth=a.vit_depth)
-    B = a.batch
+    # per-rank crops: weak scaling (--batch per GPU, the driver's form) or one global batch dealt in contiguous, balanced shards
+    sizes = D.shard_sizes(a.global_batch, world) if a.global_batch else [a.batch] * world
+    if min(sizes) < 1:
+        sys.exit(f"bench.py: --global-batch {a.global_batch} leaves a rank without crops at {world} ranks")
+    B, total_batch = sizes[rank], sum(sizes)
+    crop0 = sum(sizes[:rank])                                  # this rank's first crop in the global batch
     build_info = None
+    # LOCAL_RANK -> device: every rank of the node must sit on its own GPU (a launcher that exports a wrong LOCAL_RANK would
+    # silently stack ranks on one device and the "scaling" would be time-slicing)
+    ident = {"rank": rank, "local_rank": local_rank, "device": None if cpu_dry else torch.cuda.current_device(),
+             "uuid": None if cpu_dry else str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")) or None,
+             "host": socket.gethostname()}
+    if not cpu_dry:
+        assert torch.cuda.current_device() == local_rank, f"rank {rank}: current device {torch.cuda.current_device()} != LOCAL_RANK {local_rank}"
+    idents = [ident]
+    if use_dist:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        if not cpu_dry:
+            devs = [(i["host"], i["device"]) for i in idents]
+            assert len(set(devs)) == world, f"ranks share a GPU: {devs}"
     if cpu_dry:
         eng = FakeEngine(rank)
     else:
@@ -252,8 +308,9 @@ def main():
         from tokenhmr_amd.engine import Engine
         build_info = _cabi.load().thmr_build_info().decode()
         assert f"src:{__graft_entry__.source_hash()}" in build_info, f"stale libtokenhmr_hip.so: {build_info}"
-        eng = Engine(cfg, max_batch=B, device=dev)
+        eng = Engine(cfg, max_batch=max(sizes), device=dev)
     sd = tok = smpl = None
+    read_ckpt = rank == 0                                      # ONLY rank 0 touches the "checkpoint"; the line lists who did
     if rank == 0:
         # rank 0 "reads the checkpoint" (synthetic: no network for real weights) ...
         if not cpu_dry:
@@ -261,25 +318,52 @@ def main():
         smpl = make_synthetic_smpl(cfg, 0)
         eng.load_state(sd, tok)
         eng.load_smpl(smpl)
+    bcast_ms = None
     if use_dist:
+        # The arena is complete for a broadcast once load_state / load_smpl have returned (thmr_load_weights writes the index
+        # tables and flag words; round 2 wrote them in finalize and shipped uninitialised tables to the other ranks): the root
+        # may finalize before or after.  Receivers finalize with assume_all_loaded, which REQUIRES the loader's magic word.
         sync()
+        dist.barrier()
+        t_b = time.perf_counter()
         D.broadcast_weights(eng, src=0)        # ... and ONE RCCL broadcast replicates the packed arena
         sync()
+        bcast_ms = (time.perf_counter() - t_b) * 1e3
     eng.finalize(assume_all_loaded=(rank != 0))
 
-    g = torch.Generator().manual_seed(4000 + rank)       # rank 0: the crops of tests/golden/full_d32_b64.npz
-    shape = (B, 3, 8, 8) if cpu_dry else (B, 3, 256, 256)
-    img = torch.randn(*shape, generator=g).to(dev)       # resident in HBM before timing
+    def crops_of(r):
+        """rank r's shard of the global batch: seeded per rank (rank 0 at 64 crops = tests/golden/full_d32_b64.npz), so any
+        rank can regenerate any other rank's crops for the cross-rank check below"""
+        gen = torch.Generator().manual_seed(4000 + r)
+        shp = (sizes[r], 3, 8, 8) if cpu_dry else (sizes[r], 3, 256, 256)
+        return torch.randn(*shp, generator=gen)
+
+    img = crops_of(rank).to(dev)                         # resident in HBM before timing
     outs = eng._alloc_outputs(B, taps=False, want_probs=True)
     feats = None if cpu_dry else torch.empty(B, 192, 1280, device=dev)
     gather = use_dist and not a.no_gather and a.workload == "full"
 
     pending = []        # the previous step's all-gather, still in flight on the RCCL stream
     last = {}
+    # how long the compute stream actually WAITS for the gather it joins (0 when the xGMI traffic hid under the next ViT):
+    # HIP events on the launch stream around the wait (RCCL's wait() is a stream dependency, it does not block the host); on the
+    # CPU dry run the host clock
+    gw = {"ev": [], "host_s": 0.0, "on": False}
 
     def join():
         while pending:
-            last["records"] = pending.pop().wait()
+            h = pending.pop()
+            if gw["on"] and not cpu_dry:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                last["records"] = h.wait()
+                e1.record()
+                gw["ev"].append((e0, e1))
+            else:
+                t_w = time.perf_counter()
+                last["records"] = h.wait()
+                if gw["on"]:
+                    gw["host_s"] += time.perf_counter() - t_w
 
     def step():
         if a.workload == "vit":
@@ -293,7 +377,7 @@ def main():
             # time the next-but-one step starts (and all of them before the timed region closes)
             rec = D.pack_records(o)
             join()
-            pending.append(D.all_gather_records(rec, B * world, async_op=True))
+            pending.append(D.all_gather_records(rec, total_batch, async_op=True))
 
     for _ in range(a.warmup):
         step()
@@ -303,6 +387,7 @@ def main():
     # launches of a step costs ~1 % of it): the roofline of the dominant kernel is measured live in the timed region, the
     # full per-class breakdown comes from a separate untimed pass below.
     eng.prof_enable("gemm")
+    gw["on"] = True
     ev = [] if cpu_dry else [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     if use_dist:
         dist.barrier()
@@ -320,7 +405,9 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    gw["on"] = False
     step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps)) if ev else []
+    gather_wait_ms = (sum(e0.elapsed_time(e1) for e0, e1 in gw["ev"]) if gw["ev"] else gw["host_s"] * 1e3) / max(1, a.steps)
     eng.prof_enable(False)
     prof = eng.prof_collect()
     if not cpu_dry:
@@ -335,22 +422,47 @@ def main():
         sync()
         eng.prof_enable(False)
         prof_all = eng.prof_collect()
-    gathered_ok = None
+    gathered_ok, cross = None, None
     if gather and "records" in last:
         # every rank must hold all ranks' crops in crop order, and its own rows must equal what it just computed
         rec = last["records"]
         mine = D.pack_records(last["out"])
-        gathered_ok = bool(rec.shape[0] == B * world and torch.equal(rec[rank * B:(rank + 1) * B], mine))
+        gathered_ok = bool(rec.shape[0] == total_batch and torch.equal(rec[crop0:crop0 + B], mine))
         t = torch.tensor([1.0 if gathered_ok else 0.0], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         gathered_ok = bool(t.item() == 1.0)
+        if rank == 0 and world > 1 and not a.no_extras:
+            # ... and the OTHER ranks' rows must be what a correctly loaded model computes: rank 0 (which read the checkpoint)
+            # regenerates each rank's seeded crops, runs them through its own engine and compares the gathered rows bit for bit —
+            # same kernels, same arithmetic, another GPU.  This is the check that catches a receiver whose broadcast arena was
+            # incomplete (the round-2 regression: uninitialised resample tables on ranks != 0), which "my own rows equal what I
+            # computed" cannot.
+            worst, same = 0.0, True
+            for r in range(1, world):
+                x_r = crops_of(r).to(dev)
+                o_r = eng.forward(x_r) if cpu_dry else eng.forward(x_r, want_probs=False)
+                want = D.pack_records(o_r)
+                got = rec[sum(sizes[:r]):sum(sizes[:r + 1])]
+                same = same and torch.equal(got, want)
+                worst = max(worst, float((got[:, :20670 + 132] - want[:, :20670 + 132]).abs().max()))
+            sync()
+            cross = {"ranks_checked": world - 1, "bit_identical": bool(same), "max_abs_diff_verts_joints_m": worst,
+                     "how": "rank 0 recomputed every other rank's seeded shard on its own engine and compared the gathered records"}
+    rank_step = None
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # per-rank view of the timed region, so that a slow first 8-GPU run diagnoses itself: median step time on each rank's
+        # launch stream, exposed gather wait, and who read the checkpoint
+        mine = {"rank": rank, "step_ms_median": round(step_ms[len(step_ms) // 2], 3) if step_ms else None,
+                "gather_wait_ms_per_step": round(gather_wait_ms, 4), "read_checkpoint": bool(read_ckpt), "crops": B,
+                "bcast_ms": round(bcast_ms, 1) if bcast_ms is not None else None}
+        rank_step = [None] * world
+        dist.all_gather_object(rank_step, mine)
 
     if rank == 0:
-        total_crops = B * world * a.steps
+        total_crops = total_batch * a.steps
         value = total_crops / elapsed
         # dominant kernel = the GEMM class with the largest share of the timed region
         gemms = {k: v for k, v in prof.items() if k.startswith("gemm_") and v["launches"] > 0}
@@ -404,33 +516,68 @@ def main():
                                        "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_ms": round(lbs["ms"] / lbs["launches"], 4)}
                     if world == 1:
                         roof["lbs_hbm_b512"] = lbs_at_b512(dev, smpl)
-        par = None
+        par, facade = None, None
         if not a.no_extras and not cpu_dry and "out" in last:
             par = parity_vs_golden(last["out"], B, cfg, a.workload)
+            if world == 1:
+                # the drop-in's own rate: `model(batch)` through the facade (tokenhmr_amd/model.py) allocates its output tensors per
+                # call (84 MB of cls_logits_softmax at 64 crops) where the timed region above reuses pre-allocated ones
+                from tokenhmr_amd.model import TokenHMR
+                model = TokenHMR.from_engine(eng)
+                for _ in range(3):
+                    model({"img": img})
+                sync()
+                n_f = max(5, min(a.steps, 20))
+                t_f = time.perf_counter()
+                for _ in range(n_f):
+                    model({"img": img})
+                sync()
+                f_ms = (time.perf_counter() - t_f) / n_f * 1e3
+                facade = {"ms_per_call": round(f_ms, 3), "crops_per_s": round(B / (f_ms * 1e-3), 2), "calls": n_f,
+                          "vs_engine_forward": round((elapsed / a.steps * 1e3) / f_ms, 4),
+                          "what": "TokenHMR facade model({'img': ...}) -> dict, outputs allocated per call (untimed extra)"}
         cpu = None
         if world == 1 and not a.no_cpu_baseline and not cpu_dry:
             cpu = cpu_baseline(cfg, sd, tok, smpl, a.workload)
         line = {
             "metric": "crops_per_sec", "value": round(value, 2), "unit": "crops/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if a.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("TokenHMR full path (ViT-H/16 + 6-layer token decoder + VQ lookup/decode + SMPL LBS), "
                                     "256x256 crops, random-init weights" if a.workload == "full" else
                                     "ViT-H/16 encoder only, 256x256 crops, random-init weights"),
-                       "batch_per_gpu": B, "global_batch": B * world, "vit_depth": cfg.vit_depth,
+                       "batch_per_gpu": B if not a.global_batch else sizes, "global_batch": total_batch, "vit_depth": cfg.vit_depth,
                        "parallelism": f"dp{world}", "allgather_outputs": bool(gather),
                        "ranks": (dist.get_world_size() if use_dist else 1),
                        "backend": (dist.get_backend() if use_dist else None)},
             "roofline": roof, "cpu_baseline": cpu, "parity": par,
         }
+        if facade:
+            line["facade"] = facade
         if step_ms:
             # per-step HIP-event durations on the launch stream (median of >= 20 timed iterations);
             # `value` / `ms_per_step` stay the barrier-bracketed wall-clock numbers the driver cross-checks
             med = step_ms[len(step_ms) // 2]
             line["step_ms"] = {"median": round(med, 3), "min": round(step_ms[0], 3), "max": round(step_ms[-1], 3), "n": len(step_ms)}
-            line["value_at_median_step"] = round(B * world / (med * 1e-3), 2)
+            line["value_at_median_step"] = round(total_batch / (med * 1e-3), 2)
         if gathered_ok is not None:
             line["gathered_records_ok"] = gathered_ok
+        if use_dist:
+            meds = [r["step_ms_median"] for r in rank_step if r["step_ms_median"] is not None]
+            line["multi_gpu"] = {
+                "bcast_ms": max(r["bcast_ms"] for r in rank_step) if bcast_ms is not None else None,
+                "bcast_bytes": int(eng.weight_arena.numel()),
+                "gather_ms_exposed": max(r["gather_wait_ms_per_step"] for r in rank_step),
+                "gather_bytes_per_step": int(total_batch * D.RECORD_WORDS * 4) if gather else 0,
+                "rank_step_ms": {"min": min(meds), "max": max(meds)} if meds else None,
+                "per_rank": rank_step,
+                "checkpoint_readers": [r["rank"] for r in rank_step if r["read_checkpoint"]],
+                "devices": [{k: i[k] for k in ("rank", "local_rank", "device", "uuid")} for i in idents],
+                "cross_rank_check": cross,
+                "note": ("bcast_ms: one broadcast of the packed weight arena (max over ranks, host clock, synchronised); "
+                         "gather_ms_exposed: time the launch stream waited per step for the previous step's packed all-gather "
+                         "(HIP events around the join; 0 = hidden under the next ViT); rank_step_ms: per-rank median step on the "
+                         "launch stream")}
         if build_info:
             line["build"] = build_info
         if cpu_dry:

@@ -27,7 +27,11 @@
 extern "C" {
 #endif
 
-#define THMR_ABI_VERSION 1
+/* 2 (round 3): thmr_smpl_desc.reserved became update_hips (a round-1 host that left it uninitialised would get the hip shift at
+ * random); the resample tables / padding row / flag words of the weight arena are written by thmr_load_weights on the LOADING
+ * engine (round 1: thmr_create on every engine; round 2: thmr_finalize_weights(0)) and validated — not written — by
+ * thmr_finalize_weights(assume_all_loaded = 1). */
+#define THMR_ABI_VERSION 2
 
 typedef enum {
     THMR_OK = 0,
@@ -74,7 +78,8 @@ typedef struct {
     const int32_t* extra_verts;     /* (21) smplx vertex_ids['smplh'] */
     const int32_t* joint_map;       /* (25) smpl_wrapper.py:19-20 */
     int32_t        on_device;
-    int32_t        update_hips;     /* SMPL(update_hips=...) smpl_wrapper.py:11,33-36: 1 = shift the two hip joints (mapped joints 9, 12) */
+    int32_t        update_hips;     /* SMPL(update_hips=...) smpl_wrapper.py:11,33-36: 1 = shift the two hip joints (mapped joints 9, 12);
+                                     * MUST be 0 or 1 (it was `reserved` in ABI 1: initialise it) */
 } thmr_smpl_desc;
 
 /* Output buffers of one forward (tokenhmr.py:156-188).  Any pointer may be NULL (= not wanted). */
@@ -131,7 +136,11 @@ const char* thmr_last_error(const thmr_engine* e);   /* e may be NULL: last glob
 int thmr_load_weights(thmr_engine* e, const thmr_tensor_desc* tensors, size_t n, void* stream);
 int thmr_load_smpl(thmr_engine* e, const thmr_smpl_desc* smpl, void* stream);
 /* Checks every required tensor arrived and builds derived layouts (conv/codebook repacks,
- * J_template/J_shapedirs).  Also the hook to call after an external broadcast into the arena. */
+ * J_template/J_shapedirs).  Also the hook to call after an external broadcast into the arena:
+ * assume_all_loaded = 1 skips the per-tensor bookkeeping (this engine loaded nothing itself) and instead requires the loader's
+ * magic word in the arena — THMR_ERR_STATE if the arena was never filled by a thmr_load_weights (e.g. broadcast too early).
+ * The arena is complete for a broadcast as soon as the root's thmr_load_weights + thmr_load_smpl have returned; the root
+ * may finalize before or after broadcasting. */
 int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* stream);
 int thmr_weight_arena(thmr_engine* e, void** ptr_dev, size_t* bytes);
 
@@ -141,7 +150,9 @@ int thmr_forward(thmr_engine* e, const float* img_dev, int32_t B, const thmr_out
 
 /* Device-side health of the engine: synchronises `stream` and returns THMR_ERR_HIP if a kernel of this engine reported an
  * error asynchronously (today: the bounded grid barrier of the persistent decoder kernel timed out instead of hanging the GPU).
- * thmr_forward itself never synchronises, so callers check this at their own sync points (tests and bench.py do). */
+ * thmr_forward itself never synchronises; it does look at a host-mapped copy of the same error word on entry, so a timeout is
+ * also reported by the NEXT forward-type call.  Either way the error is returned once: the engine drains the device, resets
+ * its barrier words and switches its head to the launch chain (no co-residency needed), so re-submitting the batch works. */
 int thmr_engine_status(thmr_engine* e, void* stream);
 
 /* Diagnostics: with THMR_DEC_TIMELINE=1 in the environment at thmr_finalize_weights, workgroup 0 of the persistent decoder kernel

@@ -36,6 +36,39 @@ def test_gpus2_self_launches_two_gloo_ranks():
     assert j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak" and j["metric"] == "crops_per_sec"
     assert j["value"] > 0 and abs(j["value"] - 8 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-3
     assert "dry_run" in j
+    _check_multi_gpu_block(j, 2, [4, 4])
+
+
+def _check_multi_gpu_block(j, world, sizes):
+    m = j["multi_gpu"]
+    assert m["checkpoint_readers"] == [0], m["checkpoint_readers"]            # only rank 0 touches the "checkpoint"
+    assert [d["rank"] for d in m["devices"]] == list(range(world)) and [d["local_rank"] for d in m["devices"]] == list(range(world))
+    assert [r["crops"] for r in m["per_rank"]] == sizes and [r["rank"] for r in m["per_rank"]] == list(range(world))
+    assert m["bcast_ms"] is not None and m["bcast_ms"] >= 0 and m["bcast_bytes"] == 4096
+    assert m["gather_ms_exposed"] >= 0 and m["gather_bytes_per_step"] == sum(sizes) * 21282 * 4
+    assert m["cross_rank_check"]["ranks_checked"] == world - 1 and m["cross_rank_check"]["bit_identical"] is True
+    assert j["gathered_records_ok"] is True
+
+
+def test_gpus8_dry_run_global_batch_512_and_ragged_509():
+    """The driver's first 8-GPU run must not be a debugging session: the whole 8-rank orchestration (rank 0 loads, ONE broadcast,
+    per-step async packed all-gather joined one step later, per-rank diagnostics, cross-rank check, one JSON line) runs here on
+    gloo / CPU tensors, weak-scaled at 64 crops per rank (global 512, BASELINE configs[3]) and with ONE ragged global batch of
+    509 crops dealt 64,64,64,64,64,63,63,63."""
+    j = _line(_run(["--gpus", "8", "--backend", "gloo", "--fake-engine", "--steps", "3", "--warmup", "1"], timeout=900))
+    assert j["n_gpus"] == 8 and j["config"]["ranks"] == 8 and j["config"]["global_batch"] == 512 and j["config"]["batch_per_gpu"] == 64
+    assert j["scaling"] == "weak" and j["config"]["parallelism"] == "dp8"
+    assert abs(j["value"] - 512 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-3
+    _check_multi_gpu_block(j, 8, [64] * 8)
+    j = _line(_run(["--gpus", "8", "--backend", "gloo", "--fake-engine", "--steps", "2", "--warmup", "1", "--global-batch", "509"], timeout=900))
+    assert j["config"]["global_batch"] == 509 and j["config"]["batch_per_gpu"] == [64, 64, 64, 64, 64, 63, 63, 63] and j["scaling"] == "strong"
+    assert abs(j["value"] - 509 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-3
+    _check_multi_gpu_block(j, 8, [64, 64, 64, 64, 64, 63, 63, 63])
+
+
+def test_global_batch_smaller_than_world_is_refused():
+    r = _run(["--gpus", "2", "--backend", "gloo", "--fake-engine", "--global-batch", "1"])
+    assert r.returncode != 0 and "leaves a rank without crops" in r.stderr
 
 
 def test_gpus_flag_must_agree_with_the_launcher():
@@ -63,6 +96,9 @@ def test_self_launch_on_rccl_world1(built_lib, cuda_dev):
     assert j["n_gpus"] == 1 and j["config"]["ranks"] == 1 and j["config"]["backend"] == "nccl"
     assert j["config"]["allgather_outputs"] is True and j["gathered_records_ok"] is True
     assert j["roofline"]["frac"] > 0 and "src:" in j["build"]
+    m = j["multi_gpu"]
+    assert m["checkpoint_readers"] == [0] and m["bcast_ms"] > 0 and m["bcast_bytes"] > 1e8 and m["devices"][0]["device"] == 0
+    assert m["gather_ms_exposed"] >= 0 and m["rank_step_ms"]["min"] > 0
 
 
 @pytest.mark.gpu

@@ -74,3 +74,46 @@ def test_cabi_collectives_on_a_raw_rccl_communicator(built_lib, cuda_dev):
         assert lib.thmr_allgather_records(None, C.c_void_p(rec.data_ptr()), 4, C.c_void_p(recv.data_ptr()), st) < 0   # null communicator
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+def test_receiver_of_a_broadcast_made_before_the_root_finalized(built_lib, cuda_dev):
+    """The round-2 regression: bench.py and the INTEGRATION.md recipe broadcast the arena BEFORE rank 0
+    finalizes, and the resample tables / padding row / flag words were written by finalize(assume_all_loaded=0) only — ranks
+    != 0 ran on uninitialised tables.  One GPU per box, so the receiver is a second engine whose arena starts as garbage and is
+    filled by exactly the bytes a broadcast would deliver at that moment (a device copy of the root's arena after load, before
+    its finalize).  Its outputs must equal the root's bit for bit and the CPU oracle's within the usual tolerance."""
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd import weights as W, _cabi
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    from tokenhmr_amd.engine import Engine
+    from oracle import tokenhmr_oracle as O
+    cfg = HMRConfig(vit_depth=1, dec_depth=2)
+    sd, tok, smpl = W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0), make_synthetic_smpl(cfg, 0)
+    tok_full = dict(tok)
+    tok_full.update(W.make_synthetic_encoder(cfg, 0))
+    root = Engine(cfg, max_batch=3, device=cuda_dev)
+    recv = Engine(cfg, max_batch=3, device=cuda_dev)
+    recv.weight_arena.view(torch.int32).fill_(0x7FC0DEAD)          # NaN patterns / wild indices wherever nothing arrives
+    torch.cuda.synchronize()
+    # a receiver whose arena never got a loaded model must refuse to finalize (magic word), not run on garbage
+    with pytest.raises(_cabi.EngineError, match="does not carry a loaded model"):
+        recv.finalize(assume_all_loaded=True)
+    root.load_state(sd, tok_full)
+    root.load_smpl(smpl)
+    torch.cuda.synchronize()
+    recv.weight_arena.copy_(root.weight_arena)                       # "the broadcast", before the root finalizes
+    torch.cuda.synchronize()
+    root.finalize()
+    recv.finalize(assume_all_loaded=True)
+    img = torch.randn(3, 3, 256, 256, generator=torch.Generator().manual_seed(11))
+    a, b = root.forward(img.to(cuda_dev), taps=True), recv.forward(img.to(cuda_dev), taps=True)
+    torch.cuda.synchronize()
+    root.status(), recv.status()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    ref = O.forward(img, sd, tok, smpl, cfg)
+    assert (b["pred_vertices"].cpu() - ref["pred_vertices"]).abs().max() < 1e-4
+    assert (b["pred_keypoints_2d"].cpu() - ref["pred_keypoints_2d"]).abs().max() < 1e-3
+    # the "encoder present" flag travelled with the arena as well
+    pose = torch.randn(2, 21, 6, generator=torch.Generator().manual_seed(12)).to(cuda_dev)
+    assert torch.equal(root.encode_tokens(pose), recv.encode_tokens(pose))

@@ -59,7 +59,7 @@ def test_one_hip_runtime_per_process_whatever_the_import_order(built_lib):
 @pytest.mark.parametrize("vd,dd", [(2, 2), (32, 6)])
 def test_checkpoint_contract_cpp_equals_python(built_lib, vd, dd):
     cfg = HMRConfig(vit_depth=vd, dec_depth=dd)
-    cc = _cabi.Config(abi_version=1, vit_depth=vd, dec_depth=dd, max_batch=2, device=0)
+    cc = _cabi.Config(abi_version=_cabi.ABI_VERSION, vit_depth=vd, dec_depth=dd, max_batch=2, device=0)
     n = built_lib.thmr_spec(C.byref(cc), -1, None, None)
     cpp = {}
     for i in range(n):
@@ -71,7 +71,7 @@ def test_checkpoint_contract_cpp_equals_python(built_lib, vd, dd):
 
 
 def test_arena_sizes(built_lib):
-    cc = _cabi.Config(abi_version=1, vit_depth=32, dec_depth=6, max_batch=64, device=0)
+    cc = _cabi.Config(abi_version=_cabi.ABI_VERSION, vit_depth=32, dec_depth=6, max_batch=64, device=0)
     wb, sb = C.c_size_t(0), C.c_size_t(0)
     assert built_lib.thmr_arena_bytes(C.byref(cc), C.byref(wb), C.byref(sb)) == 0
     n_params = sum(math.prod(s) for _, s, *_ in W.spec(RELEASE) + W.tokenizer_spec(RELEASE))
@@ -83,7 +83,7 @@ def test_arena_sizes(built_lib):
 def test_bad_config_is_rejected(built_lib):
     wb = C.c_size_t(0)
     for kw in (dict(abi_version=99), dict(vit_depth=0), dict(dec_depth=7), dict(max_batch=0)):
-        base = dict(abi_version=1, vit_depth=2, dec_depth=2, max_batch=2, device=0)
+        base = dict(abi_version=_cabi.ABI_VERSION, vit_depth=2, dec_depth=2, max_batch=2, device=0)
         base.update(kw)
         cc = _cabi.Config(**base)
         assert built_lib.thmr_arena_bytes(C.byref(cc), C.byref(wb), None) == -1
@@ -93,7 +93,7 @@ def test_bad_config_is_rejected(built_lib):
 def test_create_without_gpu_fails_loudly(built_lib):
     if torch.cuda.is_available():
         pytest.skip("GPU present")
-    cc = _cabi.Config(abi_version=1, vit_depth=1, dec_depth=1, max_batch=1, device=0)
+    cc = _cabi.Config(abi_version=_cabi.ABI_VERSION, vit_depth=1, dec_depth=1, max_batch=1, device=0)
     h = C.c_void_p(0)
     rc = built_lib.thmr_create(C.byref(cc), None, None, C.byref(h))
     assert rc != 0 and not h.value

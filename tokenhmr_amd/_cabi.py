@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtokenhmr_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "tokenhmr_hip.h")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 PROF_NAMES = ["gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "attention", "layernorm", "patch_embed",
               "dec_kv", "head", "lbs"]
 

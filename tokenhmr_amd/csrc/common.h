@@ -216,6 +216,7 @@ struct DecParams {
     const float *ro_w, *ro_b, *mt_w, *mt_b;           // read-outs (31 rows + zero row), mixer_trans.ff.0 (10240 rows)
     float *dx, *dv, *dq, *dca, *dff, *ro, *mt;        // scratch: (B,1024) (B,512) (B,512) (B,512) (B,1024) (B,32) (B,10240)
     unsigned* sync;
+    unsigned* host_err;                               // host-mapped sticky error word (null = none), see GridSync
     int64_t ldkv;
     int depth, B;
     int timeline;                                     // 1: workgroup 0 stamps the wall clock into sync[16..] (diagnostics)
@@ -230,6 +231,7 @@ struct DecParams {
 };
 
 int launch_decoder_fused(const DecParams& p, hipStream_t s);
+int decoder_max_coresident_blocks(int device);      // > 0, or negative if the kernel cannot be resident at all
 
 // ---- the MLP-Mixer stack kernel (mixer_fused.hip; parameter structs above DecParams) ----
 int launch_mixer_fused(const MixerParams& p, int B, hipStream_t s);

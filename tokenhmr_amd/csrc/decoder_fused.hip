@@ -48,6 +48,7 @@ struct GridSync {
     unsigned* w;
     unsigned base;      // sync[1] at kernel start
     unsigned n;         // barriers passed so far
+    unsigned* host_err; // host-mapped copy of the sticky error word (may be null): the host sees a timeout without a D2H copy
 };
 
 // `pf` runs after this wave's stores have drained and before it waits: the place to request what the NEXT stage needs and does not
@@ -76,7 +77,10 @@ __device__ __forceinline__ bool grid_barrier(GridSync& gs, int tid, volatile int
         }
         __syncthreads();
         if (tid == 0) {
-            if (*s_ok == 0) __hip_atomic_store(&gs.w[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (*s_ok == 0) {
+                __hip_atomic_store(&gs.w[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (gs.host_err) __hip_atomic_store(gs.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             __hip_atomic_store(&gs.w[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // also on failure: let the others leave
         }
     } else if (tid == 0) {
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(NWAVE * 64) void decoder_persistent_kernel(DecParam
     const int tid = threadIdx.x;
     if (tid == 0) s_base = __hip_atomic_load(&p.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    GridSync gs{p.sync, s_base, 0};
+    GridSync gs{p.sync, s_base, 0, p.host_err};
     bool ok = true;
     const int B = p.B;
     // optional stage timeline (THMR_DEC_TIMELINE=1): workgroup 0 stamps the 100 MHz wall clock after every step and barrier
@@ -576,6 +580,25 @@ int launch_decoder_fused(const DecParams& p, hipStream_t s) {
     if (p.max_blocks > 0 && grid > p.max_blocks) grid = p.max_blocks;
     if (grid > 256) grid = 256;                  // workgroup 0 polls one arrival flag per thread pair at most; flags[256]
     if (grid < p.mixer_cluster * p.B) return -1;                        // the caller picks a split that fits (engine.hip head_forward)
+    // THMR_DEC_COOP=1 (A/B knob): cooperative launch — the runtime then refuses a grid that cannot be co-resident instead of
+    // letting the bounded barrier find out.  The default is a plain launch of a grid sized from the occupancy query
+    // (decoder_max_coresident_blocks, engine.hip finalize), which is the same guarantee for everything this process controls.
+    static const bool coop = [] { const char* e = getenv("THMR_DEC_COOP"); return e && e[0] == '1'; }();
+    if (coop) {
+        DecParams pc = p;
+        void* args[] = {&pc};
+        return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&decoder_persistent_kernel), dim3(grid), dim3(NWAVE * 64), args, 0, s) == hipSuccess ? 0 : -2;
+    }
     hipLaunchKernelGGL(decoder_persistent_kernel, dim3(grid), dim3(NWAVE * 64), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Workgroups of the persistent decoder kernel that can be resident on the device at once (occupancy query x CUs): the grid
+// barrier needs every workgroup of a launch resident, so launch_decoder_fused never launches more than this (DecParams::max_blocks).
+int decoder_max_coresident_blocks(int device) {
+    int cus = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) return -2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decoder_persistent_kernel, NWAVE * 64, 0) != hipSuccess || per_cu < 1) return -2;
+    // one workgroup per CU is what the step scheduling assumes (bytes per CU bound the steps); more would only share a CU
+    return cus;
 }

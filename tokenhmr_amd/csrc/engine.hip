@@ -82,6 +82,7 @@ struct thmr_engine {
     bool mixer_cluster = true;        // THMR_MIXER_CLUSTER=0: always run the mixer stack as its own one-workgroup-per-crop kernel (A/B only)
     bool tiny_gemm = true;            // THMR_TINY_GEMM=0: the VQ decoder's GEMMs stay on the ring kernel in the small-batch regime (A/B only)
     bool smpl_loaded = false, finalized = false;
+    unsigned* host_err = nullptr;     // host-mapped sticky error word of the persistent decoder kernel (hipHostMalloc)
     std::string err;
     // derived / constant regions (float offsets in weight arena)
     size_t o_kv_all = 0, o_ro_w = 0, o_ro_b = 0;
@@ -95,7 +96,7 @@ struct thmr_engine {
     std::vector<size_t> enc_convp;   // repacked encoder convs, index by kEnc id
     size_t o_idx_enc = 0, o_flags = 0;
     bool enc_ready = false;
-    int32_t flag_host = 0, hips_host = 0;
+    int32_t flag_host[2] = {0, 0}, hips_host = 0;
     std::vector<int32_t> idx_host, eidx_host, inv_host;   // staging for the index tables (must outlive the async copy)
     int vq_len[5] = {160, 125, 90, 55, 21};
     // scratch offsets (floats)
@@ -718,7 +719,29 @@ void build_idx_tables(thmr_engine* e) {
         o += 2 * tin;
     }
 }
-constexpr int32_t kEncMagic = 0x454e4331;   // 'ENC1': arena flag word 0 = "tokenizer encoder tensors present + repacked"
+constexpr int32_t kEncMagic = 0x454e4331;   // 'ENC1': arena flag word 0 = "tokenizer encoder tensors present"
+constexpr int32_t kArenaMagic = 0x54484d32; // 'THM2': arena flag word 1 = "the non-checkpoint regions below were written by a loading engine"
+
+// Everything in the weight arena that is neither a checkpoint tensor nor derived from one: the resample index tables, the zero
+// padding row of the read-out matrix and the flag words.  Written by the engine that LOADS tensors, at load time — so the arena
+// is complete for a broadcast the moment loading ends, whether or not the root has finalized yet (round 2 wrote them in
+// thmr_finalize_weights(assume_all_loaded = 0) only: a root that broadcast BEFORE finalizing shipped uninitialised tables, and
+// receivers, which finalize with assume_all_loaded = 1, never wrote them).  Receivers validate kArenaMagic instead of writing:
+// their arena may be another engine's live one (Engine(weight_arena=...)).
+int write_arena_constants(thmr_engine* e, hipStream_t st) {
+    build_idx_tables(e);
+    HIP_OK(hipMemcpyAsync(e->warena + e->o_idx, e->idx_host.data(), e->idx_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(e->warena + e->o_inv, e->inv_host.data(), e->inv_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(e->warena + e->o_idx_enc, e->eidx_host.data(), e->eidx_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(e->warena + e->o_ro_w + (size_t)31 * E, 0, E * sizeof(float), st));
+    // optional encoder: present only when every 'encoder.encoder.*' tensor arrived (all-or-nothing, checked by finalize)
+    size_t enc_loaded = 0;
+    for (auto& n : e->enc_names) enc_loaded += e->slots[n].loaded ? 1 : 0;
+    e->flag_host[0] = enc_loaded == e->enc_names.size() ? kEncMagic : 0;
+    e->flag_host[1] = kArenaMagic;
+    HIP_OK(hipMemcpyAsync(e->warena + e->o_flags, e->flag_host, 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    return 0;
+}
 
 // The persistent decoder kernel needs ALL its workgroups resident at once (grid barrier) and, from 49 crops on, asks for every
 // CU.  Two of them launched concurrently by two engines on two streams could each grab part of the chip and wait for the rest
@@ -754,8 +777,24 @@ int launch_decoder_serialised(thmr_engine* e, const DecParams& d, hipStream_t st
     return r;
 }
 
+// The persistent decoder kernel's bounded grid barrier timed out in an earlier call (its workgroups were not resident together:
+// another process on the GPU, a partition with fewer CUs than reported ...).  That call's outputs are garbage and its barrier
+// words are in an undefined state.  Recover instead of staying poisoned: drain the device, zero the barrier words and the
+// sticky error, and run this engine's head as the launch chain from now on (it needs no co-residency), so the caller can
+// simply re-submit.  Returns the error ONCE.
+int recover_decoder_timeout(thmr_engine* e) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(e->sarena + e->so.sync, 0, 512 * sizeof(float));
+    if (e->host_err) *e->host_err = 0;
+    e->legacy_head = true;
+    return fail(e, THMR_ERR_HIP, "persistent decoder kernel: grid barrier timed out in a previous forward (its workgroups could not be "
+                                 "resident together); that call's outputs are invalid.  The engine has reset its barrier and switched to "
+                                 "the launch-chain head: re-submit the batch");
+}
+
 int check_ready(thmr_engine* e, int B) {
     if (!e) return fail(nullptr, THMR_ERR_INVALID, "null engine");
+    if (e->host_err && *static_cast<volatile unsigned*>(e->host_err) != 0) return recover_decoder_timeout(e);
     if (!e->finalized) return fail(e, THMR_ERR_STATE, "weights not finalized: call thmr_finalize_weights first");
     if (B < 1 || B > e->max_batch) return fail(e, THMR_ERR_INVALID, "batch " + std::to_string(B) + " outside [1, max_batch=" + std::to_string(e->max_batch) + "]");
     return 0;
@@ -832,6 +871,9 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     if (hipMemset(e->sarena + e->so.sync, 0, 512 * sizeof(float)) != hipSuccess) return bail(THMR_ERR_HIP, "hipMemset(sync words) failed");
     // arrival counters of the fused skin + joints kernel (self-resetting; zero before the first call)
     if (hipMemset(e->sarena + e->so.lcnt, 0, (size_t)e->max_batch * sizeof(float)) != hipSuccess) return bail(THMR_ERR_HIP, "hipMemset(lbs counters) failed");
+    // sticky error word of the persistent decoder kernel, host-mapped so that the next call sees a timeout without a D2H copy
+    if (hipHostMalloc(reinterpret_cast<void**>(&e->host_err), 64, hipHostMallocMapped) != hipSuccess) return bail(THMR_ERR_NOMEM, "hipHostMalloc(error word) failed");
+    *e->host_err = 0;
     { const char* lg = getenv("THMR_LEGACY_HEAD"); e->legacy_head = lg && lg[0] == '1'; }
     { const char* mc = getenv("THMR_MIXER_CLUSTER"); e->mixer_cluster = !(mc && mc[0] == '0'); }
     { const char* tg = getenv("THMR_TINY_GEMM"); e->tiny_gemm = !(tg && tg[0] == '0'); }
@@ -844,6 +886,7 @@ void thmr_destroy(thmr_engine* e) {
     if (!e) return;
     if (e->counted) { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[e->cfg.device] -= 1; }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->host_err) (void)hipHostFree(e->host_err);
     if (e->own_w && e->warena) (void)hipFree(e->warena);
     if (e->own_s && e->sarena) (void)hipFree(e->sarena);
     delete e;
@@ -864,7 +907,7 @@ int thmr_load_weights(thmr_engine* e, const thmr_tensor_desc* t, size_t n, void*
         it->second.loaded = true;
     }
     e->finalized = false;
-    return 0;
+    return write_arena_constants(e, st);
 }
 
 int thmr_load_smpl(thmr_engine* e, const thmr_smpl_desc* s, void* stream) {
@@ -899,13 +942,25 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
             if (!e->slots[n].loaded) return fail(e, THMR_ERR_STATE, "missing tensor '" + n + "' (strict load)");
         if (!e->smpl_loaded) return fail(e, THMR_ERR_STATE, "SMPL constants not loaded (thmr_load_smpl)");
     }
+    int32_t* flags = reinterpret_cast<int32_t*>(e->warena + e->o_flags);
     if (!assume_all_loaded) {
-        // regions of the arena that are not checkpoint tensors: index tables, the (finite) padding row of the read-out matrix
-        build_idx_tables(e);
-        HIP_OK(hipMemcpyAsync(e->warena + e->o_idx, e->idx_host.data(), e->idx_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemcpyAsync(e->warena + e->o_inv, e->inv_host.data(), e->inv_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemcpyAsync(e->warena + e->o_idx_enc, e->eidx_host.data(), e->eidx_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemsetAsync(e->warena + e->o_ro_w + (size_t)31 * E, 0, E * sizeof(float), st));
+        if (int r = write_arena_constants(e, st)) return r;      // idempotent (load time wrote them already)
+        size_t enc_loaded = 0;
+        for (auto& n : e->enc_names) enc_loaded += e->slots[n].loaded ? 1 : 0;
+        if (enc_loaded != 0 && enc_loaded != e->enc_names.size())
+            return fail(e, THMR_ERR_STATE, "tokenizer encoder partially loaded: " + std::to_string(enc_loaded) + " of " +
+                                               std::to_string(e->enc_names.size()) + " tensors");
+        e->enc_ready = enc_loaded == e->enc_names.size();
+    } else {
+        // the arena was filled by someone else (a broadcast from the loading rank, or it is another engine's live arena): it must
+        // carry the loader's magic word, otherwise the index tables / padding row / flags are uninitialised memory
+        int32_t f[2] = {0, 0};
+        HIP_OK(hipMemcpyAsync(f, flags, sizeof(f), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        if (f[1] != kArenaMagic)
+            return fail(e, THMR_ERR_STATE, "thmr_finalize_weights(assume_all_loaded=1): the weight arena does not carry a loaded model "
+                                           "(no loader magic word): was it broadcast before the root called thmr_load_weights, or never received?");
+        e->enc_ready = f[0] == kEncMagic;
     }
     for (int i = 0; i < 9; ++i)
         LAUNCH_OK(launch_conv_repack(e->W(std::string(kConv3[i]) + ".weight"), e->warena + e->convp[i], kConv3Co[i], kConv3Ci[i], 3, st));
@@ -914,24 +969,6 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
     LAUNCH_OK(launch_lbs_jreg(e->warena + e->o_smpl_jr, e->warena + e->o_smpl_vt, e->warena + e->o_smpl_sd,
                               e->warena + e->o_smpl_jt, e->warena + e->o_smpl_jsd, st));
     LAUNCH_OK(launch_lbs_build_dirs(e->warena + e->o_smpl_sd, e->warena + e->o_smpl_pd, e->warena + e->o_smpl_dirs, st));
-    // optional encoder: ready only when every 'encoder.encoder.*' tensor arrived (all-or-nothing).  The fact travels with
-    // the arena as a flag word, so an engine that received the arena by broadcast (or shares it) can encode too.
-    int32_t* flags = reinterpret_cast<int32_t*>(e->warena + e->o_flags);
-    if (!assume_all_loaded) {
-        size_t enc_loaded = 0;
-        for (auto& n : e->enc_names) enc_loaded += e->slots[n].loaded ? 1 : 0;
-        if (enc_loaded != 0 && enc_loaded != e->enc_names.size())
-            return fail(e, THMR_ERR_STATE, "tokenizer encoder partially loaded: " + std::to_string(enc_loaded) + " of " +
-                                               std::to_string(e->enc_names.size()) + " tensors");
-        e->enc_ready = enc_loaded == e->enc_names.size();
-        e->flag_host = e->enc_ready ? kEncMagic : 0;
-        HIP_OK(hipMemcpyAsync(flags, &e->flag_host, sizeof(int32_t), hipMemcpyHostToDevice, st));
-    } else {
-        int32_t f = 0;
-        HIP_OK(hipMemcpyAsync(&f, flags, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
-        e->enc_ready = f == kEncMagic;
-    }
     if (e->enc_ready)
         for (int i = 0; i < kEncN; ++i)
             if (kEnc[i].ks > 1)
@@ -975,9 +1012,11 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
         d.depth = e->dec_depth; d.B = 0;
         { const char* tl = getenv("THMR_DEC_TIMELINE"); d.timeline = tl && tl[0] == '1'; }
         {
-            int cus = 0;
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device) != hipSuccess || cus < 1) cus = 64;
-            d.max_blocks = cus;
+            // never more workgroups than can be resident at once (occupancy query x CUs): the grid barrier depends on it
+            const int nb = decoder_max_coresident_blocks(e->cfg.device);
+            if (nb < 1) return fail(e, THMR_ERR_HIP, "persistent decoder kernel cannot be resident on this device (occupancy query failed)");
+            d.max_blocks = nb;
+            d.host_err = e->host_err;
         }
         MixerParams& m = e->mix;
         const std::string C = "smpl_head.decpose.";
@@ -1092,7 +1131,7 @@ int thmr_engine_status(thmr_engine* e, void* stream) {
     unsigned words[4] = {0, 0, 0, 0};
     HIP_OK(hipMemcpyAsync(words, e->sarena + e->so.sync, sizeof(words), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    if (words[3] != 0) return fail(e, THMR_ERR_HIP, "persistent decoder kernel: grid barrier timed out (were its 64 workgroups prevented from being resident together?)");
+    if (words[3] != 0 || (e->host_err && *static_cast<volatile unsigned*>(e->host_err) != 0)) return recover_decoder_timeout(e);
     return 0;
 }
 

@@ -52,12 +52,15 @@ __global__ __launch_bounds__(256) void lbs_jreg_kernel(const float* __restrict__
 __global__ __launch_bounds__(128) void lbs_prep_kernel(const float* __restrict__ rotmat, const float* __restrict__ betas,
                                                        const float* __restrict__ Jt, const float* __restrict__ Jsd,
                                                        const int32_t* __restrict__ parents, float* __restrict__ A,
-                                                       float* __restrict__ xf, float* __restrict__ Jtr) {
+                                                       float* __restrict__ xf, float* __restrict__ Jtr, unsigned* __restrict__ cnt) {
     __shared__ float J[NJ][3];
     __shared__ float G[NJ][12];
     __shared__ float R[NJ][9];
     __shared__ float bs[NB];
     const int b = blockIdx.x, t = threadIdx.x;
+    // arrival counter of this crop's 27 skin workgroups (lbs_skin_joints_kernel): zeroed HERE, by the launch that always precedes
+    // them on the stream, so an aborted launch cannot leave a count behind for the next call (round 2: the last arriver re-zeroed it)
+    if (t == 0) cnt[b] = 0u;
     for (int i = t; i < NJ * 9; i += 128) R[i / 9][i % 9] = rotmat[(int64_t)b * NJ * 9 + i];
     if (t < NB) bs[t] = betas[(int64_t)b * NB + t];
     __syncthreads();
@@ -152,9 +155,9 @@ __global__ __launch_bounds__(256) void lbs_skin_joints_kernel(const float* __res
     for (int q = 0; q < NJ / 4; ++q) wv[q] = reinterpret_cast<const f32x4*>(W + (int64_t)vv * NJ)[q];
 #pragma unroll
     for (int j = 0; j < 19; ++j) J19s[j][tid] = vok ? J19[(int64_t)j * NV + v] : 0.f;
-    int slot = -1;                        // which of the 21 extra-joint vertices this thread's vertex is, if any
+    unsigned slots = 0;                   // which of the 21 extra-joint slots pick this thread's vertex (bit k; an id may repeat)
     for (int k = 0; k < 21; ++k)
-        if (vok && extra[k] == v) slot = k;
+        if (vok && extra[k] == v) slots |= 1u << k;
     // software pipeline over the crops of this pass: the posed vertex and the bone matrices of crop c + 1 are requested before
     // crop c is skinned (a pass is a serial chain per workgroup; without this every crop exposed one full memory round trip)
     const int b0 = blockIdx.y * CG;
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(256) void lbs_skin_joints_kernel(const float* __res
         outs[tid * 3 + 0] = vok ? ox : 0.f;
         outs[tid * 3 + 1] = vok ? oy : 0.f;
         outs[tid * 3 + 2] = vok ? oz : 0.f;
-        if (slot >= 0) {
-            float* xo = xv + ((int64_t)b * 21 + slot) * 3;
+        for (unsigned m = slots; m; m &= m - 1) {
+            float* xo = xv + ((int64_t)b * 21 + __builtin_ctz(m)) * 3;
             st_dev(xo + 0, ox); st_dev(xo + 1, oy); st_dev(xo + 2, oz);
         }
         __syncthreads();
@@ -241,7 +244,6 @@ __global__ __launch_bounds__(256) void lbs_skin_joints_kernel(const float* __res
                 kp2d[((int64_t)b * 44 + tid) * 2 + 0] = (px / pz) * focal_over_size;
                 kp2d[((int64_t)b * 44 + tid) * 2 + 1] = (py / pz) * focal_over_size;
             }
-            if (tid == 0) __hip_atomic_store(&cnt[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
         }
     }
 }
@@ -285,13 +287,13 @@ int launch_lbs_build_dirs(const float* sd, const float* pd, float* dirsT, hipStr
 }
 
 // scratch: A (B,24,12), xf (B, 224 + 27*57) [operand rows, then J19 partial sums], Jtr (B,24,3), vposed (B,20670),
-//          xv (B,21,3) picked extra-joint vertices, cnt (B) arrival counters (zero before the first call; the kernel re-zeroes them)
+//          xv (B,21,3) picked extra-joint vertices, cnt (B) arrival counters (zeroed by lbs_prep_kernel of the same call)
 int launch_lbs(const float* rotmat, const float* betas, const float* cam_t, const float* Jt, const float* Jsd,
                const int32_t* parents, const float* vt, const float* dirsT, const float* W, const float* J19,
                const int32_t* extra, const int32_t* jmap, const int32_t* update_hips, float* A, float* xf, float* Jtr,
                float* vposed, float* verts, float* joints, float* kp2d, float focal_over_size, int B, float* xv,
                unsigned* cnt, hipStream_t s) {
-    hipLaunchKernelGGL(lbs_prep_kernel, dim3(B), dim3(128), 0, s, rotmat, betas, Jt, Jsd, parents, A, xf, Jtr);
+    hipLaunchKernelGGL(lbs_prep_kernel, dim3(B), dim3(128), 0, s, rotmat, betas, Jt, Jsd, parents, A, xf, Jtr, cnt);
     GemmArgs g{};
     g.A = xf; g.lda = KX; g.W = dirsT; g.ldw = KX; g.bias = vt; g.resid = nullptr; g.ldr = 0;
     g.C = vposed; g.ldc = NV * 3; g.M = B; g.N = NV * 3; g.K = KX; g.qscale = 1.f; g.qcols = 0;

@@ -40,9 +40,26 @@ def pack_records(o):
         import ctypes as C
         from . import _cabi
         lib = _cabi.load()
-        ts = {name: o[name].contiguous() for name, _ in RECORD_FIELDS}
-        st = _cabi.Outputs(**{k: (ts[k].data_ptr() if k in ts else None) for k in _cabi.OUTPUT_FIELDS})
         dev = o["pred_cam"].device
+        ts = {}
+        for name, n in RECORD_FIELDS:
+            # thmr_pack_records reads raw 32-bit words: a forward_fn that hands back e.g. an int64 token_idx or a tensor on another
+            # device must not be packed as garbage
+            want = torch.int32 if name == "token_idx" else torch.float32
+            t = o[name]
+            if t.device != dev:
+                raise ValueError(f"pack_records: '{name}' lives on {t.device}, 'pred_cam' on {dev}")
+            if t.dtype != want:
+                if name == "token_idx" and t.dtype in (torch.int64, torch.int16, torch.uint8, torch.int8):
+                    t = t.to(torch.int32)
+                elif name != "token_idx" and t.is_floating_point():
+                    t = t.to(torch.float32)
+                else:
+                    raise TypeError(f"pack_records: '{name}' must be {want}, got {t.dtype}")
+            if t.numel() != B * n:
+                raise ValueError(f"pack_records: '{name}' has {t.numel()} elements, expected {B} x {n}")
+            ts[name] = t.contiguous()
+        st = _cabi.Outputs(**{k: (ts[k].data_ptr() if k in ts else None) for k in _cabi.OUTPUT_FIELDS})
         rec = torch.empty(B, RECORD_WORDS, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             rc = lib.thmr_pack_records(C.byref(st), B, C.c_void_p(rec.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
@@ -53,7 +70,9 @@ def pack_records(o):
     for name, n in RECORD_FIELDS:
         t = o[name]
         if name == "token_idx":
-            t = t.contiguous().view(torch.float32)
+            t = t.to(torch.int32).contiguous().view(torch.float32)
+        elif t.dtype != torch.float32:
+            t = t.to(torch.float32)
         parts.append(t.reshape(B, n))
     return torch.cat(parts, dim=1).contiguous()
 
@@ -119,11 +138,16 @@ class ShardedRunner:
     """Runs `forward_fn(img_shard) -> engine-output dict` on this rank's shard of a global batch and
     (optionally) all-gathers the packed records so every rank sees all crops."""
 
-    def __init__(self, forward_fn, gather: bool = True):
+    def __init__(self, forward_fn, gather: bool = True, device=None):
+        """device: where this rank's records live (the engine's device).  Default: the current CUDA device under the nccl
+        backend, else the device of the batch handed to __call__."""
         self.forward_fn = forward_fn
         self.gather = gather
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        if device is None and dist.is_initialized() and dist.get_backend() == "nccl":
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device) if device is not None else None
 
     def local_slice(self, total):
         return shard_range(total, self.world, self.rank)
@@ -136,7 +160,8 @@ class ShardedRunner:
         else:
             # fewer crops than ranks (e.g. 3 detections in a frame on 8 GPUs): this rank has nothing to run — the engine
             # rejects B < 1 — but it must still enter the collective, with a zero-row record block
-            rec = torch.zeros(0, RECORD_WORDS, dtype=torch.float32, device=img_global.device)
+            # (on the device the OTHER ranks' records live on — the batch itself may still be a host tensor that forward_fn uploads)
+            rec = torch.zeros(0, RECORD_WORDS, dtype=torch.float32, device=self.device if self.device is not None else img_global.device)
         if not self.gather:
             return unpack_records(rec)
         return unpack_records(all_gather_records(rec, total))

@@ -46,6 +46,17 @@ class TokenHMR:
         m.smpl = _SmplHandle(smpl["faces"])
         return m
 
+    @classmethod
+    def from_engine(cls, engine, faces=None, model_cfg=None):
+        """The facade around an engine that is already loaded and finalized (bench.py times it beside Engine.forward)."""
+        m = cls.__new__(cls)
+        m.hmr_cfg = engine.cfg
+        m.cfg = model_cfg if model_cfg is not None else types.SimpleNamespace(**engine.cfg.to_dict())
+        m.max_batch, m.device, m.engine = engine.max_batch, engine.device, engine
+        m.smpl = _SmplHandle(faces if faces is not None else torch.zeros(13776, 3, dtype=torch.int64))
+        m.training, m.return_taps = False, False
+        return m
+
     # ---- nn.Module-like surface used by eval.py:52-54 / demo.py:35-37 ------------------------
     def to(self, device):
         if torch.device(device).type == "cuda" and torch.device(device) != self.engine.device and torch.device(device).index is not None:
@@ -70,8 +81,9 @@ class TokenHMR:
         """tokenhmr.py:135-188: batch['img'] (B,3,256,256) fp32 -> output dict.  Batches larger
         than max_batch are processed in max_batch chunks."""
         img = batch["img"]
-        if not img.is_cuda:
-            raise RuntimeError("batch['img'] must be on the GPU (recursive_to(batch, device), eval.py:145)")
+        if img.device.type != self.engine.device.type:
+            raise RuntimeError(f"batch['img'] is on {img.device}, the engine on {self.engine.device}: move the batch first "
+                               "(recursive_to(batch, device), eval.py:145) — there is no CPU path")
         if img.dtype != torch.float32:
             img = img.float()
         B = img.shape[0]
@@ -132,13 +144,30 @@ def _read_yaml_cfg(path):
 
 
 def load_tokenhmr(checkpoint_path="", model_cfg="", dataset_dir="", is_train_state=False, is_demo=False,
-                  max_batch=64, device="cuda:0"):
-    """Drop-in for tokenhmr/lib/models/__init__.py:3-26 (eval branch of TokenHMR.__init__, tokenhmr.py:49-53,84-85).
+                  max_batch=64, device="cuda:0", strict=True):
+    """Drop-in for tokenhmr/lib/models/__init__.py:3-26: (model, cfg) from the reference's files.  See read_reference_files
+    for what is read and how; `device` is where the engine is built (the reference builds on the CPU and the caller moves the
+    module, eval.py:52-54 — an engine cannot be moved, so pass the target here; `.to()` of the same device is a no-op)."""
+    hcfg, state, tok, smpl, cfg = read_reference_files(checkpoint_path, model_cfg, dataset_dir, is_train_state, strict)
+    model = TokenHMR.from_state(hcfg, state, tok, smpl, max_batch=max_batch, device=device, model_cfg=cfg)
+    return model, cfg
+
+
+def read_reference_files(checkpoint_path="", model_cfg="", dataset_dir="", is_train_state=False, strict=True):
+    """The file-reading half of load_tokenhmr (no GPU needed): -> (HMRConfig, state, tokenizer, smpl, cfg).
+    Mirrors tokenhmr/lib/models/__init__.py:3-26 (eval branch of TokenHMR.__init__, tokenhmr.py:49-53,84-85).
 
     Reads the Lightning checkpoint ['state_dict'] (misc.py:242-256), the tokenizer checkpoint named
-    by MODEL.TOKENIZER_CHECKPOINT_PATH ['net'] (vanilla_pose_vqvae.py:265,299-301) and the SMPL
+    by MODEL.TOKENIZER_CHECKPOINT_PATH ['net'] + ['hparams'].ARCH (vanilla_pose_vqvae.py:265-278,299-301) and the SMPL
     pickles named by SMPL.MODEL_PATH / SMPL.JOINT_REGRESSOR_EXTRA, and returns (model, cfg).
+
+    Both checkpoints are un-pickled by `ckpt_io.load_checkpoint` (restricted find_class): the yacs CfgNode in tokenizer.pth
+    and the config nodes under a Lightning checkpoint's 'hyper_parameters' need neither yacs, omegaconf nor
+    pytorch_lightning to be importable.  `strict=False` mirrors what the reference effectively does with unexpected
+    'backbone.*' / 'smpl_head.*' keys (prepare_statedict, misc.py:228-238: log a warning and carry on); missing or
+    mis-shaped tensors are always an error here (the reference would run on a random initialisation).
     """
+    from . import ckpt_io
     if is_train_state:
         raise NotImplementedError("tokenhmr_amd implements the inference path only")
     cfg, _ = _read_yaml_cfg(model_cfg)
@@ -155,16 +184,28 @@ def load_tokenhmr(checkpoint_path="", model_cfg="", dataset_dir="", is_train_sta
     if not os.path.exists(checkpoint_path):
         raise FileNotFoundError(f"Missing full pretrained model from {checkpoint_path}")   # reference: exit(1), misc.py:252-254
     td = dict(cfg.MODEL.SMPL_HEAD.TRANSFORMER_DECODER.__dict__)
-    # torch>=2.6 defaults weights_only=True, but these checkpoints pickle config nodes
-    ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)["state_dict"]
-    state = {k: v for k, v in ckpt.items() if k.startswith(("backbone.", "smpl_head."))}
+    ckpt = ckpt_io.load_checkpoint(checkpoint_path)
+    if not isinstance(ckpt, dict) or "state_dict" not in ckpt:
+        raise KeyError(f"{checkpoint_path}: no 'state_dict' entry (misc.py:249 reads torch.load(...)['state_dict'])")
+    full = ckpt["state_dict"]
     # the backbone depth is a property of the checkpoint (32 for the released ViT-H, vit.py:17), not of model_config.yaml
-    blocks = {int(k.split(".")[2]) for k in state if k.startswith("backbone.blocks.")}
+    blocks = {int(k.split(".")[2]) for k in full if k.startswith("backbone.blocks.")}
     if not blocks or blocks != set(range(len(blocks))):
         raise KeyError(f"checkpoint has no contiguous 'backbone.blocks.N.*' tensors (found indices {sorted(blocks)[:8]})")
     hcfg = HMRConfig(vit_depth=len(blocks), dec_depth=int(td.get("depth", 6)))
-    tok = torch.load(cfg.MODEL.TOKENIZER_CHECKPOINT_PATH, map_location="cpu", weights_only=False)["net"]
-    tok = {k: v for k, v in tok.items() if k.startswith("decoder.decoder.") or k == "quantizer.codebook"}
+    known = {n for n, *_ in W.spec(hcfg)}
+    state = ckpt_io.select_state(full, ("backbone.", "smpl_head."), known, strict=strict, what=os.path.basename(checkpoint_path))
+    tck = ckpt_io.load_checkpoint(cfg.MODEL.TOKENIZER_CHECKPOINT_PATH)
+    if not isinstance(tck, dict) or "net" not in tck:
+        raise KeyError(f"{cfg.MODEL.TOKENIZER_CHECKPOINT_PATH}: no 'net' entry (vanilla_pose_vqvae.py:299-301)")
+    # DecodeTokens builds its decoder from ckpt['hparams'].ARCH (vanilla_pose_vqvae.py:266-278); the engine's VQ kernels are built
+    # for ONE architecture, so the file's must be that one
+    ckpt_io.check_tokenizer_arch(ckpt_io.tokenizer_arch(tck), hcfg)
+    net = tck["net"]
+    tok = {k: v for k, v in net.items() if k.startswith("decoder.decoder.") or k == "quantizer.codebook"}
+    enc_names = [n for n, *_ in W.tokenizer_encoder_spec(hcfg)]
+    if all(n in net for n in enc_names):        # the tokenizer's encoder half (EncodeTokens, :304-346) enables engine.encode_tokens()
+        tok.update({n: net[n] for n in enc_names})
     mean = __import__("numpy").load(cfg.SMPL.MEAN_PARAMS)
     state.setdefault("smpl_head.init_body_pose", torch.from_numpy(mean["pose"].astype("float32")).unsqueeze(0))
     state.setdefault("smpl_head.init_betas", torch.from_numpy(mean["shape"].astype("float32")).unsqueeze(0))
@@ -173,5 +214,5 @@ def load_tokenhmr(checkpoint_path="", model_cfg="", dataset_dir="", is_train_sta
     smpl = load_smpl_pkl(os.path.join(cfg.SMPL.MODEL_PATH, f"SMPL_{gender}.pkl"), cfg.SMPL.JOINT_REGRESSOR_EXTRA, hcfg)
     # tokenhmr.py:84-85 passes every cfg.SMPL key (lower-cased) to SMPL(...): update_hips is one of its keyword arguments
     smpl["update_hips"] = bool(getattr(cfg.SMPL, "UPDATE_HIPS", getattr(cfg.SMPL, "update_hips", False)))
-    model = TokenHMR.from_state(hcfg, state, tok, smpl, max_batch=max_batch, device=device, model_cfg=cfg)
-    return model, cfg
+    W.validate_state(state, hcfg, tok)
+    return hcfg, state, tok, smpl, cfg
