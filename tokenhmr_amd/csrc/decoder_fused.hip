@@ -599,6 +599,8 @@ int decoder_max_coresident_blocks(int device) {
     int cus = 0, per_cu = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) return -2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decoder_persistent_kernel, NWAVE * 64, 0) != hipSuccess || per_cu < 1) return -2;
-    // one workgroup per CU is what the step scheduling assumes (bytes per CU bound the steps); more would only share a CU
+    // Only "at least one per CU" is taken from the query: the API over-reports by one block per CU in some SGPR ranges on this
+    // ROCm (MI355X_MICROARCH.md, correctness boundaries), and one workgroup per CU is what the step scheduling assumes anyway
+    // (bytes per CU bound the steps; a second workgroup would only share the CU).
     return cus;
 }

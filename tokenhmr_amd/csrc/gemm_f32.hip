@@ -32,6 +32,8 @@
 //     row panels / W column panels) are given to the same XCD's L2.
 //   * fused epilogues: bias, exact-erf GELU, ReLU, residual add, q-scale, pos-embed add.  The epilogue
 //     loads a whole 16-row fragment of residual/pos values BEFORE combining (no load->wait->store chains).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -846,7 +848,8 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         // NOT beyond 256 tiles: with two blocks per CU the 2-buffer kernel is the faster one (fc2 at 8 crops, 480 tiles: 176 us
         // against 229 us on the ring kernel — a threshold of 512 was tried in round 2 and cost B = 8 11 %, profiles/r2ad_batch_sweep.jsonl)
         const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-        if (variant == 9 && tiles64 <= 256 && epi != EPI_BIAS_POS) return launch_ring<4>(a, epi, 1, nullptr, s);
+        static const long ring_max_tiles = [] { const char* e = getenv("THMR_RING_MAX_TILES"); return e ? atol(e) : 256L; }();   // A/B knob
+        if (variant == 9 && tiles64 <= ring_max_tiles && epi != EPI_BIAS_POS) return launch_ring<4>(a, epi, 1, nullptr, s);
     }
 #ifdef THMR_GEMM_ABLATION
     switch (variant) {     // 30 + ABL: timing-only ablations of the 128x160 DMA kernel (EPI_NONE)
