@@ -109,7 +109,7 @@ struct thmr_engine {
         size_t total;
     } so{};
     // profiler
-    int prof_on = 0;            // 0 off, 1 every kernel class, 2 only the four ViT GEMM classes
+    int prof_on = 0;            // 0 off, 1 every kernel class, 2 only the four ViT GEMM classes, 3 only fc1 (the dominant kernel)
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_next = 0;
@@ -354,7 +354,7 @@ struct ProfScope {
     hipStream_t s;
     bool on;
     size_t rec = 0;
-    ProfScope(thmr_engine* e_, hipStream_t s_, int cls, double flops, double bytes) : e(e_), s(s_), on(e_->prof_on == 1 || (e_->prof_on == 2 && cls <= THMR_PROF_GEMM_FC2)) {
+    ProfScope(thmr_engine* e_, hipStream_t s_, int cls, double flops, double bytes) : e(e_), s(s_), on(e_->prof_on == 1 || (e_->prof_on == 2 && cls <= THMR_PROF_GEMM_FC2) || (e_->prof_on == 3 && cls == THMR_PROF_GEMM_FC1)) {
         if (!on) return;
         if (e->ev_next + 2 > e->ev_pool.size()) {
             for (int i = 0; i < 512; ++i) {
@@ -1380,7 +1380,7 @@ int thmr_regress_joints(const float* J, const float* verts, int32_t nj, int32_t 
 // ---- profiler ----
 int thmr_prof_enable(thmr_engine* e, int32_t on) {
     if (!e) return fail(e, THMR_ERR_INVALID, "null engine");
-    e->prof_on = on < 0 ? 0 : (on > 2 ? 1 : on);
+    e->prof_on = on < 0 ? 0 : (on > 3 ? 1 : on);
     return 0;
 }
 

@@ -14,8 +14,8 @@
 //     posedirs.  It runs on the MFMA GEMM (gemm_f32.hip) with the template as the bias epilogue, so the 18.5 MB dirs
 //     stream is read once per 64-row tile of crops at matrix-core speed (the first version did these 6890*621 FMAs per
 //     crop on the VALU out of LDS and took 107 us at B = 64).
-//   * skin + joints kernel: one thread per vertex, 8 crops per workgroup pass: 24 weights x 24 bone matrices (LDS broadcast) ->
-//     3x4 transform; the crop's last workgroup finishes its 44 joints (three launches per call: prep, blend GEMM, skin + joints).
+//   * skin + joints kernel: one thread per vertex, 8 crops per workgroup pass: 24 weights (registers) x 24 bone matrices (scalar
+//     loads) -> 3x4 transform; the crop group's last workgroup finishes its joints (three launches per call: prep, blend GEMM, skin + joints).
 //   * every global access is coalesced: consecutive lanes = consecutive vertices (12 B each) on loads and stores.
 #include "common.h"
 
@@ -123,17 +123,23 @@ __global__ __launch_bounds__(256) void lbs_build_dirs_kernel(const float* __rest
 
 // ---- skinning + joints in ONE kernel.
 //   skin:   T = sum_j W[v][j] * A[b][j] (3x4), out = T . [v_posed; 1] — one thread per vertex, a workgroup owns 256 vertices and
-//           walks CG crops, so the vertex's 24 skinning weights (registers) and the 19 x 256 slice of the extra-joint regressor
-//           (LDS) are read ONCE per CG crops instead of once per crop;
-//   J19:    the workgroup's 256 skinned vertices go through LDS and 228 threads each add 64 products in a fixed order
-//           (smpl_wrapper.py:38-39 vertices2joints) — the first version spent 57 wave reductions (342 cross-lane ops) per thread
-//           and crop on this and re-read the regressor for every crop: 35 us of the 63 us stage at 64 crops;
-//   joints: the LAST of a crop's 27 workgroups to finish (device-scope arrival counter) adds the 27 partial sums in block order,
-//           picks the 21 extra vertices (vertex_joint_selector), applies joint_map (smpl_wrapper.py:19-20,32), update_hips
-//           (:33-36), appends the 19 regressed joints and projects (geometry.py:86-124).  What crosses workgroups (partials,
-//           the 21 picked vertices) moves with device-scope stores / loads, so no cache maintenance and no extra launch. ----
+//           walks CG crops, so the per-vertex constants (24 skinning weights, the J19 regressor entries) stay in registers for
+//           the whole pass.  The crop's 24 bone matrices are wave-uniform: they are read with SCALAR loads (288 floats through
+//           the scalar cache into SGPRs, one SGPR operand per FMA), not staged in LDS.
+//   J19:    (smpl_wrapper.py:38-39 vertices2joints) thread (joint j, vertex group g) of 19 x 12 adds its 22 vertices' products
+//           for all three coordinates — the regressor entries come from registers, the skinned vertex is ONE broadcast
+//           ds_read_b128 — then 57 threads add the 12 group sums in a fixed order.
+//   joints: the LAST of a crop group's 27 workgroups to finish (ONE device-scope arrival per pass) adds the 27 partial sums in
+//           block order for each crop of the group, picks the 21 extra vertices (vertex_joint_selector), applies joint_map
+//           (smpl_wrapper.py:19-20,32), update_hips (:33-36), appends the 19 regressed joints and projects (geometry.py:86-124).
+//           What crosses workgroups (partials, the 21 picked vertices) moves with device-scope stores / loads.
+// Round 3 (PMC at 512 crops, profiles/r3a_pmc_lbs_b512.json): the round-2 kernel was LDS-bound, not HBM- or latency-bound —
+// every thread re-read the 72 float4 of the bone matrices from LDS per crop and the regression did two ds_read_b32 per FMA:
+// ~3700 LDS cycles per workgroup and crop = 83 of its 142 us; it also drained its stores and took one device-scope atomic round
+// trip PER CROP.  Here: no LDS traffic for the skinning, 22 ds_read_b128 per thread for the regression, one arrival per pass. ----
 constexpr int SKB = (NV + 255) / 256;     // skin workgroups per crop = 27
 constexpr int CG_MAX = 8;                 // most crops per workgroup pass (chosen per call: enough workgroups first)
+constexpr int RG = 12, RV = 22;           // regression: 12 vertex groups of 22 (the last one: 14) x 19 joints = 228 threads
 __global__ __launch_bounds__(256) void lbs_skin_joints_kernel(const float* __restrict__ vposed, const float* __restrict__ W,
                                                               const float* __restrict__ A, const float* __restrict__ J19,
                                                               const float* __restrict__ Jtr, const int32_t* __restrict__ extra,
@@ -141,10 +147,8 @@ __global__ __launch_bounds__(256) void lbs_skin_joints_kernel(const float* __res
                                                               const float* __restrict__ cam_t, float* __restrict__ verts,
                                                               float* jpart, float* xv, unsigned* cnt, float* __restrict__ joints,
                                                               float* __restrict__ kp2d, float focal_over_size, int B, int CG) {
-    __shared__ f32x4 AS[2][NJ * 3];          // bone matrices of the current / next crop
-    __shared__ float J19s[19][257];
-    __shared__ float outs[256 * 3];
-    __shared__ float part[4][57];
+    __shared__ __attribute__((aligned(16))) float outs[256 * 4];     // the crop's skinned vertices of this workgroup (x, y, z, -)
+    __shared__ float part[RG][57];
     __shared__ float jo[44][3];
     __shared__ int s_last;
     const int tid = threadIdx.x, v = blockIdx.x * 256 + tid;
@@ -153,98 +157,118 @@ __global__ __launch_bounds__(256) void lbs_skin_joints_kernel(const float* __res
     f32x4 wv[NJ / 4];
 #pragma unroll
     for (int q = 0; q < NJ / 4; ++q) wv[q] = reinterpret_cast<const f32x4*>(W + (int64_t)vv * NJ)[q];
+    // regression thread (rj, rg): joint rj, vertices rg*22 .. rg*22+21 of this workgroup's 256; its regressor entries, once
+    const int rj = tid % 19, rg = tid / 19;
+    float jw[RV];
 #pragma unroll
-    for (int j = 0; j < 19; ++j) J19s[j][tid] = vok ? J19[(int64_t)j * NV + v] : 0.f;
+    for (int u = 0; u < RV; ++u) {
+        const int lv = rg * RV + u, gv = blockIdx.x * 256 + lv;
+        jw[u] = (rg < RG && lv < 256 && gv < NV) ? J19[(int64_t)rj * NV + gv] : 0.f;
+    }
     unsigned slots = 0;                   // which of the 21 extra-joint slots pick this thread's vertex (bit k; an id may repeat)
-    for (int k = 0; k < 21; ++k)
-        if (vok && extra[k] == v) slots |= 1u << k;
-    // software pipeline over the crops of this pass: the posed vertex and the bone matrices of crop c + 1 are requested before
-    // crop c is skinned (a pass is a serial chain per workgroup; without this every crop exposed one full memory round trip)
+#pragma unroll
+    for (int k = 0; k < 21; ++k) slots |= (extra[k] == v && vok) ? 1u << k : 0u;      // 21 scalar loads in one batch, no branches
     const int b0 = blockIdx.y * CG;
+    // the posed vertex of crop c + 1 is requested before crop c is skinned
     float xn = 0.f, yn = 0.f, zn = 0.f;
-    f32x4 an = {0.f, 0.f, 0.f, 0.f};
     if (b0 < B) {
         const float* p = vposed + ((int64_t)b0 * NV + vv) * 3;
         xn = p[0]; yn = p[1]; zn = p[2];
-        if (tid < NJ * 3) AS[0][tid] = reinterpret_cast<const f32x4*>(A + (int64_t)b0 * NJ * 12)[tid];
     }
     for (int c = 0; c < CG; ++c) {
-        const int b = b0 + c;
+        const int b = b0 + c;             // wave-uniform
         if (b >= B) break;
-        __syncthreads();                  // AS[c & 1] is complete; outs / part / jo of the previous crop are no longer read
         const float x = xn, y = yn, z = zn;
-        const bool more = c + 1 < CG && b + 1 < B;
-        if (more) {
+        if (c + 1 < CG && b + 1 < B) {
             const float* p = vposed + ((int64_t)(b + 1) * NV + vv) * 3;
             xn = p[0]; yn = p[1]; zn = p[2];
-            if (tid < NJ * 3) an = reinterpret_cast<const f32x4*>(A + (int64_t)(b + 1) * NJ * 12)[tid];
         }
-        const f32x4* ASc = AS[c & 1];
-        f32x4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0;
+        const float* __restrict__ Ab = A + (int64_t)b * NJ * 12;      // uniform address: scalar loads
+        float T[12];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const float w = wv[j >> 2][j & 3];
-            T0 += w * ASc[j * 3 + 0];
-            T1 += w * ASc[j * 3 + 1];
-            T2 += w * ASc[j * 3 + 2];
+        for (int k = 0; k < 12; ++k) T[k] = 0.f;
+        // two joints (24 scalars = three s_load_dwordx8) at a time; the FMA is spelled in assembly with the matrix entry as its SGPR
+        // operand: left to itself hipcc packs pairs of these FMAs into v_pk_fma_f32, assembles their SGPR pairs with s_mov and
+        // spills SGPRs to VGPR lanes (210 VGPRs, 292 v_readlane / v_writelane per crop)
+#pragma unroll
+        for (int q = 0; q < NJ / 2; ++q) {
+            float a[24];
+#pragma unroll
+            for (int k = 0; k < 24; ++k) a[k] = Ab[q * 24 + k];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const float w = wv[q >> 1][(q & 1) * 2 + jj];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) asm("v_fmac_f32 %0, %1, %2" : "+v"(T[k]) : "s"(a[jj * 12 + k]), "v"(w));
+            }
         }
-        const float ox = T0[0] * x + T0[1] * y + T0[2] * z + T0[3];
-        const float oy = T1[0] * x + T1[1] * y + T1[2] * z + T1[3];
-        const float oz = T2[0] * x + T2[1] * y + T2[2] * z + T2[3];
+        const float ox = T[0] * x + T[1] * y + T[2] * z + T[3];
+        const float oy = T[4] * x + T[5] * y + T[6] * z + T[7];
+        const float oz = T[8] * x + T[9] * y + T[10] * z + T[11];
         if (vok) {
             float* o = verts + ((int64_t)b * NV + v) * 3;
             o[0] = ox; o[1] = oy; o[2] = oz;
         }
-        outs[tid * 3 + 0] = vok ? ox : 0.f;
-        outs[tid * 3 + 1] = vok ? oy : 0.f;
-        outs[tid * 3 + 2] = vok ? oz : 0.f;
         for (unsigned m = slots; m; m &= m - 1) {
             float* xo = xv + ((int64_t)b * 21 + __builtin_ctz(m)) * 3;
             st_dev(xo + 0, ox); st_dev(xo + 1, oy); st_dev(xo + 2, oz);
         }
+        __syncthreads();                  // outs / part of the previous crop are no longer read
+        *reinterpret_cast<f32x4*>(outs + tid * 4) = f32x4{vok ? ox : 0.f, vok ? oy : 0.f, vok ? oz : 0.f, 0.f};
         __syncthreads();
-        if (tid < 228) {                  // 57 outputs x 4 quarters of 64 vertices, fixed order
-            const int o = tid % 57, q = tid / 57, j = o / 3, i = o - j * 3;
+        if (tid < 19 * RG) {
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+            for (int u = 0; u < RV; ++u) {
+                const int lv = min(rg * RV + u, 255);                 // past the end: weight 0
+                const f32x4 o = *reinterpret_cast<const f32x4*>(outs + lv * 4);
+                sx = fmaf(jw[u], o[0], sx); sy = fmaf(jw[u], o[1], sy); sz = fmaf(jw[u], o[2], sz);
+            }
+            part[rg][rj * 3 + 0] = sx; part[rg][rj * 3 + 1] = sy; part[rg][rj * 3 + 2] = sz;
+        }
+        __syncthreads();
+        if (tid < 57) {
+            float sacc = part[0][tid];
+#pragma unroll
+            for (int g = 1; g < RG; ++g) sacc += part[g][tid];
+            st_dev(jpart + ((int64_t)b * SKB + blockIdx.x) * 57 + tid, sacc);
+        }
+    }
+    // ONE arrival per pass: this workgroup's device-scope stores for all its crops have completed before it counts itself in
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&cnt[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(SKB - 1);
+    __syncthreads();
+    if (!s_last) return;
+    for (int c = 0; c < CG; ++c) {        // all 27 workgroups of this crop group have arrived: finish its crops
+        const int b = b0 + c;
+        if (b >= B) break;
+        if (tid < 57) {                   // J19 regressor: the partial sums of workgroups 0 .. 26 in order
             float sacc = 0.f;
-#pragma unroll 8
-            for (int u = 0; u < 64; ++u) sacc = fmaf(J19s[j][q * 64 + u], outs[(q * 64 + u) * 3 + i], sacc);
-            part[q][o] = sacc;
+            for (int k = 0; k < SKB; ++k) sacc += ld_dev(jpart + ((int64_t)b * SKB + k) * 57 + tid);
+            jo[25 + tid / 3][tid % 3] = sacc;
+        }
+        if (tid >= 64 && tid < 64 + 75) {
+            const int t = tid - 64, j = t / 3, i = t % 3;
+            const int src = jmap[j];
+            jo[j][i] = (src < NJ) ? Jtr[((int64_t)b * NJ + src) * 3 + i] : ld_dev(xv + ((int64_t)b * 21 + (src - NJ)) * 3 + i);
         }
         __syncthreads();
-        if (tid < 57) st_dev(jpart + ((int64_t)b * SKB + blockIdx.x) * 57 + tid, ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid]);
-        if (more && tid < NJ * 3) AS[(c + 1) & 1][tid] = an;          // next crop's bone matrices (landed during the regression)
-        // arrival: this workgroup's device-scope stores for crop b have completed before it counts itself in
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) s_last = __hip_atomic_fetch_add(&cnt[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(SKB - 1);
-        __syncthreads();
-        if (s_last) {                     // all 27 workgroups of crop b have arrived: finish the crop
-            if (tid < 57) {               // J19 regressor: the partial sums of workgroups 0 .. 26 in order
-                float sacc = 0.f;
-                for (int k = 0; k < SKB; ++k) sacc += ld_dev(jpart + ((int64_t)b * SKB + k) * 57 + tid);
-                jo[25 + tid / 3][tid % 3] = sacc;
-            }
-            if (tid >= 64 && tid < 64 + 75) {
-                const int t = tid - 64, j = t / 3, i = t % 3;
-                const int src = jmap[j];
-                jo[j][i] = (src < NJ) ? Jtr[((int64_t)b * NJ + src) * 3 + i] : ld_dev(xv + ((int64_t)b * 21 + (src - NJ)) * 3 + i);
-            }
-            __syncthreads();
-            // SMPL(update_hips=True), smpl_wrapper.py:33-36, on the 25 mapped joints (before the extra joints are appended):
-            //   j[9,12] = (j[9,12] + 0.25*(j[9,12] - j[12,9])) + 0.5*(j[8] - 0.5*(j[9,12] + j[12,9]))
-            if (*update_hips && tid < 3) {
-                const float a = jo[9][tid], cc = jo[12][tid], m = jo[8][tid];
-                jo[9][tid] = (a + 0.25f * (a - cc)) + 0.5f * (m - 0.5f * (a + cc));
-                jo[12][tid] = (cc + 0.25f * (cc - a)) + 0.5f * (m - 0.5f * (cc + a));
-            }
-            __syncthreads();
-            if (tid < 132 && joints) joints[(int64_t)b * 132 + tid] = jo[tid / 3][tid % 3];
-            if (tid < 44 && kp2d && cam_t) {
-                const float px = jo[tid][0] + cam_t[b * 3 + 0], py = jo[tid][1] + cam_t[b * 3 + 1], pz = jo[tid][2] + cam_t[b * 3 + 2];
-                kp2d[((int64_t)b * 44 + tid) * 2 + 0] = (px / pz) * focal_over_size;
-                kp2d[((int64_t)b * 44 + tid) * 2 + 1] = (py / pz) * focal_over_size;
-            }
+        // SMPL(update_hips=True), smpl_wrapper.py:33-36, on the 25 mapped joints (before the extra joints are appended):
+        //   j[9,12] = (j[9,12] + 0.25*(j[9,12] - j[12,9])) + 0.5*(j[8] - 0.5*(j[9,12] + j[12,9]))
+        if (*update_hips && tid < 3) {
+            const float a = jo[9][tid], cc = jo[12][tid], m = jo[8][tid];
+            jo[9][tid] = (a + 0.25f * (a - cc)) + 0.5f * (m - 0.5f * (a + cc));
+            jo[12][tid] = (cc + 0.25f * (cc - a)) + 0.5f * (m - 0.5f * (cc + a));
         }
+        __syncthreads();
+        if (tid < 132 && joints) joints[(int64_t)b * 132 + tid] = jo[tid / 3][tid % 3];
+        if (tid < 44 && kp2d && cam_t) {
+            const float px = jo[tid][0] + cam_t[b * 3 + 0], py = jo[tid][1] + cam_t[b * 3 + 1], pz = jo[tid][2] + cam_t[b * 3 + 2];
+            kp2d[((int64_t)b * 44 + tid) * 2 + 0] = (px / pz) * focal_over_size;
+            kp2d[((int64_t)b * 44 + tid) * 2 + 1] = (py / pz) * focal_over_size;
+        }
+        __syncthreads();                  // jo is rewritten by the next crop
     }
 }
 

@@ -235,9 +235,11 @@ class Engine:
 
     # ------------------------------------------------------------------ profiler
     def prof_enable(self, on=True):
-        """on: False / True (every kernel class) / "gemm" (only the four ViT GEMM classes: cheapest, see the header)."""
+        """on: False / True (every kernel class) / "gemm" (the four ViT GEMM classes) / "fc1" (only the dominant kernel: cheapest,
+        see the header)."""
+        mode = {"gemm": 2, "fc1": 3}.get(on, 1 if on else 0)
         with torch.cuda.device(self.device):
-            _cabi.check(self.lib.thmr_prof_enable(self.h, 2 if on == "gemm" else (1 if on else 0)), self.h)
+            _cabi.check(self.lib.thmr_prof_enable(self.h, mode), self.h)
 
     def prof_collect(self, reset=True):
         arr = (_cabi.ProfEntry * len(_cabi.PROF_NAMES))()
