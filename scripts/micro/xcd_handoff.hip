@@ -87,7 +87,9 @@ __device__ __forceinline__ void produce(float* buf, int rows, int it, int tid) {
     }
 }
 
-// every workgroup reads the 64-row panel (blockIdx % (rows/64)) completely; returns the number of wrong values seen by this thread
+// every workgroup reads the 64-row panel (blockIdx % (rows/64)) completely; returns the number of wrong values seen by this thread.
+// Eight 16-byte loads per thread are in flight at a time (a GEMM's ring keeps 3-4 K tiles = 12-16 KB per wave in flight); the LDS-DMA
+// variant double-buffers 16 KiB chunks and tracks them with vmcnt like the ring kernel does.
 template <int V>
 __device__ __forceinline__ unsigned consume(const float* buf, int rows, int it, int tid, float* lds) {
     const int panel = blockIdx.x % (rows / 64);
@@ -95,37 +97,63 @@ __device__ __forceinline__ unsigned consume(const float* buf, int rows, int it, 
     const int base_idx = panel * 64 * COLS;
     unsigned bad = 0;
     if (V == 4) {
-        // 64 rows x 1280 floats = 320 KiB: 20 chunks of 16 KiB through LDS; a wave instruction moves 1 KiB (64 lanes x 16 B, lane-linear)
+        // 64 rows x 1280 floats = 320 KiB: 20 chunks of 16 KiB through a 2 x 16 KiB LDS ring; a wave instruction moves 1 KiB
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         const uint32_t l0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)lds;
-        for (int c = 0; c < 20; ++c) {
+        auto issue = [&](int c) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int piece = c * 16 + q * 4 + wave;                              // 1 KiB pieces of the panel, in order
-                dma16_sc1(p + (size_t)piece * 256, (uint32_t)lane * 16u, l0 + (uint32_t)(q * 4 + wave) * 1024u);
+                dma16_sc1(p + (size_t)piece * 256, (uint32_t)lane * 16u, l0 + (uint32_t)((c & 1) * 16 + q * 4 + wave) * 1024u);
             }
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            for (int i = tid; i < 4096; i += NT) bad += lds[i] != expect(it, base_idx + c * 4096 + i);
-            __syncthreads();
+        };
+        issue(0);
+        for (int c = 0; c < 20; ++c) {
+            if (c + 1 < 20) {
+                issue(c + 1);
+                asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");      // chunk c has landed (in-order return), c + 1 in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            const float* L = lds + (c & 1) * 4096;
+            for (int i = tid; i < 4096; i += NT) bad += L[i] != expect(it, base_idx + c * 4096 + i);
+            __syncthreads();                                                          // the buffer is rewritten by chunk c + 2
         }
         return bad;
     }
-    for (int i = tid; i < 64 * COLS / 4; i += NT) {
-        f32x4 v;
-        if (V == 2) {
+    constexpr int U = 8;
+    for (int i0 = tid; i0 < 64 * COLS / 4; i0 += NT * U) {
+        f32x4 v[U];
+        if (V == 3) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __hip_atomic_load(p + i * 4 + e, __ATOMIC_RELAXED, AGENT);
-        } else if (V == 3) v = load16_sc1(p + i * 4);
-        else v = *reinterpret_cast<const f32x4*>(p + i * 4);
+            for (int k = 0; k < U; ++k) {
+                const int i = min(i0 + k * NT, 64 * COLS / 4 - 1);
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[k]) : "v"(p + i * 4) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bad += v[e] != expect(it, base_idx + i * 4 + e);
+            for (int k = 0; k < U; ++k) {
+                const int i = min(i0 + k * NT, 64 * COLS / 4 - 1);
+                if (V == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[k][e] = __hip_atomic_load(p + i * 4 + e, __ATOMIC_RELAXED, AGENT);
+                } else v[k] = *reinterpret_cast<const f32x4*>(p + i * 4);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int i = min(i0 + k * NT, 64 * COLS / 4 - 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bad += v[k][e] != expect(it, base_idx + i * 4 + e);
+        }
     }
     return bad;
 }
 
 template <int V>
 __global__ __launch_bounds__(NT) void persistent(unsigned* sync, float* buf, int rows, int iters, unsigned* errors, unsigned long long* cyc) {
-    __shared__ __attribute__((aligned(16))) float lds[4096];
+    __shared__ __attribute__((aligned(16))) float lds[2 * 4096];
     __shared__ int s_ok;
     const int tid = threadIdx.x;
     unsigned bad = 0, epoch = __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, AGENT);

@@ -154,7 +154,7 @@ def test_full_depth_vs_golden(built_lib, cuda_dev):
     """ViT-H depth 32 + 6-layer decoder: the release architecture, vs tensors the reference's own modules produced — once as
     the fixture's own B=2 batch (small-batch regime) and once at BASELINE.json's full size, B=64 (large-batch regime), where
     the fixture crops are rows 0-1 of the batch.  Size-independent properties at B=64: duplicated crops (rows 2-3) give
-    bit-identical rows, a crop's result does not depend on the batch it rides in (the first 8 crops as their own batch),
+    bit-identical rows, a crop's result does not depend on the batch it rides in (the first 32 crops as their own batch),
     and two runs agree bit for bit."""
     from tokenhmr_amd.config import RELEASE
     from tokenhmr_amd.model import TokenHMR
@@ -167,10 +167,10 @@ def test_full_depth_vs_golden(built_lib, cuda_dev):
     for k in keys:
         assert torch.equal(full[k][2:4], full[k][0:2]), k                    # duplicated crops
     again = model({"img": batch.to(cuda_dev)})
-    eight = model({"img": batch[:8].to(cuda_dev)})
+    part = model({"img": batch[:32].to(cuda_dev)})
     for k in keys:
         assert torch.equal(again[k], full[k]), k                              # deterministic
-        assert torch.equal(eight[k], full[k][:8]), k                          # batch-size invariant within the regime
+        assert torch.equal(part[k], full[k][:32]), k                          # batch-size invariant within the regime (>= 24 crops: unsplit K)
     assert torch.isfinite(full["pred_vertices"]).all() and full["pred_vertices"].shape == (64, 6890, 3)
     del model
     torch.cuda.empty_cache()
@@ -219,9 +219,8 @@ def test_b64_tokens_vs_reference_golden(built_lib, cuda_dev):
 def test_batch_invariance_and_determinism(small):
     """Crops are independent units: a crop's outputs must not depend on its batch position or batch size,
     and two runs must agree bit for bit (deterministic reduction orders everywhere).  Bit-exact batch-size invariance
-    holds within each of the engine's two regimes — B <= 6 (small-batch split-K ViT path, fixed split factor) and
-    B >= 7 (big tiles, unsplit K); across the boundary the K summation is associated differently
-    (test_batch_regimes_agree)."""
+    holds within each of the ViT's four batch ranges — <= 6, 7 ... 11, 12 ... 23, >= 24 crops: one split factor of the proj / fc2
+    K sums each; across a boundary the K summation is associated differently (test_batch_regimes_agree)."""
     cfg, sd, tok, smpl, model = small
     img = _inputs(4, seed=3).to(model.engine.device)
     a = model({"img": img})
@@ -354,26 +353,31 @@ def test_standalone_smpl_gt_meshes(built_lib, cuda_dev):
 
 
 def test_batch_regimes_agree(built_lib, cuda_dev):
-    """The same crops through the small-batch regime (B <= 6: ring kernel, split-K proj / fc2 fused into the LayerNorm,
-    64-query attention workgroups) and the large-batch regime (B >= 7: big tiles): bit-identical within a regime,
-    fp32-rounding-close across them."""
+    """The ViT has four ranges of the batch size, each with ONE association of the proj / fc2 K sums (csrc/engine.hip kSmallM,
+    kMid4M, kMid2M): B <= 6 (64x64 ring kernel, split-K 4, 64-query attention workgroups), 7 ... 11 (big tiles, split-K 4),
+    12 ... 23 (big tiles, split-K 2), >= 24 (big tiles, unsplit).  The same crops must come out bit-identical within a range
+    whatever the batch they ride in, and fp32-rounding-close across ranges."""
     from tokenhmr_amd.config import HMRConfig
     from tokenhmr_amd.model import TokenHMR
     cfg = HMRConfig(vit_depth=3, dec_depth=2)
     sd, tok, smpl = _assets(cfg, seed=5)
-    model = TokenHMR.from_state(cfg, sd, tok, smpl, max_batch=8, device=cuda_dev)
-    img = _inputs(8, seed=11).to(cuda_dev)
-    big = model({"img": img})
-    seven = model({"img": img[:7]})
-    assert torch.equal(seven["pred_vertices"], big["pred_vertices"][:7]) and torch.equal(seven["token_idx"], big["token_idx"][:7])
-    outs = {b: model({"img": img[:b]}) for b in (1, 2, 3, 4, 5, 6)}
-    for b in (1, 2, 3, 4, 5):
-        assert torch.equal(outs[b]["pred_vertices"], outs[6]["pred_vertices"][:b]), b
-        assert torch.equal(outs[b]["cls_logits_softmax"], outs[6]["cls_logits_softmax"][:b]), b
-    d = (outs[6]["pred_vertices"] - big["pred_vertices"][:6]).abs().max().item()
-    dl = (outs[6]["cls_logits_softmax"] - big["cls_logits_softmax"][:6]).abs().max().item()
-    print(f"small-vs-large regime: verts {d:.2e} m, softmax {dl:.2e}")
-    assert d < 2e-5 and dl < 1e-5          # 0.02 mm: different association of the K sum only
+    model = TokenHMR.from_state(cfg, sd, tok, smpl, max_batch=26, device=cuda_dev)
+    img = _inputs(26, seed=11).to(cuda_dev)
+
+    def run(b):
+        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in model({"img": img[:b]}).items()}
+    outs = {b: run(b) for b in (1, 2, 3, 4, 5, 6, 7, 9, 11, 12, 17, 23, 24, 26)}
+    for lo, hi in ((1, 6), (7, 11), (12, 23), (24, 26)):
+        for b in outs:
+            if lo <= b < hi:
+                assert torch.equal(outs[b]["pred_vertices"], outs[hi]["pred_vertices"][:b]), (b, hi)
+                assert torch.equal(outs[b]["cls_logits_softmax"], outs[hi]["cls_logits_softmax"][:b]), (b, hi)
+                assert torch.equal(outs[b]["token_idx"], outs[hi]["token_idx"][:b]), (b, hi)
+    for a, b in ((6, 11), (11, 23), (23, 26), (6, 26)):
+        d = (outs[a]["pred_vertices"] - outs[b]["pred_vertices"][:a]).abs().max().item()
+        dl = (outs[a]["cls_logits_softmax"] - outs[b]["cls_logits_softmax"][:a]).abs().max().item()
+        print(f"range of {a} crops vs range of {b}: verts {d:.2e} m, softmax {dl:.2e}")
+        assert d < 2e-5 and dl < 1e-5          # 0.02 mm: different association of the K sum only
     del model
     torch.cuda.empty_cache()
 

@@ -101,6 +101,44 @@ def test_gemm_ring_deterministic_and_qscale(built_lib, cuda_dev):
     assert torch.equal(ops.gemm(a, w, b, variant="ring8", **kw), ref)
 
 
+SPLITK_SHAPES = [(1536, 1280, 5120), (1344, 1280, 1280), (3072, 1280, 5120), (200, 72, 512), (130, 1280, 256)]
+
+
+@pytest.mark.parametrize("shape", SPLITK_SHAPES)
+def test_gemm_big_tile_splitk(built_lib, cuda_dev, shape):
+    """Split-K on the big LDS-DMA tiles (proj / fc2 at 7 ... 23 crops): every tile x split factor against fp64, run-to-run
+    determinism, and the two invariants the engine's regimes rely on — within a split factor the result does not depend on the
+    tile (each K slice is summed in the one order all big tiles share, the slices are added in a fixed order), and a row's
+    result does not depend on how many rows share the launch."""
+    from tokenhmr_amd import ops
+    M, N, K = shape
+    a, w, b, r = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(N, seed=3), _rand(M, N, seed=4)
+    da, dw, db, dr = a.to(cuda_dev), w.to(cuda_dev), b.to(cuda_dev), r.to(cuda_dev)
+    for ks in (2, 4):
+        if K % (32 * ks):
+            continue
+        outs = {}
+        for tile in ("128x128", "128x160", "128x96", "auto"):
+            for epi in ("bias", "bias_resid"):
+                o = ops.gemm(da, dw, db, dr if epi == "bias_resid" else None, epi=epi, variant=f"{tile}/k{ks}")
+                assert torch.allclose(o.cpu(), _gemm_ref(a, w, b, r, epi, 1.0, 0), atol=3e-5, rtol=1e-5), (tile, ks, epi)
+                assert torch.equal(o, ops.gemm(da, dw, db, dr if epi == "bias_resid" else None, epi=epi, variant=f"{tile}/k{ks}"))
+                outs[(tile, epi)] = o
+        for epi in ("bias", "bias_resid"):
+            for tile in ("128x160", "128x96", "auto"):
+                assert torch.equal(outs[(tile, epi)], outs[("128x128", epi)]), (tile, ks, epi)      # tile-independent
+        if M > 256:
+            half = ops.gemm(da[:M // 2].contiguous(), dw, db, epi="bias", variant=f"auto/k{ks}")
+            assert torch.equal(half, outs[("auto", "bias")][:M // 2]), ks                            # batch-independent
+
+
+def test_gemm_big_tile_splitk_rejects(built_lib, cuda_dev):
+    from tokenhmr_amd import ops, _cabi
+    a, w = _rand(256, 96, seed=1).to(cuda_dev), _rand(128, 96, seed=2).to(cuda_dev)
+    with pytest.raises(_cabi.EngineError):
+        ops.gemm(a, w, variant="128x128/k2")          # 96 % 64 != 0
+
+
 TINY_SHAPES = [(21, 512, 1536), (160, 512, 768), (160, 256, 2048), (126, 6, 1536), (960, 512, 1536), (55, 512, 512), (37, 31, 256)]
 
 

@@ -41,6 +41,10 @@ struct GemmArgs {
     float* cs_out;
     const int32_t* cs_inv;
     int cs_tin, cs_tout, cs_dil, cs_relu;
+    // split-K of the big-tile kernel (gemm_f32_kernel, launch_gemm_splitk): ksplit > 1 = the launch holds ksplit copies of the tile
+    // grid, copy sp reduces K slice [sp*K/ksplit, (sp+1)*K/ksplit) and stores its RAW partial tile to C + sp*M*ldc (C = the
+    // partial-sum buffer part[ksplit][M][N], no epilogue); 0 / 1 = off.
+    int ksplit;
 };
 
 // Branch-free fp32 erf, < 1.5 ulp over the whole line (tests/test_gpu_ops.py::test_gelu_epilogue_ulp): two minimax
@@ -238,6 +242,9 @@ int launch_mixer_fused(const MixerParams& p, int B, hipStream_t s);
 
 // host-side launch helpers (defined in the .hip files); all return 0 / negative
 int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s);          // gemm_f32.hip
+// mid-size batches: the same big LDS-DMA tiles with K split `ksplit` ways into part[ksplit][M][N] (raw partial sums, summed in a
+// fixed order by launch_splitk_resid_ln / launch_splitk_epilogue); variant as for launch_gemm (-1 = cost model over tiles * ksplit)
+int launch_gemm_splitk(const GemmArgs& a, int variant, int ksplit, float* part, hipStream_t s);
 // small-M path: 64x64 tiles, `ring`-deep LDS-DMA ring (4 or 8), optional split-K into part[ksplit][M][N] (epilogue then
 // applied by launch_splitk_epilogue / launch_splitk_resid_ln)
 int launch_gemm_ring(const GemmArgs& a, int epi, int ring, int ksplit, float* part, hipStream_t s);   // gemm_f32.hip

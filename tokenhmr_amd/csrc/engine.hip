@@ -35,6 +35,9 @@ constexpr float VIT_EPS = 1e-6f, LN_EPS = 1e-5f;
 constexpr float FOCAL = 5000.0f, IMG = 256.0f;
 // small-batch ViT path (gemm_ring_kernel): used while M = 192*B <= kSmallM; crossovers measured in profiles/r1_small_gemm_variants.log
 constexpr int kSmallM = 1152, kSplitKMax = 4;     // B <= 6
+// mid-size batches: proj / fc2 (N = 1280: 120-480 big output tiles) run split-K on the big LDS-DMA tiles, 4 ways up to kMid4M rows
+// and 2 ways up to kMid2M (crossovers measured, profiles/r3c_mid_batch_splitk.log); each range is its own regime of the K sum
+constexpr int kMid4M = 11 * 192, kMid2M = 23 * 192;
 // decoder + mixer stack: the persistent decoder kernel and the one-workgroup-per-crop mixer kernel win while the work is
 // latency-bound (B = 1: 0.96 vs 1.01 ms, B = 64: 1.58 vs 1.93 ms per head); from a few hundred crops on the same products are
 // real GEMMs (M = B and M = 160 B rows) and the tiled MFMA kernels win (B = 512: 6.7 vs 7.5 ms) — profiles/r2e_head_fused_vs_chain.log
@@ -81,6 +84,7 @@ struct thmr_engine {
     bool legacy_head = false;         // THMR_LEGACY_HEAD=1: force the chain-of-GEMMs head at every batch size (A/B only)
     bool mixer_cluster = true;        // THMR_MIXER_CLUSTER=0: always run the mixer stack as its own one-workgroup-per-crop kernel (A/B only)
     bool tiny_gemm = true;            // THMR_TINY_GEMM=0: the VQ decoder's GEMMs stay on the ring kernel in the small-batch regime (A/B only)
+    int mid_split_force = -1;         // THMR_MID_SPLIT=0|2|4: force the split factor of proj / fc2 at 7 ... 23 crops (A/B only; -1 = rule)
     bool smpl_loaded = false, finalized = false;
     unsigned* host_err = nullptr;     // host-mapped sticky error word of the persistent decoder kernel (hipHostMalloc)
     std::string err;
@@ -104,6 +108,7 @@ struct thmr_engine {
         size_t x, h, big, part;
         size_t dx, dh, dv, dq, dca, dff, ro;
         size_t mt, cf, cf2, y1, tT, u, yt, y, s, z0, zh, nl, nl2;
+        size_t part_floats;       // capacity of `part`
         size_t feat, gat, gat2, act0, act1, act2, bpose, tokidx, sync;
         size_t A, pf, Jtr, vposed, rot, betas, cam, camt, verts, joints, pose6d, xv, lcnt;
         size_t total;
@@ -328,7 +333,12 @@ void layout_scratch(thmr_engine* e) {
     s.x = take(M * DIM);
     s.h = take(M * DIM);
     s.big = take(M * 6144);
-    s.part = take((size_t)kSplitKMax * kSmallM * DIM);   // split-K partial sums of the small-batch proj / fc2 GEMMs
+    {   // split-K partial sums of the proj / fc2 GEMMs: 4 x M x 1280 up to kMid4M rows, 2 x M x 1280 up to kMid2M rows
+        const size_t m4 = M < (size_t)kMid4M ? M : (size_t)kMid4M, m2 = M < (size_t)kMid2M ? M : (size_t)kMid2M;
+        const size_t need = 4 * m4 > 2 * m2 ? 4 * m4 : 2 * m2;
+        s.part_floats = (need > (size_t)kSplitKMax * kSmallM ? need : (size_t)kSplitKMax * kSmallM) * DIM;
+        s.part = take(s.part_floats);
+    }
     s.dx = take(B * E); s.dh = take(B * E); s.dv = take(B * INNER); s.dq = take(B * INNER); s.dca = take(B * INNER);
     s.dff = take(B * DEC_MLP); s.ro = take(B * 32);
     s.mt = take(B * TN * HID); s.cf = take(B * TN * HID); s.cf2 = take(B * TN * HID);
@@ -403,6 +413,11 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
     // one split factor for the whole regime, so a crop's result does not depend on how many crops share its batch (B <= 6)
     const int ks_proj = kSplitKMax, ks_fc2 = kSplitKMax;
     float* part = e->S(e->so.part);
+    // mid-size batches (7 ... 23 crops): proj / fc2 split K 4 or 2 ways on the big tiles, reduced by the same residual + LayerNorm
+    // kernel; ONE factor per range for both GEMMs, so a crop's result does not depend on the batch it rides in within a range
+    int mid_split = small ? 1 : e->mid_split_force >= 0 ? (e->mid_split_force > 1 && M <= kMid2M ? e->mid_split_force : 1)
+                          : M <= kMid4M ? 4 : M <= kMid2M ? 2 : 1;
+    if ((size_t)mid_split * M * DIM > e->so.part_floats) mid_split = 1;      // only reachable with the A/B knob
     // x += Linear(A) + bias;  y = LayerNorm(x)      (vit.py:149 / :150 followed by the next norm)
     auto resid_linear_ln = [&](int cls, const float* A, int K, const float* Wt, const float* bias, int ks, const float* g,
                                const float* bt, float* y) -> int {
@@ -415,6 +430,14 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             }
             ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (ks + 3.0) * M * DIM);
             LAUNCH_OK(launch_splitk_resid_ln(part, ks, M, DIM, bias, x, x, g, bt, y, VIT_EPS, st));
+        } else if (mid_split > 1) {
+            {
+                ProfScope ps(e, st, cls, fl, by);
+                GemmArgs a = mk(A, K, Wt, K, nullptr, nullptr, 0, x, DIM, M, DIM, K);
+                LAUNCH_OK(launch_gemm_splitk(a, -1, mid_split, part, st));
+            }
+            ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (mid_split + 3.0) * M * DIM);
+            LAUNCH_OK(launch_splitk_resid_ln(part, mid_split, M, DIM, bias, x, x, g, bt, y, VIT_EPS, st));
         } else {
             {
                 ProfScope ps(e, st, cls, fl, by);
@@ -877,6 +900,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* lg = getenv("THMR_LEGACY_HEAD"); e->legacy_head = lg && lg[0] == '1'; }
     { const char* mc = getenv("THMR_MIXER_CLUSTER"); e->mixer_cluster = !(mc && mc[0] == '0'); }
     { const char* tg = getenv("THMR_TINY_GEMM"); e->tiny_gemm = !(tg && tg[0] == '0'); }
+    { const char* ms = getenv("THMR_MID_SPLIT"); e->mid_split_force = ms ? atoi(ms) : -1; }
     { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
     *out = e;
     return 0;
@@ -1243,6 +1267,26 @@ int thmr_op_gemm(const float* A, int64_t lda, const float* W, const float* bias,
         }
         LAUNCH_OK(launch_gemm_ring(a, epi, ring, ksplit, ws, st));
         if (ksplit > 1) LAUNCH_OK(launch_splitk_epilogue(a, epi, ws, ksplit, st));
+    } else if (variant >= 200 && variant < 500) {
+        // split-K on the big LDS-DMA tiles: 200 + tile (7 / 8 / 10, 0 = cost model) = 2 ways, 400 + tile = 4 ways; partial sums in a
+        // grow-only workspace, then the fixed-order reduce + epilogue (what the engine fuses into its residual + LayerNorm kernel)
+        const int ksplit = variant >= 400 ? 4 : 2, tile = variant % 100;
+        if (epi == EPI_BIAS_POS) return fail(e, THMR_ERR_INVALID, "split-K GEMM has no pos-embed epilogue");
+        static std::mutex mu2;
+        static std::map<std::pair<int, void*>, std::pair<float*, size_t>> pool2;
+        int dev = 0;
+        HIP_OK(hipGetDevice(&dev));
+        std::unique_lock<std::mutex> lk(mu2);
+        auto& slot = pool2[{dev, stream}];
+        const size_t need = (size_t)ksplit * M * N;
+        if (need > slot.second) {
+            if (slot.first) { HIP_OK(hipDeviceSynchronize()); HIP_OK(hipFree(slot.first)); slot = {nullptr, 0}; }
+            float* p = nullptr;
+            HIP_OK(hipMalloc(&p, need * sizeof(float)));
+            slot = {p, need};
+        }
+        LAUNCH_OK(launch_gemm_splitk(a, tile == 0 ? -1 : tile, ksplit, slot.first, st));
+        LAUNCH_OK(launch_splitk_epilogue(a, epi, slot.first, ksplit, st));
     } else if (variant == 2) {
         LAUNCH_OK(launch_gemm_skinny(a, epi, st));
     } else {

@@ -75,11 +75,13 @@ typedef __attribute__((address_space(1))) const void gbl_void;
 
 // XCD-aware logical tile id (bijective on [0, nwg) for any launch size nwg, offset by the launch's first tile) -> (tile_m, tile_n),
 // grouped GM tile-rows at a time
-__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int nwg, int base, int& tile_m, int& tile_n) {
+__device__ __forceinline__ int logical_block(int nwg, int base) {
     const int bid = blockIdx.x;
     const int xcd = bid & 7, within = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
-    const int logical = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    return base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+}
+__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int logical, int& tile_m, int& tile_n) {
     constexpr int GM = 8;
     const int per_group = GM * tiles_n;
     const int group = logical / per_group;
@@ -263,7 +265,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
     float* Bs = smem + 2 * BM * LDK;     // [2][BN][LDK]
 
     int tile_m, tile_n;
-    tile_coords(tiles_m, tiles_n, nwg, tile_base, tile_m, tile_n);
+    int logical = logical_block(nwg, tile_base);
+    int nk = a.K / BK;
+    if (a.ksplit > 1) {      // split-K: this block belongs to copy sp of the tile grid and reduces K slice sp into part[sp] (wave-uniform)
+        const int tiles = tiles_m * tiles_n, sp = logical / tiles;
+        logical -= sp * tiles;
+        nk /= a.ksplit;
+        a.A += (int64_t)sp * nk * BK;
+        a.W += (int64_t)sp * nk * BK;
+        a.C += (int64_t)sp * a.M * a.ldc;
+    }
+    tile_coords(tiles_m, tiles_n, logical, tile_m, tile_n);
     const int bm0 = tile_m * BM, bn0 = tile_n * BN;
     if constexpr (DPH != 0) {
         const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, TG_ID = bits 16..19
@@ -388,7 +400,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs a, int 
         for (int ni = 0; ni < TN; ++ni) bf[slot][ni] = *reinterpret_cast<const f32x4*>(Bb + ni * 32 * LDK);
     };
 
-    const int nk = a.K / BK;
     // ---- prologue: tile 0 in LDS (REG: tile 1 already in flight to registers) ----
     if constexpr (DMA) {
         dma_tile(0, 0);
@@ -780,7 +791,7 @@ template <int WM, int WN, int TM, int TN, bool DMA>
 int launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-    const int tiles = tiles_m * tiles_n;
+    const int tiles = tiles_m * tiles_n * (a.ksplit > 1 ? a.ksplit : 1);     // split-K: ksplit copies of the tile grid in one launch
     // separate tail launch only for the 128-row LDS-DMA tiles whose static LDS (> 64 KB) + 16 KB exceeds half a CU
     constexpr bool kCanIsolate = DMA && 2 * (BM + BN) * LDK * 4 + kTailLds > 80 * 1024;
     const int tail = tiles % kSlots;
@@ -875,6 +886,39 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         case 9: return launch_cfg<2, 2, 1, 1, true>(a, epi, s);
         case 10: return launch_cfg<4, 1, 1, 3, true>(a, epi, s);     // 128x96
         default: return launch_cfg<2, 2, 2, 2, true>(a, epi, s);
+    }
+}
+
+// Split-K on the big LDS-DMA tiles (mid-size batches: the N = 1280 GEMMs of 7 ... ~23 crops have only 120-480 output tiles of
+// 128x128, so proj / fc2 either ran on the 64x64 tile (0.82 of the big tiles' per-area rate) or left half the resident slots
+// empty).  `ksplit` copies of the tile grid in ONE launch, copy sp reducing K slice sp into part[sp] (raw fp32 partial tiles,
+// [ksplit][M][N]); the partials are summed in a fixed order by the residual + LayerNorm kernel that follows proj / fc2 anyway
+// (launch_splitk_resid_ln), so split-K adds no launch.  Within a slice K is summed in the same order by every tile variant.
+int launch_gemm_splitk(const GemmArgs& a0, int variant, int ksplit, float* part, hipStream_t s) {
+    if (ksplit < 2 || part == nullptr) return -1;
+    if (a0.M <= 0 || a0.N <= 0 || a0.K <= 0 || (a0.K % (BK * ksplit)) != 0) return -1;
+    if ((a0.lda % 4) != 0 || (a0.ldw % 4) != 0 || a0.lda >= (1 << 22) || a0.ldw >= (1 << 22)) return -1;
+    GemmArgs a = a0;
+    a.ksplit = ksplit;
+    a.C = part; a.ldc = a.N;
+    a.bias = nullptr; a.resid = nullptr; a.ldr = 0; a.cs_out = nullptr;
+    if (variant < 0) {
+        auto cost = [&](int BM, int BN, double eff) {
+            const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * ksplit;
+            return (double)((tiles + 255) / 256) * BM * BN / eff;
+        };
+        const double c7 = cost(128, 128, 0.99), c8 = cost(128, 160, 1.0), c10 = cost(128, 96, 0.985);
+        variant = 8;
+        double best = c8;
+        if (c7 < best) { best = c7; variant = 7; }
+        if (c10 < best) { best = c10; variant = 10; }
+    }
+    switch (variant) {
+        case 8: return launch_cfg<4, 1, 1, 5, true>(a, EPI_NONE, s);
+        case 9: return launch_cfg<2, 2, 1, 1, true>(a, EPI_NONE, s);
+        case 10: return launch_cfg<4, 1, 1, 3, true>(a, EPI_NONE, s);
+        case 7: return launch_cfg<2, 2, 2, 2, true>(a, EPI_NONE, s);
+        default: return -1;
     }
 }
 

@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256) void lbs_build_dirs_kernel(const float* __rest
 // ---- skinning + joints in ONE kernel.
 //   skin:   T = sum_j W[v][j] * A[b][j] (3x4), out = T . [v_posed; 1] — one thread per vertex, a workgroup owns 256 vertices and
 //           walks CG crops, so the per-vertex constants (24 skinning weights, the J19 regressor entries) stay in registers for
-//           the whole pass.  The crop's 24 bone matrices are wave-uniform: they are read with SCALAR loads (288 floats through
-//           the scalar cache into SGPRs, one SGPR operand per FMA), not staged in LDS.
+//           the whole pass.  The crop's 24 bone matrices are staged in LDS (double-buffered, requested one crop ahead) and read
+//           as broadcast ds_read_b128.
 //   J19:    (smpl_wrapper.py:38-39 vertices2joints) thread (joint j, vertex group g) of 19 x 12 adds its 22 vertices' products
 //           for all three coordinates — the regressor entries come from registers, the skinned vertex is ONE broadcast
 //           ds_read_b128 — then 57 threads add the 12 group sums in a fixed order.
@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void lbs_build_dirs_kernel(const float* __rest
 // Round 3 (PMC at 512 crops, profiles/r3a_pmc_lbs_b512.json): the round-2 kernel was LDS-bound, not HBM- or latency-bound —
 // every thread re-read the 72 float4 of the bone matrices from LDS per crop and the regression did two ds_read_b32 per FMA:
 // ~3700 LDS cycles per workgroup and crop = 83 of its 142 us; it also drained its stores and took one device-scope atomic round
-// trip PER CROP.  Here: no LDS traffic for the skinning, 22 ds_read_b128 per thread for the regression, one arrival per pass. ----
+// trip PER CROP.  Here: 22 ds_read_b128 per thread for the regression instead of 128 ds_read_b32, one arrival per pass; the 72
+// broadcast reads of the bone matrices stay (their 73 KB of LDS return traffic per wave and crop is what is left of the bound). ----
 constexpr int SKB = (NV + 255) / 256;     // skin workgroups per crop = 27
 constexpr int CG_MAX = 8;                 // most crops per workgroup pass (chosen per call: enough workgroups first)
 constexpr int RG = 12, RV = 22;           // regression: 12 vertex groups of 22 (the last one: 14) x 19 joints = 228 threads
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(256) void lbs_skin_joints_kernel(const float* __res
                                                               const float* __restrict__ cam_t, float* __restrict__ verts,
                                                               float* jpart, float* xv, unsigned* cnt, float* __restrict__ joints,
                                                               float* __restrict__ kp2d, float focal_over_size, int B, int CG) {
+    __shared__ f32x4 AS[2][NJ * 3];          // bone matrices of the current / next crop
     __shared__ __attribute__((aligned(16))) float outs[256 * 4];     // the crop's skinned vertices of this workgroup (x, y, z, -)
     __shared__ float part[RG][57];
     __shared__ float jo[44][3];
@@ -171,40 +173,38 @@ __global__ __launch_bounds__(256) void lbs_skin_joints_kernel(const float* __res
     const int b0 = blockIdx.y * CG;
     // the posed vertex of crop c + 1 is requested before crop c is skinned
     float xn = 0.f, yn = 0.f, zn = 0.f;
+    f32x4 an = {0.f, 0.f, 0.f, 0.f};
     if (b0 < B) {
         const float* p = vposed + ((int64_t)b0 * NV + vv) * 3;
         xn = p[0]; yn = p[1]; zn = p[2];
+        if (tid < NJ * 3) AS[0][tid] = reinterpret_cast<const f32x4*>(A + (int64_t)b0 * NJ * 12)[tid];
     }
     for (int c = 0; c < CG; ++c) {
         const int b = b0 + c;             // wave-uniform
         if (b >= B) break;
+        __syncthreads();                  // AS[c & 1] is complete; outs / part of the previous crop are no longer read
         const float x = xn, y = yn, z = zn;
-        if (c + 1 < CG && b + 1 < B) {
+        const bool more = c + 1 < CG && b + 1 < B;
+        if (more) {
             const float* p = vposed + ((int64_t)(b + 1) * NV + vv) * 3;
             xn = p[0]; yn = p[1]; zn = p[2];
+            if (tid < NJ * 3) an = reinterpret_cast<const f32x4*>(A + (int64_t)(b + 1) * NJ * 12)[tid];
         }
-        const float* __restrict__ Ab = A + (int64_t)b * NJ * 12;      // uniform address: scalar loads
-        float T[12];
+        // (Round 3 also tried the bone matrices as SCALAR loads — 288 floats into SGPRs, one SGPR operand per FMA, no LDS return
+        // traffic: each new crop misses the scalar cache and the 12 dependent s_load round trips per crop made the kernel slower,
+        // 161 vs 142 us at 512 crops, profiles/r3b_lbs_scalar_loads.log.)
+        const f32x4* ASc = AS[c & 1];
+        f32x4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) T[k] = 0.f;
-        // two joints (24 scalars = three s_load_dwordx8) at a time; the FMA is spelled in assembly with the matrix entry as its SGPR
-        // operand: left to itself hipcc packs pairs of these FMAs into v_pk_fma_f32, assembles their SGPR pairs with s_mov and
-        // spills SGPRs to VGPR lanes (210 VGPRs, 292 v_readlane / v_writelane per crop)
-#pragma unroll
-        for (int q = 0; q < NJ / 2; ++q) {
-            float a[24];
-#pragma unroll
-            for (int k = 0; k < 24; ++k) a[k] = Ab[q * 24 + k];
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const float w = wv[q >> 1][(q & 1) * 2 + jj];
-#pragma unroll
-                for (int k = 0; k < 12; ++k) asm("v_fmac_f32 %0, %1, %2" : "+v"(T[k]) : "s"(a[jj * 12 + k]), "v"(w));
-            }
+        for (int j = 0; j < NJ; ++j) {
+            const float w = wv[j >> 2][j & 3];
+            T0 += w * ASc[j * 3 + 0];
+            T1 += w * ASc[j * 3 + 1];
+            T2 += w * ASc[j * 3 + 2];
         }
-        const float ox = T[0] * x + T[1] * y + T[2] * z + T[3];
-        const float oy = T[4] * x + T[5] * y + T[6] * z + T[7];
-        const float oz = T[8] * x + T[9] * y + T[10] * z + T[11];
+        const float ox = T0[0] * x + T0[1] * y + T0[2] * z + T0[3];
+        const float oy = T1[0] * x + T1[1] * y + T1[2] * z + T1[3];
+        const float oz = T2[0] * x + T2[1] * y + T2[2] * z + T2[3];
         if (vok) {
             float* o = verts + ((int64_t)b * NV + v) * 3;
             o[0] = ox; o[1] = oy; o[2] = oz;
@@ -213,7 +213,6 @@ __global__ __launch_bounds__(256) void lbs_skin_joints_kernel(const float* __res
             float* xo = xv + ((int64_t)b * 21 + __builtin_ctz(m)) * 3;
             st_dev(xo + 0, ox); st_dev(xo + 1, oy); st_dev(xo + 2, oz);
         }
-        __syncthreads();                  // outs / part of the previous crop are no longer read
         *reinterpret_cast<f32x4*>(outs + tid * 4) = f32x4{vok ? ox : 0.f, vok ? oy : 0.f, vok ? oz : 0.f, 0.f};
         __syncthreads();
         if (tid < 19 * RG) {
@@ -233,6 +232,7 @@ __global__ __launch_bounds__(256) void lbs_skin_joints_kernel(const float* __res
             for (int g = 1; g < RG; ++g) sacc += part[g][tid];
             st_dev(jpart + ((int64_t)b * SKB + blockIdx.x) * 57 + tid, sacc);
         }
+        if (more && tid < NJ * 3) AS[(c + 1) & 1][tid] = an;          // next crop's bone matrices (landed during the regression)
     }
     // ONE arrival per pass: this workgroup's device-scope stores for all its crops have completed before it counts itself in
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -384,6 +384,9 @@ int launch_splitk_resid_ln(const float* part, int S, int rows, int D, const floa
     if (S == 4)
         hipLaunchKernelGGL((splitk_resid_ln_kernel<5, 4>), dim3((rows + 3) / 4), dim3(256), 0, s, part, S, (int64_t)rows * D, bias,
                            resid, xout, gamma, beta, y, rows, eps);
+    else if (S == 2)
+        hipLaunchKernelGGL((splitk_resid_ln_kernel<5, 2>), dim3((rows + 3) / 4), dim3(256), 0, s, part, S, (int64_t)rows * D, bias,
+                           resid, xout, gamma, beta, y, rows, eps);
     else
         hipLaunchKernelGGL((splitk_resid_ln_kernel<5, 0>), dim3((rows + 3) / 4), dim3(256), 0, s, part, S, (int64_t)rows * D, bias,
                            resid, xout, gamma, beta, y, rows, eps);
