@@ -276,3 +276,49 @@ def test_fused_head_equals_chain_head_across_batch_sizes(built_lib, cuda_dev, mo
     fused.status()
     chain.status()
     plain.status()
+
+
+def test_decoder_timeout_is_reported_once_and_the_engine_recovers(built_lib, cuda_dev, monkeypatch):
+    """when the persistent decoder kernel's bounded grid barrier times out, the sticky error word used to
+    poison every later forward, and thmr_forward kept returning 0.  Now the NEXT forward-type call (host-mapped copy of the word)
+    or thmr_engine_status reports it ONCE, the engine resets its barrier words and switches its head to the launch chain (no
+    co-residency needed), and a re-submitted batch gives the chain head's bits.  THMR_DEC_FORCE_TIMEOUT=1 makes the kernel report a
+    timeout that did not happen (and abandon its work, as a real one does)."""
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd import weights as W, _cabi
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    from tokenhmr_amd.engine import Engine
+    cfg = HMRConfig(vit_depth=1, dec_depth=2)
+    sd, tok, smpl = W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0), make_synthetic_smpl(cfg, 0)
+    monkeypatch.setenv("THMR_LEGACY_HEAD", "1")
+    chain = Engine(cfg, max_batch=4, device=cuda_dev)
+    chain.load_state(sd, tok)
+    chain.load_smpl(smpl)
+    chain.finalize()
+    monkeypatch.delenv("THMR_LEGACY_HEAD")
+    monkeypatch.setenv("THMR_DEC_FORCE_TIMEOUT", "1")          # read at finalize
+    a = Engine(cfg, max_batch=4, device=cuda_dev, weight_arena=chain.weight_arena)
+    a.finalize(assume_all_loaded=True)
+    b = Engine(cfg, max_batch=4, device=cuda_dev, weight_arena=chain.weight_arena)
+    b.finalize(assume_all_loaded=True)
+    monkeypatch.delenv("THMR_DEC_FORCE_TIMEOUT")
+    img = torch.randn(4, 3, 256, 256, generator=torch.Generator().manual_seed(3)).to(cuda_dev)
+    ref = {k: v.clone() for k, v in chain.forward(img).items()}
+    # (1) reported by the next forward
+    a.forward(img)
+    torch.cuda.synchronize()
+    with pytest.raises(_cabi.EngineError, match="timed out in a previous forward"):
+        a.forward(img)
+    out = a.forward(img)                                        # re-submit: works, on the chain head
+    torch.cuda.synchronize()
+    a.status()                                                  # and the error is not sticky
+    for k in ("pred_vertices", "pred_cam", "token_idx", "cls_logits_softmax"):
+        assert torch.equal(out[k], ref[k]), k
+    # (2) reported by thmr_engine_status at the caller's sync point
+    b.forward(img)
+    with pytest.raises(_cabi.EngineError, match="timed out"):
+        b.status()
+    b.status()
+    out = b.forward(img)
+    torch.cuda.synchronize()
+    assert torch.equal(out["pred_vertices"], ref["pred_vertices"])

@@ -145,3 +145,32 @@ def test_gpu_vs_real_smplx_fixture(built_lib, cuda_dev):
         o = m(R[:, :1], R[:, 1:], betas, pose2rot=False)
         assert np.abs(o.joints.cpu().numpy() - g[f"joints_{tag}"]).max() < 1e-5
     assert np.abs(o.vertices.cpu().numpy()[:, ::7] - g["vertices"]).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_lbs_duplicate_extra_vertex_ids_and_repeated_calls(built_lib, cuda_dev):
+    """the fused skin + joints kernel mapped a vertex to ONE extra-joint slot, so a vertex id that appears twice in
+    extra_verts left the earlier slot unwritten; and its arrival counters are now zeroed by the prep kernel of the same call
+    instead of by the last arriver.  Two extra-joint slots naming the same vertex must both carry it, at several batch sizes
+    (1 / 2 / 8 crops per workgroup pass) and on repeated calls."""
+    import torch
+    from tokenhmr_amd.smpl import SMPL
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    from oracle import tokenhmr_oracle as O
+    smpl = make_synthetic_smpl(seed=4)
+    ev = smpl["extra_verts"].clone()
+    ev[1] = ev[0]                                  # slots 0 and 1 -> mapped joints 0 and 15 (smpl_wrapper.py:19-20)
+    ev[9] = ev[4]
+    smpl["extra_verts"] = ev
+    for B in (3, 64, 300):
+        m = SMPL(smpl, max_batch=B, device=cuda_dev)
+        g = torch.Generator().manual_seed(B)
+        R = O.rot6d_to_rotmat(torch.randn(B * 24, 6, generator=g)).view(B, 24, 3, 3)
+        betas = torch.randn(B, 10, generator=g)
+        for _ in range(2):
+            out = m(R[:, :1], R[:, 1:], betas, pose2rot=False)
+            v, j = out.vertices.cpu(), out.joints.cpu()
+            assert torch.equal(j[:, 0], v[:, int(ev[0])]) and torch.equal(j[:, 15], v[:, int(ev[0])])
+            rv, rj = O.smpl_forward(R[:, :1], R[:, 1:], betas, smpl)
+            assert (v - rv).abs().max() < 2e-5 and (j - rj).abs().max() < 2e-5
+        m.close()

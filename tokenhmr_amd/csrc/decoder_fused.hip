@@ -484,6 +484,10 @@ __global__ __launch_bounds__(NWAVE * 64) void decoder_persistent_kernel(DecParam
     __syncthreads();
     GridSync gs{p.sync, s_base, 0, p.host_err};
     bool ok = true;
+    if (p.debug_fail && blockIdx.x == 0 && tid == 0) {      // tests only: exercise the host's recovery path without a real timeout
+        __hip_atomic_store(&gs.w[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gs.host_err) __hip_atomic_store(gs.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const int B = p.B;
     // optional stage timeline (THMR_DEC_TIMELINE=1): workgroup 0 stamps the 100 MHz wall clock after every step and barrier
     unsigned long long* stamp = (p.timeline && blockIdx.x == 0 && tid == 0) ? reinterpret_cast<unsigned long long*>(p.sync + 16) : nullptr;

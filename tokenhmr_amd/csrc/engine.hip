@@ -35,9 +35,11 @@ constexpr float VIT_EPS = 1e-6f, LN_EPS = 1e-5f;
 constexpr float FOCAL = 5000.0f, IMG = 256.0f;
 // small-batch ViT path (gemm_ring_kernel): used while M = 192*B <= kSmallM; crossovers measured in profiles/r1_small_gemm_variants.log
 constexpr int kSmallM = 1152, kSplitKMax = 4;     // B <= 6
-// mid-size batches: proj / fc2 (N = 1280: 120-480 big output tiles) run split-K on the big LDS-DMA tiles, 4 ways up to kMid4M rows
-// and 2 ways up to kMid2M (crossovers measured, profiles/r3c_mid_batch_splitk.log); each range is its own regime of the K sum
-constexpr int kMid4M = 11 * 192, kMid2M = 23 * 192;
+// mid-size batches: from 9 to 16 crops proj / fc2 (N = 1280: 135-240 output tiles of 128x128 on 512 resident slots) run split-K 2
+// on the big LDS-DMA tiles (measured per batch size and per GEMM, profiles/r3d_mid_batch_splitk_sweep.log: -10 % per call at 9
+// and 10 crops, -2.5 ... -3.7 % at 11 ... 16; below 9 and from 17 on the unsplit launch is the faster one, and 4 ways never beats 2).
+// That range is its own regime of the K sum; 7-8 crops and >= 17 crops share the unsplit arithmetic.
+constexpr int kMidLoM = 9 * 192, kMidHiM = 16 * 192, kMidSplit = 2;
 // decoder + mixer stack: the persistent decoder kernel and the one-workgroup-per-crop mixer kernel win while the work is
 // latency-bound (B = 1: 0.96 vs 1.01 ms, B = 64: 1.58 vs 1.93 ms per head); from a few hundred crops on the same products are
 // real GEMMs (M = B and M = 160 B rows) and the tiled MFMA kernels win (B = 512: 6.7 vs 7.5 ms) — profiles/r2e_head_fused_vs_chain.log
@@ -84,7 +86,7 @@ struct thmr_engine {
     bool legacy_head = false;         // THMR_LEGACY_HEAD=1: force the chain-of-GEMMs head at every batch size (A/B only)
     bool mixer_cluster = true;        // THMR_MIXER_CLUSTER=0: always run the mixer stack as its own one-workgroup-per-crop kernel (A/B only)
     bool tiny_gemm = true;            // THMR_TINY_GEMM=0: the VQ decoder's GEMMs stay on the ring kernel in the small-batch regime (A/B only)
-    int mid_split_force = -1;         // THMR_MID_SPLIT=0|2|4: force the split factor of proj / fc2 at 7 ... 23 crops (A/B only; -1 = rule)
+    int mid_split_force[2] = {-1, -1};   // THMR_MID_SPLIT=<p><f> (digits 0|2|4): force the split factors of proj and fc2 above 6 crops where the partial-sum buffer allows (A/B only)
     bool smpl_loaded = false, finalized = false;
     unsigned* host_err = nullptr;     // host-mapped sticky error word of the persistent decoder kernel (hipHostMalloc)
     std::string err;
@@ -333,9 +335,8 @@ void layout_scratch(thmr_engine* e) {
     s.x = take(M * DIM);
     s.h = take(M * DIM);
     s.big = take(M * 6144);
-    {   // split-K partial sums of the proj / fc2 GEMMs: 4 x M x 1280 up to kMid4M rows, 2 x M x 1280 up to kMid2M rows
-        const size_t m4 = M < (size_t)kMid4M ? M : (size_t)kMid4M, m2 = M < (size_t)kMid2M ? M : (size_t)kMid2M;
-        const size_t need = 4 * m4 > 2 * m2 ? 4 * m4 : 2 * m2;
+    {   // split-K partial sums of the proj / fc2 GEMMs: 4 x M x 1280 up to kSmallM rows (ring kernel), 2 x M x 1280 up to kMidHiM rows
+        const size_t m2 = M < (size_t)kMidHiM ? M : (size_t)kMidHiM, need = (size_t)kMidSplit * m2;
         s.part_floats = (need > (size_t)kSplitKMax * kSmallM ? need : (size_t)kSplitKMax * kSmallM) * DIM;
         s.part = take(s.part_floats);
     }
@@ -413,13 +414,17 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
     // one split factor for the whole regime, so a crop's result does not depend on how many crops share its batch (B <= 6)
     const int ks_proj = kSplitKMax, ks_fc2 = kSplitKMax;
     float* part = e->S(e->so.part);
-    // mid-size batches (7 ... 23 crops): proj / fc2 split K 4 or 2 ways on the big tiles, reduced by the same residual + LayerNorm
-    // kernel; ONE factor per range for both GEMMs, so a crop's result does not depend on the batch it rides in within a range
-    int mid_split = small ? 1 : e->mid_split_force >= 0 ? (e->mid_split_force > 1 && M <= kMid2M ? e->mid_split_force : 1)
-                          : M <= kMid4M ? 4 : M <= kMid2M ? 2 : 1;
-    if ((size_t)mid_split * M * DIM > e->so.part_floats) mid_split = 1;      // only reachable with the A/B knob
+    // mid-size batches (9 ... 16 crops): proj / fc2 split K two ways on the big tiles, reduced by the same residual + LayerNorm
+    // kernel; ONE factor for the whole range and both GEMMs, so a crop's result does not depend on the batch it rides in within it
+    auto pick = [&](int forced, int rule) {
+        int sp = small ? 1 : forced >= 0 ? (forced > 1 ? forced : 1) : rule;
+        if ((size_t)sp * M * DIM > e->so.part_floats) sp = 1;      // only reachable with the A/B knob
+        return sp;
+    };
+    const int rule = (M >= kMidLoM && M <= kMidHiM) ? kMidSplit : 1;
+    const int mid_proj = pick(e->mid_split_force[0], rule), mid_fc2 = pick(e->mid_split_force[1], rule);
     // x += Linear(A) + bias;  y = LayerNorm(x)      (vit.py:149 / :150 followed by the next norm)
-    auto resid_linear_ln = [&](int cls, const float* A, int K, const float* Wt, const float* bias, int ks, const float* g,
+    auto resid_linear_ln = [&](int cls, const float* A, int K, const float* Wt, const float* bias, int ks, int mid_split, const float* g,
                                const float* bt, float* y) -> int {
         const double fl = 2.0 * M * DIM * (double)K, by = 4.0 * ((double)M * K + (double)DIM * K + 2.0 * M * DIM);
         if (small) {
@@ -472,7 +477,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             LAUNCH_OK(launch_vit_attention(big, h, B, st));
         }
         // proj + residual, then norm2 (vit.py:123,149,150)
-        if (int rc = resid_linear_ln(THMR_PROF_GEMM_PROJ, h, DIM, w.pw, w.pb, ks_proj, w.n2w, w.n2b, h)) return rc;
+        if (int rc = resid_linear_ln(THMR_PROF_GEMM_PROJ, h, DIM, w.pw, w.pb, ks_proj, mid_proj, w.n2w, w.n2b, h)) return rc;
         {   // fc1 + exact GELU (vit.py:83-84)
             ProfScope ps(e, st, THMR_PROF_GEMM_FC1, 2.0 * M * DIM * (double)MLP, 4.0 * ((double)M * DIM + (double)DIM * MLP + (double)M * MLP));
             GemmArgs a = mk(h, DIM, w.f1w, DIM, w.f1b, nullptr, 0, big, MLP, M, MLP, DIM);
@@ -481,7 +486,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         }
         // fc2 + residual (vit.py:85,150), then the next block's norm1 — or last_norm (vit.py:335), kept token-major: the
         // :337 permute is undone by token_head.py:69
-        if (int rc = resid_linear_ln(THMR_PROF_GEMM_FC2, big, MLP, w.f2w, w.f2b, ks_fc2, nxt_w, nxt_b, last && feats_out ? feats_out : h))
+        if (int rc = resid_linear_ln(THMR_PROF_GEMM_FC2, big, MLP, w.f2w, w.f2b, ks_fc2, mid_fc2, nxt_w, nxt_b, last && feats_out ? feats_out : h))
             return rc;
     }
     return 0;
@@ -900,7 +905,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* lg = getenv("THMR_LEGACY_HEAD"); e->legacy_head = lg && lg[0] == '1'; }
     { const char* mc = getenv("THMR_MIXER_CLUSTER"); e->mixer_cluster = !(mc && mc[0] == '0'); }
     { const char* tg = getenv("THMR_TINY_GEMM"); e->tiny_gemm = !(tg && tg[0] == '0'); }
-    { const char* ms = getenv("THMR_MID_SPLIT"); e->mid_split_force = ms ? atoi(ms) : -1; }
+    { const char* ms = getenv("THMR_MID_SPLIT"); if (ms && ms[0] && ms[1]) { e->mid_split_force[0] = ms[0] - '0'; e->mid_split_force[1] = ms[1] - '0'; } }
     { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
     *out = e;
     return 0;
@@ -1035,6 +1040,7 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
         d.sync = reinterpret_cast<unsigned*>(e->S(e->so.sync));
         d.depth = e->dec_depth; d.B = 0;
         { const char* tl = getenv("THMR_DEC_TIMELINE"); d.timeline = tl && tl[0] == '1'; }
+        { const char* ft = getenv("THMR_DEC_FORCE_TIMEOUT"); d.debug_fail = ft && ft[0] == '1'; }
         {
             // never more workgroups than can be resident at once (occupancy query x CUs): the grid barrier depends on it
             const int nb = decoder_max_coresident_blocks(e->cfg.device);
