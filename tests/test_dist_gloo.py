@@ -233,3 +233,50 @@ def test_run_eval_sharded_over_two_ranks_equals_one_process():
     for _, res, counter, names in got:
         assert counter == total and names == one.imgnames == [f"img{i}" for i in range(total)]
         assert res.keys() == ref.keys() and all(abs(res[k] - ref[k]) < 1e-12 for k in ref)
+
+
+def test_pack_records_casts_and_checks_dtypes():
+    """a forward_fn that hands back an int64 token_idx or float64 joints must not be packed as garbage words: the CPU
+    path casts (token indices bit-exactly through int32), and the packed block round-trips."""
+    o = _fake_forward(torch.randn(3, 3, 4, 4, generator=torch.Generator().manual_seed(1)))
+    ref = D.pack_records(o)
+    o2 = dict(o)
+    o2["token_idx"] = o["token_idx"].to(torch.int64)
+    o2["pred_keypoints_3d"] = o["pred_keypoints_3d"].double()
+    got = D.pack_records(o2)
+    assert got.dtype == torch.float32 and got.shape == ref.shape and torch.equal(got.view(torch.int32), ref.view(torch.int32))
+    back = D.unpack_records(got)
+    assert back["token_idx"].dtype == torch.int32 and torch.equal(back["token_idx"], o["token_idx"])
+
+
+def _worker_empty_shard_device(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seen = {}
+
+        def fwd(x):
+            seen["dev"] = x.device
+            return _fake_forward(x)
+        # 1 crop on 2 ranks: rank 1's shard is empty.  The runner is told where this rank's records live (device=...): the
+        # zero-row block must be created THERE, not wherever the (possibly host-side) batch lives.
+        runner = D.ShardedRunner(fwd, gather=True, device="cpu")
+        img = torch.randn(1, 3, 4, 4, generator=torch.Generator().manual_seed(5))
+        out = runner(img)
+        ref = D.unpack_records(D.pack_records(_fake_forward(img)))
+        q.put((rank, all(torch.equal(out[k], ref[k]) for k in ref), str(runner.device), "dev" in seen))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_empty_shard_record_lives_on_the_runner_device():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_empty_shard_device, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert res == [(0, True, "cpu", True), (1, True, "cpu", False)], res
