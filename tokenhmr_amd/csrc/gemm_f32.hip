@@ -833,6 +833,7 @@ int launch_abl(const GemmArgs& a, hipStream_t s) {
 // variant: 0 = 128x128 REG (2x2 waves of 64x64)   1 = 128x160 REG (4x1 waves of 32x160)
 //          7 = 128x128 DMA                         8 = 128x160 DMA            9 = 64x64 DMA (2x2 waves of 32x32)
 //         10 = 128x96 DMA (4x1 waves of 32x96)          11 = 32x32 tiny-M kernel (K split over 8 waves, no LDS staging)
+//         12 = 64x128 DMA (2x2 waves of 32x64)          13 = 128x64 DMA (4x1 waves of 32x64)   [round 3: measured, not in the cost model]
 //         -1 = DMA, tile picked by a cost model over 256 CUs   (2 is the skinny kernel, see thmr_op_gemm)
 int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % BK) != 0) return -1;
@@ -885,6 +886,8 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         case 8: return launch_cfg<4, 1, 1, 5, true>(a, epi, s);
         case 9: return launch_cfg<2, 2, 1, 1, true>(a, epi, s);
         case 10: return launch_cfg<4, 1, 1, 3, true>(a, epi, s);     // 128x96
+        case 12: return launch_cfg<2, 2, 1, 2, true>(a, epi, s);     // 64x128 (2x2 waves of 32x64)
+        case 13: return launch_cfg<4, 1, 1, 2, true>(a, epi, s);     // 128x64 (4x1 waves of 32x64)
         default: return launch_cfg<2, 2, 2, 2, true>(a, epi, s);
     }
 }
@@ -902,6 +905,8 @@ int launch_gemm_splitk(const GemmArgs& a0, int variant, int ksplit, float* part,
     a.ksplit = ksplit;
     a.C = part; a.ldc = a.N;
     a.bias = nullptr; a.resid = nullptr; a.ldr = 0; a.cs_out = nullptr;
+    static const int forced_tile = [] { const char* e = getenv("THMR_MID_TILE"); return e ? atoi(e) : -1; }();     // A/B knob
+    if (variant < 0 && forced_tile > 0) variant = forced_tile;
     if (variant < 0) {
         auto cost = [&](int BM, int BN, double eff) {
             const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * ksplit;
@@ -917,6 +922,8 @@ int launch_gemm_splitk(const GemmArgs& a0, int variant, int ksplit, float* part,
         case 8: return launch_cfg<4, 1, 1, 5, true>(a, EPI_NONE, s);
         case 9: return launch_cfg<2, 2, 1, 1, true>(a, EPI_NONE, s);
         case 10: return launch_cfg<4, 1, 1, 3, true>(a, EPI_NONE, s);
+        case 12: return launch_cfg<2, 2, 1, 2, true>(a, EPI_NONE, s);
+        case 13: return launch_cfg<4, 1, 1, 2, true>(a, EPI_NONE, s);
         case 7: return launch_cfg<2, 2, 2, 2, true>(a, EPI_NONE, s);
         default: return -1;
     }
