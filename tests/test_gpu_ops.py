@@ -39,7 +39,7 @@ SHAPES = [(128, 128, 32), (256, 320, 64), (384, 1280, 1280), (200, 72, 96), (130
           (384, 3840, 1280), (384, 1280, 5120), (1, 160, 64), (1344, 512, 512)]
 
 
-@pytest.mark.parametrize("variant", ["128x128", "128x160", "128x96", "64x64", "128x128reg", "128x160reg", "auto"])
+@pytest.mark.parametrize("variant", ["128x128", "128x160", "128x96", "64x64", "64x128", "128x64", "128x128reg", "128x160reg", "auto"])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_gemm_shapes(built_lib, cuda_dev, shape, variant):
     from tokenhmr_amd import ops
@@ -118,14 +118,14 @@ def test_gemm_big_tile_splitk(built_lib, cuda_dev, shape):
         if K % (32 * ks):
             continue
         outs = {}
-        for tile in ("128x128", "128x160", "128x96", "auto"):
+        for tile in ("128x128", "128x160", "128x96", "64x128", "128x64", "auto"):
             for epi in ("bias", "bias_resid"):
                 o = ops.gemm(da, dw, db, dr if epi == "bias_resid" else None, epi=epi, variant=f"{tile}/k{ks}")
                 assert torch.allclose(o.cpu(), _gemm_ref(a, w, b, r, epi, 1.0, 0), atol=3e-5, rtol=1e-5), (tile, ks, epi)
                 assert torch.equal(o, ops.gemm(da, dw, db, dr if epi == "bias_resid" else None, epi=epi, variant=f"{tile}/k{ks}"))
                 outs[(tile, epi)] = o
         for epi in ("bias", "bias_resid"):
-            for tile in ("128x160", "128x96", "auto"):
+            for tile in ("128x160", "128x96", "64x128", "128x64", "auto"):
                 assert torch.equal(outs[(tile, epi)], outs[("128x128", epi)]), (tile, ks, epi)      # tile-independent
         if M > 256:
             half = ops.gemm(da[:M // 2].contiguous(), dw, db, epi="bias", variant=f"auto/k{ks}")
@@ -225,6 +225,20 @@ def test_gemm_deterministic(built_lib, cuda_dev):
     from tokenhmr_amd import ops
     a, w = _rand(384, 1280, seed=1).to(cuda_dev), _rand(1280, 1280, seed=2, scale=0.03).to(cuda_dev)
     assert torch.equal(ops.gemm(a, w), ops.gemm(a, w))
+
+
+def test_gemm_result_does_not_depend_on_the_tile(built_lib, cuda_dev):
+    """Every LDS-DMA tile (and the auto-selector, whatever it picks) sums K in the same order: the tile is a scheduling choice only.
+    The engine relies on it — a crop's bits must not change with the tile its batch size selects (7-8 crops: 64x128 on the N = 1280
+    GEMMs, 17+ crops: 128x128 / 128x160)."""
+    from tokenhmr_amd import ops
+    for (M, N, K), epi in (((1536, 1280, 5120), "bias_resid"), ((1344, 1280, 1280), "bias_resid"), ((1536, 3840, 1280), "bias_qscale"),
+                           ((530, 200, 96), "bias_gelu")):
+        a, w, b, r = _rand(M, K, seed=1).to(cuda_dev), _rand(N, K, seed=2, scale=1 / math.sqrt(K)).to(cuda_dev), _rand(N, seed=3).to(cuda_dev), _rand(M, N, seed=4).to(cuda_dev)
+        kw = dict(epi=epi, qscale=80 ** -0.5, qcols=N // 3) if epi == "bias_qscale" else dict(epi=epi)
+        ref = ops.gemm(a, w, b, r if epi == "bias_resid" else None, variant="128x160", **kw)
+        for v in ("128x128", "128x96", "64x64", "64x128", "128x64", "auto"):
+            assert torch.equal(ops.gemm(a, w, b, r if epi == "bias_resid" else None, variant=v, **kw), ref), (M, N, K, v)
 
 
 @pytest.mark.parametrize("rows,D,eps,relu", [(384, 1280, 1e-6, False), (7, 1280, 1e-6, False), (64, 1024, 1e-5, False),

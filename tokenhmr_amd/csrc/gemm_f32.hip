@@ -833,7 +833,7 @@ int launch_abl(const GemmArgs& a, hipStream_t s) {
 // variant: 0 = 128x128 REG (2x2 waves of 64x64)   1 = 128x160 REG (4x1 waves of 32x160)
 //          7 = 128x128 DMA                         8 = 128x160 DMA            9 = 64x64 DMA (2x2 waves of 32x32)
 //         10 = 128x96 DMA (4x1 waves of 32x96)          11 = 32x32 tiny-M kernel (K split over 8 waves, no LDS staging)
-//         12 = 64x128 DMA (2x2 waves of 32x64)          13 = 128x64 DMA (4x1 waves of 32x64)   [round 3: measured, not in the cost model]
+//         12 = 64x128 DMA (2x2 waves of 32x64)          13 = 128x64 DMA (4x1 waves of 32x64)   [round 3]
 //         -1 = DMA, tile picked by a cost model over 256 CUs   (2 is the skinny kernel, see thmr_op_gemm)
 int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % BK) != 0) return -1;
@@ -855,11 +855,19 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         if (c7 < best) { best = c7; variant = 7; }
         if (c10 < best) { best = c10; variant = 10; }
         if (c9 < best) { best = c9; variant = 9; }
+        // 64x128 / 128x64 (round 3): between the 64x64 tile (0.82 of the big tiles' per-area rate with two blocks per CU) and 128x96.
+        // They win exactly where measured (profiles/r3f_n1280_tile_sweep.log): the N = 1280 GEMMs at 7 and 8 crops, 210-240 tiles
+        // that run one per CU — proj 48.6 -> 46.5 us, fc2 171.6 -> 161.8 us at 8 crops.  Only for grids beyond the ring kernel's range.
+        const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+        if (tiles64 > 256 && a.M > 1152) {
+            const double c12 = cost(64, 128, 0.97), c13 = cost(128, 64, 0.97);
+            if (c12 < best) { best = c12; variant = 12; }
+            if (c13 < best) { best = c13; variant = 13; }
+        }
         // at most one 64x64 block per CU: nothing hides the 2-buffer kernel's per-K-tile memory round trip, so the 4-deep
         // ring version of the same tile is used (same K order, bit-identical; measured 46 -> ~30 us on the head's B = 1 convs).
         // NOT beyond 256 tiles: with two blocks per CU the 2-buffer kernel is the faster one (fc2 at 8 crops, 480 tiles: 176 us
         // against 229 us on the ring kernel — a threshold of 512 was tried in round 2 and cost B = 8 11 %, profiles/r2ad_batch_sweep.jsonl)
-        const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
         static const long ring_max_tiles = [] { const char* e = getenv("THMR_RING_MAX_TILES"); return e ? atol(e) : 256L; }();   // A/B knob
         if (variant == 9 && tiles64 <= ring_max_tiles && epi != EPI_BIAS_POS) return launch_ring<4>(a, epi, 1, nullptr, s);
     }
