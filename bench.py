@@ -48,6 +48,10 @@ def parse(argv=None):
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--fake-engine", action="store_true", help="CPU dry run of the N-rank orchestration (with --backend gloo)")
     ap.add_argument("--self-launch", action="store_true", help="re-exec under torch.distributed.run even at --gpus 1")
+    ap.add_argument("--single-device", action="store_true",
+                    help="TEST ONLY (with --backend gloo): every rank builds its real engine on cuda:0, so the N > 1 orchestration — "
+                         "rank 0 loads, broadcast, receivers finalize, sharded forward, gather, cross-rank check — runs with real "
+                         "engines on a one-GPU box; `value` is meaningless (the ranks time-slice one GPU)")
     return ap.parse_args(argv)
 
 
@@ -260,7 +264,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cpu") if cpu_dry else torch.device("cuda", local_rank)
+    if a.single_device and a.backend != "gloo":
+        sys.exit("--single-device stacks the ranks on one GPU, which RCCL refuses: use it with --backend gloo")
+    dev_index = 0 if a.single_device else local_rank
+    dev = torch.device("cpu") if cpu_dry else torch.device("cuda", dev_index)
     if not cpu_dry:
         torch.cuda.set_device(dev)
 
@@ -286,12 +293,12 @@ def main():
              "uuid": None if cpu_dry else str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")) or None,
              "host": socket.gethostname()}
     if not cpu_dry:
-        assert torch.cuda.current_device() == local_rank, f"rank {rank}: current device {torch.cuda.current_device()} != LOCAL_RANK {local_rank}"
+        assert torch.cuda.current_device() == dev_index, f"rank {rank}: current device {torch.cuda.current_device()} != LOCAL_RANK {local_rank}"
     idents = [ident]
     if use_dist:
         idents = [None] * world
         dist.all_gather_object(idents, ident)
-        if not cpu_dry:
+        if not cpu_dry and not a.single_device:
             devs = [(i["host"], i["device"]) for i in idents]
             assert len(set(devs)) == world, f"ranks share a GPU: {devs}"
     if cpu_dry:
@@ -428,7 +435,7 @@ def main():
         rec = last["records"]
         mine = D.pack_records(last["out"])
         gathered_ok = bool(rec.shape[0] == total_batch and torch.equal(rec[crop0:crop0 + B], mine))
-        t = torch.tensor([1.0 if gathered_ok else 0.0], device=dev)
+        t = torch.tensor([1.0 if gathered_ok else 0.0], device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         gathered_ok = bool(t.item() == 1.0)
         if rank == 0 and world > 1 and not a.no_extras:
@@ -450,7 +457,7 @@ def main():
                      "how": "rank 0 recomputed every other rank's seeded shard on its own engine and compared the gathered records"}
     rank_step = None
     if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # per-rank view of the timed region, so that a slow first 8-GPU run diagnoses itself: median step time on each rank's
@@ -584,6 +591,8 @@ def main():
             line["build"] = build_info
         if cpu_dry:
             line["dry_run"] = "fake engine on CPU tensors: orchestration only, `value` is meaningless"
+        if a.single_device:
+            line["dry_run"] = "--single-device: real engines, all ranks time-slicing cuda:0 over gloo: orchestration + cross-rank check only, `value` is meaningless"
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
             line["gpu_over_cpu_b1"] = round(value / cpu["value_b1"], 1)

@@ -91,24 +91,45 @@ def unpack_records(rec):
     return out
 
 
+def _gloo_with_gpu_tensor(t) -> bool:
+    """The gloo backend moves host memory; GPU tensors are staged through the host here (RCCL absent, or — what this exists for
+    in this repo — two ranks on ONE GPU: RCCL refuses duplicate devices, gloo does not, so the N > 1 code path can run with real
+    engines on a one-GPU box: bench.py --single-device, tests/test_bench_cli.py)."""
+    return dist.is_initialized() and dist.get_backend() == "gloo" and t.is_cuda
+
+
 def broadcast_weights(engine, src: int = 0):
     """ONE collective for the whole model: rank `src` has loaded the checkpoint; everyone else
     receives the packed arena and only has to finalize."""
-    if dist.is_initialized():
-        dist.broadcast(engine.weight_arena, src=src)
+    if not dist.is_initialized():
+        return
+    arena = engine.weight_arena
+    if not _gloo_with_gpu_tensor(arena):
+        dist.broadcast(arena, src=src)
+        return
+    chunk = 256 << 20                                        # bound the host staging buffer
+    flat = arena.view(-1)
+    for off in range(0, flat.numel(), chunk):
+        part = flat[off:off + chunk]
+        host = part.cpu() if dist.get_rank() == src else torch.empty(part.numel(), dtype=part.dtype)
+        dist.broadcast(host, src=src)
+        if dist.get_rank() != src:
+            part.copy_(host)
 
 
 class GatherHandle:
     """An all-gather in flight on the process group's own (RCCL) stream.  wait() makes the CURRENT stream wait for it (no host
     block) and returns the (total, RECORD_WORDS) records in crop order."""
 
-    def __init__(self, work, buf, sizes, mx):
-        self.work, self.buf, self.sizes, self.mx = work, buf, sizes, mx
+    def __init__(self, work, buf, sizes, mx, device=None):
+        self.work, self.buf, self.sizes, self.mx, self.device = work, buf, sizes, mx, device
 
     def wait(self):
         if self.work is not None:
             self.work.wait()
             self.work = None
+        if self.device is not None and self.buf.device != self.device:      # gloo with GPU records: gathered on the host
+            self.buf = self.buf.to(self.device)
         if all(s == self.mx for s in self.sizes):
             return self.buf                                  # equal shards: the gathered buffer IS the result (no copy)
         return torch.cat([self.buf[r * self.mx: r * self.mx + s] for r, s in enumerate(self.sizes)], dim=0)
@@ -128,9 +149,12 @@ def all_gather_records(local_rec, total: int, async_op: bool = False):
     if local_rec.shape[0] < mx:
         pad = torch.zeros(mx, local_rec.shape[1], dtype=local_rec.dtype, device=local_rec.device)
         pad[: local_rec.shape[0]] = local_rec
-    buf = torch.empty(world * mx, local_rec.shape[1], dtype=local_rec.dtype, device=local_rec.device)
+    dev = local_rec.device
+    if _gloo_with_gpu_tensor(local_rec):
+        pad = pad.cpu()                                      # staged through the host (see _gloo_with_gpu_tensor)
+    buf = torch.empty(world * mx, local_rec.shape[1], dtype=local_rec.dtype, device=pad.device)
     work = dist.all_gather_into_tensor(buf, pad.contiguous(), async_op=True)
-    h = GatherHandle(work, buf, sizes, mx)
+    h = GatherHandle(work, buf, sizes, mx, device=dev)
     return h if async_op else h.wait()
 
 
