@@ -222,10 +222,10 @@ def lbs_at_b512(dev, smpl):
     R = torch.linalg.qr(torch.randn(B * 24, 3, 3, generator=g))[0]
     R = (R * torch.linalg.det(R).sign()[:, None, None]).reshape(B, 24, 3, 3).to(dev)
     betas = torch.randn(B, 10, generator=g).to(dev)
-    for _ in range(3):
+    for _ in range(20):
         m(R[:, :1], R[:, 1:], betas, pose2rot=False)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 20
+    n = 100
     e0.record()
     for _ in range(n):
         m(R[:, :1], R[:, 1:], betas, pose2rot=False)

@@ -35,11 +35,11 @@ constexpr float VIT_EPS = 1e-6f, LN_EPS = 1e-5f;
 constexpr float FOCAL = 5000.0f, IMG = 256.0f;
 // small-batch ViT path (gemm_ring_kernel): used while M = 192*B <= kSmallM; crossovers measured in profiles/r1_small_gemm_variants.log
 constexpr int kSmallM = 1152, kSplitKMax = 4;     // B <= 6
-// mid-size batches: from 9 to 16 crops proj / fc2 (N = 1280: 135-240 output tiles of 128x128 on 512 resident slots) run split-K 2
-// on the big LDS-DMA tiles (measured per batch size and per GEMM, profiles/r3d_mid_batch_splitk_sweep.log: -10 % per call at 9
-// and 10 crops, -2.5 ... -3.7 % at 11 ... 16; below 9 and from 17 on the unsplit launch is the faster one, and 4 ways never beats 2).
-// That range is its own regime of the K sum; 7-8 crops and >= 17 crops share the unsplit arithmetic.
-constexpr int kMidLoM = 9 * 192, kMidHiM = 16 * 192, kMidSplit = 2;
+// mid-size batches: from 7 to 16 crops proj / fc2 (N = 1280: 110-240 output tiles of 128x128 on 512 resident slots) run split-K 2
+// on the big LDS-DMA tiles (measured per batch size and per GEMM, profiles/r3d_mid_batch_splitk_sweep.log, r3f_mid_batch_forced_tile.log:
+// -10 % per call at 9 and 10 crops, -2.5 ... -3.7 % at 11 ... 16, -2 % at 7 and 8 with the 64x128 tile; from 17 on the unsplit launch
+// is the faster one, and 4 ways never beats 2).  That range is its own regime of the K sum.
+constexpr int kMidLoM = 7 * 192, kMidHiM = 16 * 192, kMidSplit = 2;
 // decoder + mixer stack: the persistent decoder kernel and the one-workgroup-per-crop mixer kernel win while the work is
 // latency-bound (B = 1: 0.96 vs 1.01 ms, B = 64: 1.58 vs 1.93 ms per head); from a few hundred crops on the same products are
 // real GEMMs (M = B and M = 160 B rows) and the tiled MFMA kernels win (B = 512: 6.7 vs 7.5 ms) — profiles/r2e_head_fused_vs_chain.log
@@ -414,7 +414,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
     // one split factor for the whole regime, so a crop's result does not depend on how many crops share its batch (B <= 6)
     const int ks_proj = kSplitKMax, ks_fc2 = kSplitKMax;
     float* part = e->S(e->so.part);
-    // mid-size batches (9 ... 16 crops): proj / fc2 split K two ways on the big tiles, reduced by the same residual + LayerNorm
+    // mid-size batches (7 ... 16 crops): proj / fc2 split K two ways on the big tiles, reduced by the same residual + LayerNorm
     // kernel; ONE factor for the whole range and both GEMMs, so a crop's result does not depend on the batch it rides in within it
     auto pick = [&](int forced, int rule) {
         int sp = small ? 1 : forced >= 0 ? (forced > 1 ? forced : 1) : rule;

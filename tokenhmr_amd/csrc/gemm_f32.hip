@@ -855,15 +855,11 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         if (c7 < best) { best = c7; variant = 7; }
         if (c10 < best) { best = c10; variant = 10; }
         if (c9 < best) { best = c9; variant = 9; }
-        // 64x128 / 128x64 (round 3): between the 64x64 tile (0.82 of the big tiles' per-area rate with two blocks per CU) and 128x96.
-        // They win exactly where measured (profiles/r3f_n1280_tile_sweep.log): the N = 1280 GEMMs at 7 and 8 crops, 210-240 tiles
-        // that run one per CU — proj 48.6 -> 46.5 us, fc2 171.6 -> 161.8 us at 8 crops.  Only for grids beyond the ring kernel's range.
+        // (64x128 / 128x64, variants 12 / 13, were tried here in round 3: on the N = 1280 GEMMs at 7-8 crops they make 210-240 tiles
+        // that run ONE per CU.  Stand-alone with warm weights that looked 4-6 % faster than 480 tiles of 64x64; in the pipeline, with
+        // the weights streamed cold from HBM, a block that is alone on its CU pays a memory round trip per K tile and the call got
+        // 7 % SLOWER — profiles/r3f_n1280_tile_sweep.log vs r3g_mid_batch_tiles_in_cost_model.log.  They serve the split-K launcher.)
         const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-        if (tiles64 > 256 && a.M > 1152) {
-            const double c12 = cost(64, 128, 0.97), c13 = cost(128, 64, 0.97);
-            if (c12 < best) { best = c12; variant = 12; }
-            if (c13 < best) { best = c13; variant = 13; }
-        }
         // at most one 64x64 block per CU: nothing hides the 2-buffer kernel's per-K-tile memory round trip, so the 4-deep
         // ring version of the same tile is used (same K order, bit-identical; measured 46 -> ~30 us on the head's B = 1 convs).
         // NOT beyond 256 tiles: with two blocks per CU the 2-buffer kernel is the faster one (fc2 at 8 crops, 480 tiles: 176 us
@@ -916,15 +912,19 @@ int launch_gemm_splitk(const GemmArgs& a0, int variant, int ksplit, float* part,
     static const int forced_tile = [] { const char* e = getenv("THMR_MID_TILE"); return e ? atoi(e) : -1; }();     // A/B knob
     if (variant < 0 && forced_tile > 0) variant = forced_tile;
     if (variant < 0) {
+        // as launch_gemm's model, plus: a grid of at most 256 blocks runs one block per CU, where nothing hides the 2-buffer
+        // pipeline's memory round trip per K tile (weights come cold from HBM in the pipeline): +10 %; and the 64x128 tile
+        // (0.95), which turns the 210-240 tiles of 7-8 crops into 420-480 co-resident pairs
         auto cost = [&](int BM, int BN, double eff) {
             const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * ksplit;
-            return (double)((tiles + 255) / 256) * BM * BN / eff;
+            return (double)((tiles + 255) / 256) * BM * BN / eff * (tiles <= 256 ? 1.1 : 1.0);
         };
-        const double c7 = cost(128, 128, 0.99), c8 = cost(128, 160, 1.0), c10 = cost(128, 96, 0.985);
+        const double c7 = cost(128, 128, 0.99), c8 = cost(128, 160, 1.0), c10 = cost(128, 96, 0.985), c12 = cost(64, 128, 0.95);
         variant = 8;
         double best = c8;
         if (c7 < best) { best = c7; variant = 7; }
         if (c10 < best) { best = c10; variant = 10; }
+        if (c12 < best) { best = c12; variant = 12; }
     }
     switch (variant) {
         case 8: return launch_cfg<4, 1, 1, 5, true>(a, EPI_NONE, s);
