@@ -133,6 +133,16 @@ class _Gadget:
         return (os.system, ("echo pwned > /tmp/thmr_pickle_gadget",))
 
 
+class _NumpyGadget:                      # a FUNCTION of an allowed module (numpy) that is not an array-reconstruction helper
+    def __reduce__(self):
+        return (np.load, ("/tmp/thmr_does_not_exist.npy",))
+
+
+class _TorchGadget:                      # torch.hub / torch.load-style entry points are not tensor rebuild helpers either
+    def __reduce__(self):
+        return (torch.hub.load, ("someone/repo", "model"))
+
+
 def test_restricted_unpickler_never_resolves_code(tmp_path):
     """The reference's torch.load un-pickles arbitrary globals; this loader cannot: anything that is not a tensor / array /
     plain container becomes inert data."""
@@ -140,9 +150,15 @@ def test_restricted_unpickler_never_resolves_code(tmp_path):
     marker = "/tmp/thmr_pickle_gadget"
     if os.path.exists(marker):
         os.remove(marker)
-    torch.save({"state_dict": {"w": torch.ones(2)}, "evil": _Gadget(), "getattr": getattr, "eval": eval}, tmp_path / "evil.ckpt")
+    torch.save({"state_dict": {"w": torch.ones(2)}, "evil": _Gadget(), "getattr": getattr, "eval": eval, "np": _NumpyGadget(),
+                "hub": _TorchGadget(), "ok_np": np.float32(1.5), "ok_arr": np.eye(2), "ok_dtype": np.dtype("int16"), "ok_size": torch.Size([2, 3]),
+                "ok_tdtype": torch.bfloat16}, tmp_path / "evil.ckpt")
     c = ckpt_io.load_checkpoint(str(tmp_path / "evil.ckpt"))
     assert not os.path.exists(marker)
+    assert isinstance(c["np"], ckpt_io.InertNode) and c["np"]._inert_origin == ("numpy", "load")
+    assert isinstance(c["hub"], ckpt_io.InertNode) and c["hub"]._inert_origin[0] == "torch.hub"
+    assert float(c["ok_np"]) == 1.5 and np.array_equal(c["ok_arr"], np.eye(2)) and c["ok_dtype"] == np.dtype("int16")
+    assert c["ok_size"] == torch.Size([2, 3]) and c["ok_tdtype"] is torch.bfloat16
     assert isinstance(c["evil"], ckpt_io.InertNode) and c["evil"]._inert_args[0] == ("echo pwned > /tmp/thmr_pickle_gadget",)
     assert issubclass(c["getattr"], ckpt_io.InertNode) and issubclass(c["eval"], ckpt_io.InertNode)
     assert torch.equal(c["state_dict"]["w"], torch.ones(2))

@@ -26,9 +26,23 @@ import warnings
 
 import torch
 
-# modules whose globals are resolved for real (everything a tensor archive legitimately needs)
-_REAL_PREFIXES = ("torch._utils", "torch.storage", "torch._tensor", "torch.nn.parameter", "torch.serialization",
-                  "numpy", "collections", "_codecs", "copyreg")
+# globals that are resolved for real: exactly what a tensor archive legitimately needs, by (module, name) — never by module alone
+# (numpy.testing and torch.hub hold code-execution gadgets)
+_REAL_GLOBALS = {
+    "collections": {"OrderedDict", "defaultdict", "deque", "Counter"},
+    "_codecs": {"encode"},
+    "copyreg": {"_reconstructor", "__newobj__", "__newobj_ex__"},
+    "torch._utils": {"_rebuild_tensor", "_rebuild_tensor_v2", "_rebuild_tensor_v3", "_rebuild_parameter", "_rebuild_parameter_with_state",
+                     "_rebuild_qtensor", "_rebuild_sparse_tensor", "_rebuild_wrapper_subclass", "_rebuild_device_tensor_from_numpy",
+                     "_rebuild_meta_tensor_no_storage"},
+    "torch._tensor": {"_rebuild_from_type", "_rebuild_from_type_v2", "Tensor"},
+    "torch.nn.parameter": {"Parameter", "Buffer", "UninitializedParameter"},
+    "torch.storage": {"TypedStorage", "UntypedStorage", "_load_from_bytes"},
+    "torch.serialization": {"_get_layout"},
+}
+_NUMPY_MODULES = {"numpy", "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric", "numpy._core.numeric",
+                  "numpy.core._multiarray_umath", "numpy._core._multiarray_umath", "numpy.dtypes"}
+_NUMPY_FUNCS = {"_reconstruct", "_frombuffer", "scalar"}
 _REAL_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray",
                   "complex", "slice", "range", "object"}
 
@@ -116,11 +130,20 @@ class RestrictedUnpickler(pickle.Unpickler):
             if isinstance(obj, (type, torch.dtype)) or name.endswith("Storage"):
                 return super().find_class(module, name)
             return _stub_for(module, name)
-        if module.startswith(_REAL_PREFIXES) and (module.split(".")[0] in ("torch", "numpy", "collections", "_codecs", "copyreg")):
+        if name in _REAL_GLOBALS.get(module, ()):
             try:
                 return super().find_class(module, name)
             except (ImportError, AttributeError):
                 return _stub_for(module, name)
+        if module in _NUMPY_MODULES:
+            # array / scalar reconstruction helpers, and TYPES (ndarray, dtype, float64, dtypes.Float32DType ...) — no other numpy function
+            try:
+                obj = super().find_class(module, name)
+            except (ImportError, AttributeError):
+                return _stub_for(module, name)
+            if name in _NUMPY_FUNCS or isinstance(obj, type):
+                return obj
+            return _stub_for(module, name)
         return _stub_for(module, name)
 
 
