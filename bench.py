@@ -390,9 +390,10 @@ def main():
         step()
     join()
     sync()
-    # HIP events around the DOMINANT kernel only (fc1: the GEMM class with the largest share of every step): an event pair costs
-    # ~2-3 us of stream time — instrumenting the four GEMM classes (round 2) cost 0.75 % of a B = 64 step and 20 % of a B = 1
-    # call.  Its roofline is measured live in the timed region; the other classes come from a separate untimed pass below.
+    # HIP events around the DOMINANT kernel only (fc1: the GEMM class with the largest share of every step), every 4th of its 32
+    # launches per call (one shape): an event pair costs ~2-3 us of stream time — instrumenting the four GEMM classes (round 2)
+    # cost 0.75 % of a B = 64 step and 20 % of a B = 1 call.  Its roofline is measured live in the timed region; the other classes
+    # come from a separate untimed pass below.
     eng.prof_enable("fc1")
     gw["on"] = True
     ev = [] if cpu_dry else [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]

@@ -266,9 +266,9 @@ int thmr_allgather_records(void* nccl_comm, const float* rec_dev, int32_t rows, 
 const char* thmr_collective_last_error(void);
 
 /* Built-in profiler: HIP events recorded on the launch stream around each kernel class.
- * on = 0 off, 1 every class, 2 only the four ViT GEMM classes, 3 only fc1 (the dominant kernel).  An event pair costs ~2-3 us
+ * on = 0 off, 1 every class, 2 only the four ViT GEMM classes, 3 only fc1 (the dominant kernel), sampled.  An event pair costs ~2-3 us
  * of stream time: 128 pairs per call (on = 2) were 0.75 % of a B = 64 step and 20 % of a B = 1 call (round 3: the facade call
- * without events was FASTER than the timed loop), which is why bench.py times with on = 3 (32 pairs per call). */
+ * without events was FASTER than the timed loop), which is why bench.py times with on = 3, which samples every 4th fc1 launch (8 pairs per call; all 32 launches have one shape). */
 int thmr_prof_enable(thmr_engine* e, int32_t on);
 int thmr_prof_collect(thmr_engine* e, thmr_prof_entry* entries /*[THMR_PROF_NUM]*/, int32_t reset);
 
