@@ -194,6 +194,10 @@ int thmr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* b
                       int32_t rows, int32_t D, float eps, int32_t relu, void* stream);
 /* ViT global attention over 192 tokens, 16 heads x 80 (vit.py:113-122); qkv (B,192,3840) with q pre-scaled. */
 int thmr_op_vit_attention(const float* qkv_dev, float* out_dev /*(B,192,1280)*/, int32_t B, void* stream);
+/* the same with the kernel forced: 0 = the batch-size rule of thmr_op_vit_attention; 1 = three 64-query workgroups per (crop, head),
+ * 3 = one 192-query workgroup, 5 = persistent workgroups (1 / 3 / 5 are bit-identical); 6 = key-split (16 queries per workgroup,
+ * the 192 keys split over its 4 waves, partial softmaxes merged: what the engine uses up to six crops; equal to fp32 rounding) */
+int thmr_op_vit_attention_variant(const float* qkv_dev, float* out_dev, int32_t B, int32_t variant, void* stream);
 /* rot6d_to_rotmat (geometry.py:64-84): (n,6) -> (n,3,3) */
 int thmr_op_rot6d(const float* x_dev, float* R_dev, int32_t n, void* stream);
 /* aa_to_rotmat (geometry.py:5-44; axis-angle -> quaternion -> rotation matrix, the reference's in-tree "Rodrigues" used for

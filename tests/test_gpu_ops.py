@@ -267,6 +267,34 @@ def test_vit_attention(built_lib, cuda_dev, B):
     assert torch.allclose(out, ref, atol=5e-6, rtol=1e-5), (out - ref).abs().max()
 
 
+@pytest.mark.parametrize("B", [1, 2, 6])
+def test_vit_attention_keysplit(built_lib, cuda_dev, B):
+    """The small-batch regime's attention (16 queries per workgroup, the 192 keys split over its 4 waves, per-wave softmaxes merged
+    the flash-attention way): against fp64 with the error class of torch's own fp32, against the 64-query kernel to fp32 rounding,
+    deterministic, batch-independent, and finite on peaked scores (one dominant key per query, |scores| ~ 100: a wave whose 48 keys
+    are all far below the row maximum contributes 2^(-large) without producing inf / nan)."""
+    from tokenhmr_amd import ops
+    for scale, tol in ((1.0, 5e-6), (6.0, None)):
+        qkv = _rand(B, 192, 3840, seed=21 + B)
+        qkv[:, :, :1280] *= 80 ** -0.5
+        qkv[:, :, :2560] *= scale
+        d = qkv.to(cuda_dev)
+        out = ops.vit_attention(d, variant="keysplit")
+        assert torch.equal(out, ops.vit_attention(d, variant="keysplit"))
+        assert torch.equal(ops.vit_attention(d[:1].contiguous(), variant="keysplit"), out[:1])
+        t = qkv.reshape(B, 192, 3, 16, 80).permute(2, 0, 3, 1, 4)
+        ref32 = ((t[0] @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]).transpose(1, 2).reshape(B, 192, 1280)
+        t64 = t.double()
+        ref64 = ((t64[0] @ t64[1].transpose(-2, -1)).softmax(-1) @ t64[2]).transpose(1, 2).reshape(B, 192, 1280)
+        assert torch.isfinite(out).all()
+        err_hip = (out.cpu().double() - ref64).abs().max().item()
+        err_cpu = (ref32.double() - ref64).abs().max().item()
+        assert err_hip <= max(4 * err_cpu, 2e-5), (scale, err_hip, err_cpu)
+        other = ops.vit_attention(d, variant="q64")
+        if tol is not None:
+            assert torch.allclose(out, other, atol=tol, rtol=1e-5), (out - other).abs().max()
+
+
 def test_vit_attention_peaked(built_lib, cuda_dev):
     """Large score spread (|scores| ~ 100, one dominant key per query) exercises the max-subtraction path.
     Judged against an fp64 statement: the HIP fp32 error must be of the same class as torch's own fp32 error

@@ -525,9 +525,120 @@ __global__ __launch_bounds__(256, 2) void vit_attention_persistent_kernel(const 
     }
 }
 
+// ---- few crops (the ViT's small-batch regime, B <= 6): split the KEYS of a (crop, head, 16-query block) over the 4 waves ----
+// At one crop the kernels above have 48 workgroups, and what a workgroup takes is one wave's dependent chain: 240 MFMAs for
+// S (16 queries x 192 keys x 80) + 240 for P.V = 15,360 matrix-pipe cycles = 6.4 us, after a staging round trip — 12.5 us per
+// launch, 0.40 ms of a 4.1 ms call, with 80 % of the CUs idle.  Here a workgroup owns 16 queries of one (crop, head) and wave w
+// owns keys [48 w, 48 w + 48): 60 + 60 MFMAs per wave, 12 B workgroups per (crop, head) = 192 per crop.  No LDS staging: a K / V
+// element is used by exactly one wave, so the fragments go global -> VGPR in MFMA operand layout (16-byte loads for Q and K with the
+// k-permutation trick, dword loads for V^T), all requested before the first MFMA.  Each wave runs its own softmax over its 48 keys
+// (local max m_w, local sum l_w, un-normalised O_w); the four partial results are merged through LDS the flash-attention way,
+//   O = sum_w O_w 2^((m_w - M) log2 e) / sum_w l_w 2^((m_w - M) log2 e),   M = max_w m_w,
+// in wave order (deterministic).  The association of the key sum differs from the kernels above (to fp32 rounding), which is
+// why this variant serves the WHOLE small-batch regime or none of it (engine.hip kSmallM; the regimes' results agree to < 1e-5).
+__global__ __launch_bounds__(256) void vit_attention_keysplit_kernel(const float* __restrict__ qkv, float* __restrict__ out) {
+    constexpr int OS = 84;                                   // row stride of the partial-output tile in LDS (floats)
+    constexpr float LOG2E = 1.44269504088896340736f;
+    __shared__ __attribute__((aligned(16))) float so[4][16][OS];
+    __shared__ float sm[4][16], sl[4][16];
+    const int bh = blockIdx.x / 12, qb = blockIdx.x - bh * 12;
+    const int b = bh / NH, h = bh % NH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const float* base = qkv + (int64_t)b * NTOK * QKV_LD + h * HD;
+    const int q0 = qb * 16, k0 = wave * 48;
+    // every operand fragment of this wave, requested up front: Q (B operand of S^T = K Q^T), K (A operand), V^T (A operand of O^T = V^T P^T)
+    f32x4 qf[5], kf[3][5];
+    float vf[3][4][5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) qf[j] = *reinterpret_cast<const f32x4*>(base + (int64_t)(q0 + l15) * QKV_LD + j * 16 + g * 4);
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            kf[kt][j] = *reinterpret_cast<const f32x4*>(base + DIM + (int64_t)(k0 + kt * 16 + l15) * QKV_LD + j * 16 + g * 4);
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int dt = 0; dt < 5; ++dt)
+                vf[kt][r][dt] = base[2 * DIM + (int64_t)(k0 + kt * 16 + g * 4 + r) * QKV_LD + dt * 16 + l15];
+    __builtin_amdgcn_sched_barrier(0);       // all 80 loads are issued before the first MFMA (hipcc otherwise sinks each load to its use: 20 round trips)
+    // S^T tiles: s[kt][r] = S[q0 + l15][k0 + 16 kt + 4 g + r]
+    f32x4 s[3];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+        s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][j][t], qf[j][t], s[kt], 0, 0, 0);
+    }
+    // this wave's softmax over its 48 keys of query l15 (4 lanes x 12 registers)
+    float m = s[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float ml = m * LOG2E;
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], LOG2E, -ml));
+            l += s[kt][r];
+        }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    // O_w^T tiles: o[dt][i] = sum over this wave's keys of e * V, for d = 16 dt + 4 g + i, query l15
+    f32x4 o[5];
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int dt = 0; dt < 5; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][r][dt], s[kt][r], o[dt], 0, 0, 0);
+    if (g == 0) { sm[wave][l15] = m; sl[wave][l15] = l; }
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) *reinterpret_cast<f32x4*>(&so[wave][l15][dt * 16 + g * 4]) = o[dt];
+    __syncthreads();
+    // merge the four partial results in wave order; 16 queries x 80 = 1280 outputs, 5 per thread, consecutive threads = consecutive d
+#pragma unroll
+    for (int jj = 0; jj < 5; ++jj) {
+        const int idx = tid + jj * 256, q = idx / HD, d = idx - q * HD;
+        const float M = fmaxf(fmaxf(sm[0][q], sm[1][q]), fmaxf(sm[2][q], sm[3][q]));
+        float acc = 0.f, L = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a = __builtin_amdgcn_exp2f((sm[w][q] - M) * LOG2E);
+            acc = fmaf(so[w][q][d], a, acc);
+            L = fmaf(sl[w][q], a, L);
+        }
+        out[((int64_t)b * NTOK + q0 + q) * DIM + h * HD + d] = acc / L;
+    }
+}
+
 }  // namespace
 
-int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s) {
+int launch_vit_attention_keysplit(const float* qkv, float* out, int B, hipStream_t s) {
+    if (B <= 0) return -1;
+    hipLaunchKernelGGL(vit_attention_keysplit_kernel, dim3(B * NH * 12), dim3(256), 0, s, qkv, out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_vit_attention_variant(const float* qkv, float* out, int B, int variant, hipStream_t s);
+
+int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s) { return launch_vit_attention_variant(qkv, out, B, 0, s); }
+
+// variant 0 = the rule below (or THMR_ATTN_VARIANT); 1 / 3 / 5 / 12 / 6 force a kernel (unit tests, A/B)
+int launch_vit_attention_variant(const float* qkv, float* out, int B, int want, hipStream_t s) {
     if (B <= 0) return -1;
     // while 48*B workgroups of 64 queries still fit the 512 resident slots (2 per CU) they finish sooner than 16*B of 192
     static const int forced = [] { const char* e = getenv("THMR_ATTN_VARIANT"); return e ? atoi(e) : 0; }();   // A/B knob (scripts/)
@@ -538,8 +649,12 @@ int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s) {
     //   5 = the persistent kernel everywhere else; with at most 512 items every workgroup has one item and it is still ~3 % faster
     //       than the plain 192-query kernel (3): one copy-offset register instead of 17, no spills; above 512 items it fetches the
     //       next item under the current one.
-    const int variant = forced ? forced : ((B <= 10 || (B >= 17 && B <= 24)) ? 1 : 5);
+    //   6 = key-split (vit_attention_keysplit_kernel): another association of the key sum, A/B through the knob only here; the engine
+    //       selects it for its whole small-batch regime through launch_vit_attention_keysplit
+    const int variant = want ? want : forced ? forced : ((B <= 10 || (B >= 17 && B <= 24)) ? 1 : 5);
+    if (variant != 1 && variant != 3 && variant != 5 && variant != 6 && variant != 12) return -1;
     const AttnDbg nodbg{nullptr, 0, 0};
+    if (variant == 6) return launch_vit_attention_keysplit(qkv, out, B, s);
     if (variant == 5) {
         static const int dephase_us = [] { const char* e = getenv("THMR_ATTN_DEPHASE_US"); return e ? atoi(e) : kAttnDephaseUs; }();   // A/B knob
         const AttnDbg dph{nullptr, dephase_us * 100, 0};

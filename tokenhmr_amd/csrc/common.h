@@ -251,6 +251,8 @@ int launch_gemm_splitk(const GemmArgs& a, int variant, int ksplit, float* part, 
 int launch_gemm_ring(const GemmArgs& a, int epi, int ring, int ksplit, float* part, hipStream_t s);   // gemm_f32.hip
 int launch_gemm_skinny(const GemmArgs& a, int epi, hipStream_t s);                // gemm_skinny.hip
 int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s);     // attention.hip
+int launch_vit_attention_keysplit(const float* qkv, float* out, int B, hipStream_t s);   // few crops: keys split over the 4 waves
+int launch_vit_attention_variant(const float* qkv, float* out, int B, int variant, hipStream_t s);   // 0 = rule; 1 / 3 / 5 / 12 / 6
 // rowops.hip
 int launch_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int D, float eps, int relu,
                      hipStream_t s);

@@ -86,6 +86,7 @@ struct thmr_engine {
     bool legacy_head = false;         // THMR_LEGACY_HEAD=1: force the chain-of-GEMMs head at every batch size (A/B only)
     bool mixer_cluster = true;        // THMR_MIXER_CLUSTER=0: always run the mixer stack as its own one-workgroup-per-crop kernel (A/B only)
     bool tiny_gemm = true;            // THMR_TINY_GEMM=0: the VQ decoder's GEMMs stay on the ring kernel in the small-batch regime (A/B only)
+    bool attn_keysplit = true;        // THMR_ATTN_KEYSPLIT=0: the small-batch regime keeps the 64-query attention workgroups (A/B only)
     int mid_split_force[2] = {-1, -1};   // THMR_MID_SPLIT=<p><f> (digits 0|2|4): force the split factors of proj and fc2 above 6 crops where the partial-sum buffer allows (A/B only)
     bool smpl_loaded = false, finalized = false;
     unsigned* host_err = nullptr;     // host-mapped sticky error word of the persistent decoder kernel (hipHostMalloc)
@@ -476,7 +477,10 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         }
         {
             ProfScope ps(e, st, THMR_PROF_ATTN, 4.0 * B * HEADS * 192.0 * 192.0 * 80.0, 4.0 * (4.0 * M * DIM));
-            LAUNCH_OK(launch_vit_attention(big, h, B, st));
+            // small-batch regime: keys split over the waves of a workgroup (192 workgroups per crop instead of 48, 120 instead of 480
+            // dependent MFMAs per wave); its own association of the key sum, so it serves the whole regime or none of it
+            if (small && e->attn_keysplit) LAUNCH_OK(launch_vit_attention_keysplit(big, h, B, st));
+            else LAUNCH_OK(launch_vit_attention(big, h, B, st));
         }
         // proj + residual, then norm2 (vit.py:123,149,150)
         if (int rc = resid_linear_ln(THMR_PROF_GEMM_PROJ, h, DIM, w.pw, w.pb, ks_proj, mid_proj, w.n2w, w.n2b, h)) return rc;
@@ -907,6 +911,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* lg = getenv("THMR_LEGACY_HEAD"); e->legacy_head = lg && lg[0] == '1'; }
     { const char* mc = getenv("THMR_MIXER_CLUSTER"); e->mixer_cluster = !(mc && mc[0] == '0'); }
     { const char* tg = getenv("THMR_TINY_GEMM"); e->tiny_gemm = !(tg && tg[0] == '0'); }
+    { const char* ak = getenv("THMR_ATTN_KEYSPLIT"); e->attn_keysplit = !(ak && ak[0] == '0'); }
     { const char* ms = getenv("THMR_MID_SPLIT"); if (ms && ms[0] && ms[1]) { e->mid_split_force[0] = ms[0] - '0'; e->mid_split_force[1] = ms[1] - '0'; } }
     { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
     *out = e;
@@ -1315,6 +1320,13 @@ int thmr_op_vit_attention(const float* qkv, float* out, int32_t B, void* stream)
     thmr_engine* e = nullptr;
     if (!qkv || !out) return fail(e, THMR_ERR_INVALID, "null buffer");
     LAUNCH_OK(launch_vit_attention(qkv, out, B, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int thmr_op_vit_attention_variant(const float* qkv, float* out, int32_t B, int32_t variant, void* stream) {
+    thmr_engine* e = nullptr;
+    if (!qkv || !out) return fail(e, THMR_ERR_INVALID, "null buffer");
+    LAUNCH_OK(launch_vit_attention_variant(qkv, out, B, variant, static_cast<hipStream_t>(stream)));
     return 0;
 }
 

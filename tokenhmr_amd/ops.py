@@ -50,13 +50,19 @@ def layernorm(x, gamma, beta, eps, relu=False):
     return y
 
 
-def vit_attention(qkv):
-    """qkv (B,192,3840) with q pre-scaled -> (B,192,1280)."""
+ATTN_VARIANT = {"auto": 0, "q64": 1, "q192": 3, "persistent": 5, "q16x12": 12, "keysplit": 6}
+
+
+def vit_attention(qkv, variant="auto"):
+    """qkv (B,192,3840) with q pre-scaled -> (B,192,1280).  variant: "auto" (batch-size rule) or a forced kernel, see ATTN_VARIANT."""
     _req(qkv)
     B = qkv.shape[0]
     out = torch.empty(B, 192, 1280, device=qkv.device, dtype=torch.float32)
     with torch.cuda.device(qkv.device):
-        _cabi.check(_cabi.load().thmr_op_vit_attention(_p(qkv), _p(out), B, _s(qkv)))
+        if variant == "auto":
+            _cabi.check(_cabi.load().thmr_op_vit_attention(_p(qkv), _p(out), B, _s(qkv)))
+        else:
+            _cabi.check(_cabi.load().thmr_op_vit_attention_variant(_p(qkv), _p(out), B, ATTN_VARIANT[variant], _s(qkv)))
     return out
 
 
