@@ -196,7 +196,8 @@ int thmr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* b
 int thmr_op_vit_attention(const float* qkv_dev, float* out_dev /*(B,192,1280)*/, int32_t B, void* stream);
 /* the same with the kernel forced: 0 = the batch-size rule of thmr_op_vit_attention; 1 = three 64-query workgroups per (crop, head),
  * 3 = one 192-query workgroup, 5 = persistent workgroups (1 / 3 / 5 are bit-identical); 6 = key-split (16 queries per workgroup,
- * the 192 keys split over its 4 waves, partial softmaxes merged: what the engine uses up to six crops; equal to fp32 rounding) */
+ * the 192 keys split over its 4 waves, partial softmaxes merged: what the engine uses up to six crops; equal to fp32 rounding;
+ * 61 / 62 / 63 = the same with 16 / 32 / 48 queries per workgroup, bit-identical to each other) */
 int thmr_op_vit_attention_variant(const float* qkv_dev, float* out_dev, int32_t B, int32_t variant, void* stream);
 /* rot6d_to_rotmat (geometry.py:64-84): (n,6) -> (n,3,3) */
 int thmr_op_rot6d(const float* x_dev, float* R_dev, int32_t n, void* stream);

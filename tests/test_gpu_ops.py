@@ -282,6 +282,8 @@ def test_vit_attention_keysplit(built_lib, cuda_dev, B):
         out = ops.vit_attention(d, variant="keysplit")
         assert torch.equal(out, ops.vit_attention(d, variant="keysplit"))
         assert torch.equal(ops.vit_attention(d[:1].contiguous(), variant="keysplit"), out[:1])
+        for v in ("keysplit/q16", "keysplit/q32", "keysplit/q48"):                  # queries per workgroup: a scheduling choice only
+            assert torch.equal(ops.vit_attention(d, variant=v), out), v
         t = qkv.reshape(B, 192, 3, 16, 80).permute(2, 0, 3, 1, 4)
         ref32 = ((t[0] @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]).transpose(1, 2).reshape(B, 192, 1280)
         t64 = t.double()

@@ -536,23 +536,30 @@ __global__ __launch_bounds__(256, 2) void vit_attention_persistent_kernel(const 
 //   O = sum_w O_w 2^((m_w - M) log2 e) / sum_w l_w 2^((m_w - M) log2 e),   M = max_w m_w,
 // in wave order (deterministic).  The association of the key sum differs from the kernels above (to fp32 rounding), which is
 // why this variant serves the WHOLE small-batch regime or none of it (engine.hip kSmallM; the regimes' results agree to < 1e-5).
+// QT = 16-query tiles per workgroup (1, 2, 3): every query is computed by the same instruction sequence whatever QT, so the
+// variants are bit-identical and the choice per batch size is free.  QT = 1 has the shortest chain (one crop: 192 workgroups);
+// larger QT re-reads K / V less often (12 / QT workgroups per (crop, head) each fetch all of K and V).
+template <int QT>
 __global__ __launch_bounds__(256) void vit_attention_keysplit_kernel(const float* __restrict__ qkv, float* __restrict__ out) {
     constexpr int OS = 84;                                   // row stride of the partial-output tile in LDS (floats)
+    constexpr int QB = 12 / QT;                              // workgroups per (crop, head)
     constexpr float LOG2E = 1.44269504088896340736f;
-    __shared__ __attribute__((aligned(16))) float so[4][16][OS];
-    __shared__ float sm[4][16], sl[4][16];
-    const int bh = blockIdx.x / 12, qb = blockIdx.x - bh * 12;
+    __shared__ __attribute__((aligned(16))) float so[4][16 * QT][OS];
+    __shared__ float sm[4][16 * QT], sl[4][16 * QT];
+    const int bh = blockIdx.x / QB, qb = blockIdx.x - bh * QB;
     const int b = bh / NH, h = bh % NH;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
     const float* base = qkv + (int64_t)b * NTOK * QKV_LD + h * HD;
-    const int q0 = qb * 16, k0 = wave * 48;
+    const int q0 = qb * 16 * QT, k0 = wave * 48;
     // every operand fragment of this wave, requested up front: Q (B operand of S^T = K Q^T), K (A operand), V^T (A operand of O^T = V^T P^T)
-    f32x4 qf[5], kf[3][5];
+    f32x4 qf[QT][5], kf[3][5];
     float vf[3][4][5];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) qf[j] = *reinterpret_cast<const f32x4*>(base + (int64_t)(q0 + l15) * QKV_LD + j * 16 + g * 4);
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) qf[qt][j] = *reinterpret_cast<const f32x4*>(base + (int64_t)(q0 + qt * 16 + l15) * QKV_LD + j * 16 + g * 4);
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
@@ -565,53 +572,71 @@ __global__ __launch_bounds__(256) void vit_attention_keysplit_kernel(const float
 #pragma unroll
             for (int dt = 0; dt < 5; ++dt)
                 vf[kt][r][dt] = base[2 * DIM + (int64_t)(k0 + kt * 16 + g * 4 + r) * QKV_LD + dt * 16 + l15];
-    __builtin_amdgcn_sched_barrier(0);       // all 80 loads are issued before the first MFMA (hipcc otherwise sinks each load to its use: 20 round trips)
-    // S^T tiles: s[kt][r] = S[q0 + l15][k0 + 16 kt + 4 g + r]
-    f32x4 s[3];
+    __builtin_amdgcn_sched_barrier(0);       // all loads are issued before the first MFMA (hipcc otherwise sinks each load to its use: 20 round trips)
+    // S^T tiles: s[qt][kt][r] = S[q0 + 16 qt + l15][k0 + 16 kt + 4 g + r]
+    f32x4 s[QT][3];
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-        s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
         for (int j = 0; j < 5; ++j)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][j][t], qf[j][t], s[kt], 0, 0, 0);
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][j][t], qf[qt][j][t], s[qt][kt], 0, 0, 0);
+    // this wave's softmax over its 48 keys of each of its queries (4 lanes x 12 registers per query)
+    float m[QT], l[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float mm = s[qt][0][0];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mm = fmaxf(mm, s[qt][kt][r]);
+        mm = fmaxf(mm, __shfl_xor(mm, 16, 64));
+        mm = fmaxf(mm, __shfl_xor(mm, 32, 64));
+        const float ml = mm * LOG2E;
+        float ll = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[qt][kt][r] = __builtin_amdgcn_exp2f(fmaf(s[qt][kt][r], LOG2E, -ml));
+                ll += s[qt][kt][r];
+            }
+        ll += __shfl_xor(ll, 16, 64);
+        ll += __shfl_xor(ll, 32, 64);
+        m[qt] = mm; l[qt] = ll;
     }
-    // this wave's softmax over its 48 keys of query l15 (4 lanes x 12 registers)
-    float m = s[0][0];
+    // O_w^T tiles: o[qt][dt][i] = sum over this wave's keys of e * V, for d = 16 dt + 4 g + i, query 16 qt + l15
+    f32x4 o[QT][5];
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    const float ml = m * LOG2E;
-    float l = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            s[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], LOG2E, -ml));
-            l += s[kt][r];
-        }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    // O_w^T tiles: o[dt][i] = sum over this wave's keys of e * V, for d = 16 dt + 4 g + i, query l15
-    f32x4 o[5];
-#pragma unroll
-    for (int dt = 0; dt < 5; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < 5; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int dt = 0; dt < 5; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][r][dt], s[kt][r], o[dt], 0, 0, 0);
-    if (g == 0) { sm[wave][l15] = m; sl[wave][l15] = l; }
+            for (int dt = 0; dt < 5; ++dt)
 #pragma unroll
-    for (int dt = 0; dt < 5; ++dt) *reinterpret_cast<f32x4*>(&so[wave][l15][dt * 16 + g * 4]) = o[dt];
+                for (int qt = 0; qt < QT; ++qt)
+                    o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][r][dt], s[qt][kt][r], o[qt][dt], 0, 0, 0);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        if (g == 0) { sm[wave][qt * 16 + l15] = m[qt]; sl[wave][qt * 16 + l15] = l[qt]; }
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) *reinterpret_cast<f32x4*>(&so[wave][qt * 16 + l15][dt * 16 + g * 4]) = o[qt][dt];
+    }
     __syncthreads();
-    // merge the four partial results in wave order; 16 queries x 80 = 1280 outputs, 5 per thread, consecutive threads = consecutive d
+    // merge the four partial results in wave order; 16 QT queries x 80 outputs, 5 QT per thread, consecutive threads = consecutive d
 #pragma unroll
-    for (int jj = 0; jj < 5; ++jj) {
+    for (int jj = 0; jj < 5 * QT; ++jj) {
         const int idx = tid + jj * 256, q = idx / HD, d = idx - q * HD;
         const float M = fmaxf(fmaxf(sm[0][q], sm[1][q]), fmaxf(sm[2][q], sm[3][q]));
         float acc = 0.f, L = 0.f;
@@ -627,11 +652,18 @@ __global__ __launch_bounds__(256) void vit_attention_keysplit_kernel(const float
 
 }  // namespace
 
-int launch_vit_attention_keysplit(const float* qkv, float* out, int B, hipStream_t s) {
+int launch_vit_attention_keysplit_qt(const float* qkv, float* out, int B, int want_qt, hipStream_t s) {
     if (B <= 0) return -1;
-    hipLaunchKernelGGL(vit_attention_keysplit_kernel, dim3(B * NH * 12), dim3(256), 0, s, qkv, out);
+    // 16 / 32 / 48 queries per workgroup are bit-identical: one crop takes the shortest chain, more crops the fewer K / V re-reads
+    static const int forced_qt = [] { const char* e = getenv("THMR_ATTN_KEYSPLIT_QT"); return e ? atoi(e) : 0; }();   // A/B knob
+    const int qt = want_qt ? want_qt : forced_qt ? forced_qt : (B == 1 ? 1 : B <= 2 ? 2 : 3);
+    if (qt == 1) hipLaunchKernelGGL(vit_attention_keysplit_kernel<1>, dim3(B * NH * 12), dim3(256), 0, s, qkv, out);
+    else if (qt == 2) hipLaunchKernelGGL(vit_attention_keysplit_kernel<2>, dim3(B * NH * 6), dim3(256), 0, s, qkv, out);
+    else hipLaunchKernelGGL(vit_attention_keysplit_kernel<3>, dim3(B * NH * 4), dim3(256), 0, s, qkv, out);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+int launch_vit_attention_keysplit(const float* qkv, float* out, int B, hipStream_t s) { return launch_vit_attention_keysplit_qt(qkv, out, B, 0, s); }
 
 int launch_vit_attention_variant(const float* qkv, float* out, int B, int variant, hipStream_t s);
 
@@ -652,6 +684,7 @@ int launch_vit_attention_variant(const float* qkv, float* out, int B, int want, 
     //   6 = key-split (vit_attention_keysplit_kernel): another association of the key sum, A/B through the knob only here; the engine
     //       selects it for its whole small-batch regime through launch_vit_attention_keysplit
     const int variant = want ? want : forced ? forced : ((B <= 10 || (B >= 17 && B <= 24)) ? 1 : 5);
+    if (variant >= 61 && variant <= 63) return launch_vit_attention_keysplit_qt(qkv, out, B, variant - 60, s);     // key-split with 16 / 32 / 48 queries per workgroup
     if (variant != 1 && variant != 3 && variant != 5 && variant != 6 && variant != 12) return -1;
     const AttnDbg nodbg{nullptr, 0, 0};
     if (variant == 6) return launch_vit_attention_keysplit(qkv, out, B, s);

@@ -50,7 +50,7 @@ def layernorm(x, gamma, beta, eps, relu=False):
     return y
 
 
-ATTN_VARIANT = {"auto": 0, "q64": 1, "q192": 3, "persistent": 5, "q16x12": 12, "keysplit": 6}
+ATTN_VARIANT = {"auto": 0, "q64": 1, "q192": 3, "persistent": 5, "q16x12": 12, "keysplit": 6, "keysplit/q16": 61, "keysplit/q32": 62, "keysplit/q48": 63}
 
 
 def vit_attention(qkv, variant="auto"):
