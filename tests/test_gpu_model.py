@@ -219,8 +219,8 @@ def test_b64_tokens_vs_reference_golden(built_lib, cuda_dev):
 def test_batch_invariance_and_determinism(small):
     """Crops are independent units: a crop's outputs must not depend on its batch position or batch size,
     and two runs must agree bit for bit (deterministic reduction orders everywhere).  Bit-exact batch-size invariance
-    holds within each of the ViT's three regimes — <= 6 crops, 7 ... 16 crops, >= 17 crops: one split factor of the
-    proj / fc2 K sums each; across regimes the K summation is associated differently (test_batch_regimes_agree)."""
+    holds within each of the ViT's four regimes — 1-2 crops, 3 ... 6, 7 ... 16, >= 17: one split factor of the proj / fc2 K sums
+    and one attention association each; across regimes the K summation is associated differently (test_batch_regimes_agree)."""
     cfg, sd, tok, smpl, model = small
     img = _inputs(4, seed=3).to(model.engine.device)
     a = model({"img": img})
@@ -228,17 +228,21 @@ def test_batch_invariance_and_determinism(small):
     for k in ("pred_vertices", "pred_keypoints_3d", "pred_cam", "cls_logits"):
         assert torch.equal(a[k], b[k]), k
     assert torch.equal(a["token_idx"], b["token_idx"])
-    single = model({"img": img[2:3]})
-    assert torch.equal(single["pred_vertices"][0], a["pred_vertices"][2])
-    assert torch.equal(single["token_idx"][0], a["token_idx"][2])
-    chunked = model.__class__.forward  # chunking path: batch > max_batch
+    # one and two crops are a regime of their own (key-split attention kernel): bit-identical with each other, fp32-rounding-close to
+    # the same crop in a batch of three or more
+    single, pair, three = model({"img": img[2:3]}), model({"img": img[2:4]}), model({"img": img[1:4]})
+    assert torch.equal(single["pred_vertices"][0], pair["pred_vertices"][0]) and torch.equal(single["token_idx"][0], pair["token_idx"][0])
+    assert torch.equal(three["pred_vertices"][1], a["pred_vertices"][2]) and torch.equal(three["token_idx"][1], a["token_idx"][2])
+    assert (single["pred_vertices"][0] - a["pred_vertices"][2]).abs().max() < 2e-5
+    assert (single["cls_logits"][0] - a["cls_logits"][2]).abs().max() < 1e-4
+    # chunking path (batch > max_batch): chunks of two are calls of two crops each — the {1, 2} regime
     model.max_batch, old = 2, model.max_batch
     try:
         c = model({"img": img})
     finally:
         model.max_batch = old
-    assert torch.equal(c["pred_vertices"], a["pred_vertices"]) and torch.equal(c["token_idx"], a["token_idx"])
-    assert chunked is not None
+    assert torch.equal(c["pred_vertices"][2:4], pair["pred_vertices"]) and torch.equal(c["token_idx"][2:4], pair["token_idx"])
+    assert (c["pred_vertices"] - a["pred_vertices"]).abs().max() < 2e-5
 
 
 def test_lbs_standalone_b64(small):
@@ -353,10 +357,10 @@ def test_standalone_smpl_gt_meshes(built_lib, cuda_dev):
 
 
 def test_batch_regimes_agree(built_lib, cuda_dev):
-    """The ViT has three associations of the proj / fc2 K sums, by batch size (csrc/engine.hip kSmallM, kMidLoM, kMidHiM): B <= 6
-    (64x64 ring kernel, split-K 4, 64-query attention workgroups), 7 ... 16 (big tiles, split-K 2), and >= 17 (big tiles, unsplit).
-    The same crops must come out bit-identical within a regime whatever the batch they ride in, and fp32-rounding-close across
-    regimes."""
+    """The ViT has four regimes of the batch size (csrc/engine.hip kKeysplitMaxB, kSmallM, kMidLoM, kMidHiM): B <= 2 and 3 ... 6 (both:
+    64x64 ring kernel, split-K 4 on proj / fc2; one or two crops additionally use the key-split attention kernel, another association
+    of the key sum), 7 ... 16 (big tiles, split-K 2), >= 17 (big tiles, unsplit).  The same crops must come out bit-identical within a
+    regime whatever the batch they ride in, and fp32-rounding-close across regimes."""
     from tokenhmr_amd.config import HMRConfig
     from tokenhmr_amd.model import TokenHMR
     cfg = HMRConfig(vit_depth=3, dec_depth=2)
@@ -367,12 +371,12 @@ def test_batch_regimes_agree(built_lib, cuda_dev):
     def run(b):
         return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in model({"img": img[:b]}).items()}
     outs = {b: run(b) for b in (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16, 17, 26)}
-    for members, ref in (((1, 2, 3, 4, 5), 6), ((7, 8, 9, 12), 16), ((17,), 26)):
+    for members, ref in (((1,), 2), ((3, 4, 5), 6), ((7, 8, 9, 12), 16), ((17,), 26)):
         for b in members:
             assert torch.equal(outs[b]["pred_vertices"], outs[ref]["pred_vertices"][:b]), (b, ref)
             assert torch.equal(outs[b]["cls_logits_softmax"], outs[ref]["cls_logits_softmax"][:b]), (b, ref)
             assert torch.equal(outs[b]["token_idx"], outs[ref]["token_idx"][:b]), (b, ref)
-    for a, b in ((6, 16), (16, 26), (6, 26)):
+    for a, b in ((2, 6), (6, 16), (16, 26), (6, 26)):
         d = (outs[a]["pred_vertices"] - outs[b]["pred_vertices"][:a]).abs().max().item()
         dl = (outs[a]["cls_logits_softmax"] - outs[b]["cls_logits_softmax"][:a]).abs().max().item()
         print(f"range of {a} crops vs range of {b}: verts {d:.2e} m, softmax {dl:.2e}")

@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void vit_attention_persistent_kernel(const 
     }
 }
 
-// ---- few crops (the ViT's small-batch regime, B <= 6): split the KEYS of a (crop, head, 16-query block) over the 4 waves ----
+// ---- one or two crops: split the KEYS of a (crop, head, 16-query block) over the 4 waves ----
 // At one crop the kernels above have 48 workgroups, and what a workgroup takes is one wave's dependent chain: 240 MFMAs for
 // S (16 queries x 192 keys x 80) + 240 for P.V = 15,360 matrix-pipe cycles = 6.4 us, after a staging round trip — 12.5 us per
 // launch, 0.40 ms of a 4.1 ms call, with 80 % of the CUs idle.  Here a workgroup owns 16 queries of one (crop, head) and wave w
@@ -534,8 +534,9 @@ __global__ __launch_bounds__(256, 2) void vit_attention_persistent_kernel(const 
 // k-permutation trick, dword loads for V^T), all requested before the first MFMA.  Each wave runs its own softmax over its 48 keys
 // (local max m_w, local sum l_w, un-normalised O_w); the four partial results are merged through LDS the flash-attention way,
 //   O = sum_w O_w 2^((m_w - M) log2 e) / sum_w l_w 2^((m_w - M) log2 e),   M = max_w m_w,
-// in wave order (deterministic).  The association of the key sum differs from the kernels above (to fp32 rounding), which is
-// why this variant serves the WHOLE small-batch regime or none of it (engine.hip kSmallM; the regimes' results agree to < 1e-5).
+// in wave order (deterministic).  The association of the key sum differs from the kernels above (to fp32 rounding): the engine uses
+// it for one and two crops — its own regime (engine.hip kKeysplitMaxB; results agree with the other kernels' to < 1e-5).  From
+// three crops on it loses: 12 / QT workgroups per (crop, head) each fetch all of K and V, four times the 64-query kernel's traffic.
 // QT = 16-query tiles per workgroup (1, 2, 3): every query is computed by the same instruction sequence whatever QT, so the
 // variants are bit-identical and the choice per batch size is free.  QT = 1 has the shortest chain (one crop: 192 workgroups);
 // larger QT re-reads K / V less often (12 / QT workgroups per (crop, head) each fetch all of K and V).
@@ -656,7 +657,7 @@ int launch_vit_attention_keysplit_qt(const float* qkv, float* out, int B, int wa
     if (B <= 0) return -1;
     // 16 / 32 / 48 queries per workgroup are bit-identical: one crop takes the shortest chain, more crops the fewer K / V re-reads
     static const int forced_qt = [] { const char* e = getenv("THMR_ATTN_KEYSPLIT_QT"); return e ? atoi(e) : 0; }();   // A/B knob
-    const int qt = want_qt ? want_qt : forced_qt ? forced_qt : (B == 1 ? 1 : B <= 2 ? 2 : 3);
+    const int qt = want_qt ? want_qt : forced_qt ? forced_qt : (B == 1 ? 1 : B <= 2 ? 2 : 3);      // measured: profiles/r3j_attention_keysplit_ab.log
     if (qt == 1) hipLaunchKernelGGL(vit_attention_keysplit_kernel<1>, dim3(B * NH * 12), dim3(256), 0, s, qkv, out);
     else if (qt == 2) hipLaunchKernelGGL(vit_attention_keysplit_kernel<2>, dim3(B * NH * 6), dim3(256), 0, s, qkv, out);
     else hipLaunchKernelGGL(vit_attention_keysplit_kernel<3>, dim3(B * NH * 4), dim3(256), 0, s, qkv, out);

@@ -35,6 +35,7 @@ constexpr float VIT_EPS = 1e-6f, LN_EPS = 1e-5f;
 constexpr float FOCAL = 5000.0f, IMG = 256.0f;
 // small-batch ViT path (gemm_ring_kernel): used while M = 192*B <= kSmallM; crossovers measured in profiles/r1_small_gemm_variants.log
 constexpr int kSmallM = 1152, kSplitKMax = 4;     // B <= 6
+constexpr int kKeysplitMaxB = 2;                  // key-split attention kernel: one and two crops
 // mid-size batches: from 7 to 16 crops proj / fc2 (N = 1280: 110-240 output tiles of 128x128 on 512 resident slots) run split-K 2
 // on the big LDS-DMA tiles (measured per batch size and per GEMM, profiles/r3d_mid_batch_splitk_sweep.log, r3f_mid_batch_forced_tile.log:
 // -10 % per call at 9 and 10 crops, -2.5 ... -3.7 % at 11 ... 16, -2 % at 7 and 8 with the 64x128 tile; from 17 on the unsplit launch
@@ -86,7 +87,7 @@ struct thmr_engine {
     bool legacy_head = false;         // THMR_LEGACY_HEAD=1: force the chain-of-GEMMs head at every batch size (A/B only)
     bool mixer_cluster = true;        // THMR_MIXER_CLUSTER=0: always run the mixer stack as its own one-workgroup-per-crop kernel (A/B only)
     bool tiny_gemm = true;            // THMR_TINY_GEMM=0: the VQ decoder's GEMMs stay on the ring kernel in the small-batch regime (A/B only)
-    bool attn_keysplit = true;        // THMR_ATTN_KEYSPLIT=0: the small-batch regime keeps the 64-query attention workgroups (A/B only)
+    bool attn_keysplit = true;        // THMR_ATTN_KEYSPLIT=0: one and two crops keep the 64-query attention workgroups (A/B only)
     int mid_split_force[2] = {-1, -1};   // THMR_MID_SPLIT=<p><f> (digits 0|2|4): force the split factors of proj and fc2 above 6 crops where the partial-sum buffer allows (A/B only)
     bool smpl_loaded = false, finalized = false;
     unsigned* host_err = nullptr;     // host-mapped sticky error word of the persistent decoder kernel (hipHostMalloc)
@@ -477,9 +478,11 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         }
         {
             ProfScope ps(e, st, THMR_PROF_ATTN, 4.0 * B * HEADS * 192.0 * 192.0 * 80.0, 4.0 * (4.0 * M * DIM));
-            // small-batch regime: keys split over the waves of a workgroup (192 workgroups per crop instead of 48, 120 instead of 480
-            // dependent MFMAs per wave); its own association of the key sum, so it serves the whole regime or none of it
-            if (small && e->attn_keysplit) LAUNCH_OK(launch_vit_attention_keysplit(big, h, B, st));
+            // one or two crops: keys split over the waves of a workgroup (192 / 96 workgroups per crop instead of 48, 120 / 240 instead
+            // of 480 dependent MFMAs per wave): -3.9 % per call at one crop, -1 % at two, slower from three on, where its four-fold
+            // re-reads of K / V cost more than the shorter chain saves (profiles/r3j_attention_keysplit_ab.log).  Its own association of
+            // the key sum, hence its own regime {1, 2} inside the small-batch regime.
+            if (B <= kKeysplitMaxB && e->attn_keysplit) LAUNCH_OK(launch_vit_attention_keysplit(big, h, B, st));
             else LAUNCH_OK(launch_vit_attention(big, h, B, st));
         }
         // proj + residual, then norm2 (vit.py:123,149,150)
