@@ -49,6 +49,7 @@ struct GridSync {
     unsigned base;      // sync[1] at kernel start
     unsigned n;         // barriers passed so far
     unsigned* host_err; // host-mapped copy of the sticky error word (may be null): the host sees a timeout without a D2H copy
+    int a2a;            // 1: all-to-all form — every workgroup polls every arrival flag itself (one memory round trip less)
 };
 
 // `pf` runs after this wave's stores have drained and before it waits: the place to request what the NEXT stage needs and does not
@@ -65,6 +66,28 @@ __device__ __forceinline__ bool grid_barrier(GridSync& gs, int tid, volatile int
     if (tid == 0) {
         __hip_atomic_store(&gs.w[256 + blockIdx.x], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_ok = 1;
+    }
+    if (gs.a2a) {
+        // Round 3: all-to-all.  The two-hop form below costs flag store -> workgroup 0's poll -> release store -> everybody's poll
+        // = two device-scope round trips (~0.85 us each, scripts/micro/xcd_handoff.hip) + two stores; here every workgroup polls
+        // the G arrival flags itself (thread t polls flag t: one 4-line load per poll and workgroup): one round trip.
+        __syncthreads();                                            // s_ok initialised
+        if (tid < G) {
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(&gs.w[256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > LIMIT) { *s_ok = 0; break; }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (*s_ok == 0) {
+                __hip_atomic_store(&gs.w[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (gs.host_err) __hip_atomic_store(gs.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else if (__hip_atomic_load(&gs.w[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) *s_ok = 0;   // somebody else gave up
+        }
+        __syncthreads();
+        return *s_ok != 0;
     }
     if (blockIdx.x == 0) {
         __syncthreads();                                            // s_ok initialised
@@ -482,7 +505,7 @@ __global__ __launch_bounds__(NWAVE * 64) void decoder_persistent_kernel(DecParam
     const int tid = threadIdx.x;
     if (tid == 0) s_base = __hip_atomic_load(&p.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    GridSync gs{p.sync, s_base, 0, p.host_err};
+    GridSync gs{p.sync, s_base, 0, p.host_err, p.barrier_a2a};
     bool ok = true;
     if (p.debug_fail && blockIdx.x == 0 && tid == 0) {      // tests only: exercise the host's recovery path without a real timeout
         __hip_atomic_store(&gs.w[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

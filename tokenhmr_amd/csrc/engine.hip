@@ -1051,6 +1051,7 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
         d.depth = e->dec_depth; d.B = 0;
         { const char* tl = getenv("THMR_DEC_TIMELINE"); d.timeline = tl && tl[0] == '1'; }
         { const char* ft = getenv("THMR_DEC_FORCE_TIMEOUT"); d.debug_fail = ft && ft[0] == '1'; }
+        { const char* bm = getenv("THMR_DEC_BARRIER"); d.barrier_a2a = !(bm && bm[0] == '0'); }
         {
             // never more workgroups than can be resident at once (occupancy query x CUs): the grid barrier depends on it
             const int nb = decoder_max_coresident_blocks(e->cfg.device);
