@@ -225,7 +225,7 @@ struct DecParams {
     int depth, B;
     int timeline;                                     // 1: workgroup 0 stamps the wall clock into sync[16..] (diagnostics)
     int debug_fail;                                   // 1 (THMR_DEC_FORCE_TIMEOUT=1, tests only): report a barrier timeout although none happened
-    int barrier_a2a;                                  // 1: all-to-all grid barrier (THMR_DEC_BARRIER=0 selects the two-hop form, A/B)
+    int barrier_a2a;                                  // 1: all-to-all grid barrier (THMR_DEC_BARRIER=1, A/B only: measured slower than the two-hop form)
     int max_blocks;                                   // compute units of the device: at most one workgroup per CU is launched
     // Distributed MLP-Mixer tail (decoder_fused.hip mixer_cluster_stage): with mixer_cluster = 10 / 5 / 2 the kernel also runs the
     // mixer stack, that many workgroups per crop (1 / 2 / 5 of the ten 16-token tiles each), and the separate mixer_stack_kernel

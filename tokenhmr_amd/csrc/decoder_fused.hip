@@ -68,9 +68,10 @@ __device__ __forceinline__ bool grid_barrier(GridSync& gs, int tid, volatile int
         *s_ok = 1;
     }
     if (gs.a2a) {
-        // Round 3: all-to-all.  The two-hop form below costs flag store -> workgroup 0's poll -> release store -> everybody's poll
-        // = two device-scope round trips (~0.85 us each, scripts/micro/xcd_handoff.hip) + two stores; here every workgroup polls
-        // the G arrival flags itself (thread t polls flag t: one 4-line load per poll and workgroup): one round trip.
+        // Round 3 experiment (THMR_DEC_BARRIER=1), NOT the default: all-to-all.  The two-hop form below costs flag store -> workgroup 0's
+        // poll -> release store -> everybody's poll = two device-scope round trips (~0.85 us each, scripts/micro/xcd_handoff.hip);
+        // here every workgroup polls the G arrival flags itself (thread t polls flag t): one round trip on paper, but G workgroups x G
+        // polling threads contend on the flag lines — barriers 3-5 us instead of 2-3.2, head 0.711 vs 0.664 ms at one crop.
         __syncthreads();                                            // s_ok initialised
         if (tid < G) {
             unsigned spins = 0;

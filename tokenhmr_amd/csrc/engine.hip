@@ -1051,7 +1051,9 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
         d.depth = e->dec_depth; d.B = 0;
         { const char* tl = getenv("THMR_DEC_TIMELINE"); d.timeline = tl && tl[0] == '1'; }
         { const char* ft = getenv("THMR_DEC_FORCE_TIMEOUT"); d.debug_fail = ft && ft[0] == '1'; }
-        { const char* bm = getenv("THMR_DEC_BARRIER"); d.barrier_a2a = !(bm && bm[0] == '0'); }
+        // all-to-all barrier: measured SLOWER (head 0.711 vs 0.664 ms at one crop, 2.87-2.90 vs 2.81-2.82 at 64: 128-256 workgroups x
+        // 128-256 device-scope polls contend; profiles/r3k_decoder_barrier_all_to_all_ab.log) — kept behind the knob only
+        { const char* bm = getenv("THMR_DEC_BARRIER"); d.barrier_a2a = bm && bm[0] == '1'; }
         {
             // never more workgroups than can be resident at once (occupancy query x CUs): the grid barrier depends on it
             const int nb = decoder_max_coresident_blocks(e->cfg.device);
