@@ -185,8 +185,9 @@ int thmr_vq_decode(thmr_engine* e, const float* probs_dev, int32_t B, float* pos
  * elements, multiples of 4, < 2^22.  variant: -1 = tile picked by the cost model (what the engine uses); 7 / 8 / 10 / 9 = the
  * 128x128 / 128x160 / 128x96 / 64x64 LDS-DMA tiles; 0 / 1 register-staged 128x128 / 128x160 (A/B only); 2 skinny (M <= 64);
  * 100 + j (110 + j) = 64x64 ring kernel, 4- (8-) deep, split-K 2^j; 11 = tiny-M kernel (32x32 tiles, K split over the 8 waves of a
- * workgroup; K % 256 == 0; epilogues 0-5; what the engine uses for the VQ decoder up to six crops).  Every variant sums K in the
- * same order except split-K and the tiny-M kernel. */
+ * workgroup; K % 256 == 0; epilogues 0-5; what the engine uses for the VQ decoder up to six crops); 120 = small-M kernel on 16x16x4
+ * tiles (64x48 workgroup tile; epilogues 0-3, 5; the engine's qkv at one and two crops); 200 + t / 400 + t = split-K 2 / 4 on big tile t.
+ * Every variant sums K in the same order except split-K, the tiny-M kernel and variant 120. */
 int thmr_op_gemm(const float* A_dev, int64_t lda, const float* W_dev, const float* bias_dev, const float* resid_dev,
                  float* C_dev, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi, float qscale, int32_t qcols,
                  int32_t variant, void* stream);

@@ -139,6 +139,31 @@ def test_gemm_big_tile_splitk_rejects(built_lib, cuda_dev):
         ops.gemm(a, w, variant="128x128/k2")          # 96 % 64 != 0
 
 
+RING16_SHAPES = [(192, 3840, 1280), (384, 3840, 1280), (64, 48, 32), (64, 48, 96), (200, 100, 512), (37, 31, 1024), (130, 1280, 256), (576, 5120, 1280)]
+
+
+@pytest.mark.parametrize("shape", RING16_SHAPES)
+def test_gemm_ring16(built_lib, cuda_dev, shape):
+    """Small-M kernel on 16x16x4 MFMA tiles (64 x 48 workgroup tile; the engine's qkv at one and two crops): every epilogue it has
+    against fp64, K tiles fewer than the ring is deep, ragged M / N edges (partial 64-row and 48-column tiles, the uneven 4 / 4 / 3 / 3
+    split of the copies), determinism and batch-independence of a row's result."""
+    from tokenhmr_amd import ops
+    M, N, K = shape
+    a, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(N, seed=3)
+    da, dw, db = a.to(cuda_dev), w.to(cuda_dev), b.to(cuda_dev)
+    for epi, kw in (("none", {}), ("bias", {}), ("bias_gelu", {}), ("bias_relu", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
+        out = ops.gemm(da, dw, None if epi == "none" else db, epi=epi, variant="ring16", **kw)
+        ref = _gemm_ref(a, w, b, None, epi, kw.get("qscale", 1.0), kw.get("qcols", 0))
+        assert torch.allclose(out.cpu(), ref, atol=3e-5, rtol=1e-5), (epi, (out.cpu() - ref).abs().max())
+        assert torch.equal(out, ops.gemm(da, dw, None if epi == "none" else db, epi=epi, variant="ring16", **kw))
+    full = ops.gemm(da, dw, db, epi="bias", variant="ring16")
+    for m in (1, M // 2, M - 1):
+        if m >= 1:
+            assert torch.equal(ops.gemm(da[:m].contiguous(), dw, db, epi="bias", variant="ring16"), full[:m]), m
+    close = ops.gemm(da, dw, db, epi="bias", variant="128x160")
+    assert torch.allclose(full, close, atol=2e-5, rtol=1e-5)                         # another order of the K sum, same value to fp32 rounding
+
+
 TINY_SHAPES = [(21, 512, 1536), (160, 512, 768), (160, 256, 2048), (126, 6, 1536), (960, 512, 1536), (55, 512, 512), (37, 31, 256)]
 
 

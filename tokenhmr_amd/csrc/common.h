@@ -250,6 +250,7 @@ int launch_gemm_splitk(const GemmArgs& a, int variant, int ksplit, float* part, 
 // small-M path: 64x64 tiles, `ring`-deep LDS-DMA ring (4 or 8), optional split-K into part[ksplit][M][N] (epilogue then
 // applied by launch_splitk_epilogue / launch_splitk_resid_ln)
 int launch_gemm_ring(const GemmArgs& a, int epi, int ring, int ksplit, float* part, hipStream_t s);   // gemm_f32.hip
+int launch_gemm_ring16(const GemmArgs& a, int epi, hipStream_t s);                // gemm_f32.hip: small M on 16x16x4 tiles (64 x 48)
 int launch_gemm_skinny(const GemmArgs& a, int epi, hipStream_t s);                // gemm_skinny.hip
 int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s);     // attention.hip
 int launch_vit_attention_keysplit(const float* qkv, float* out, int B, hipStream_t s);   // few crops: keys split over the 4 waves

@@ -87,6 +87,7 @@ struct thmr_engine {
     bool legacy_head = false;         // THMR_LEGACY_HEAD=1: force the chain-of-GEMMs head at every batch size (A/B only)
     bool mixer_cluster = true;        // THMR_MIXER_CLUSTER=0: always run the mixer stack as its own one-workgroup-per-crop kernel (A/B only)
     bool tiny_gemm = true;            // THMR_TINY_GEMM=0: the VQ decoder's GEMMs stay on the ring kernel in the small-batch regime (A/B only)
+    bool qkv_ring16 = true;           // THMR_QKV_RING16=0: one and two crops keep the 64x64 ring kernel for qkv (A/B only)
     bool attn_keysplit = true;        // THMR_ATTN_KEYSPLIT=0: one and two crops keep the 64-query attention workgroups (A/B only)
     int mid_split_force[2] = {-1, -1};   // THMR_MID_SPLIT=<p><f> (digits 0|2|4): force the split factors of proj and fc2 above 6 crops where the partial-sum buffer allows (A/B only)
     bool smpl_loaded = false, finalized = false;
@@ -473,7 +474,10 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             ProfScope ps(e, st, THMR_PROF_GEMM_QKV, 2.0 * M * DIM * 3.0 * DIM, 4.0 * ((double)M * DIM + 3.0 * DIM * DIM + 3.0 * M * DIM));
             GemmArgs a = mk(h, DIM, w.qkvw, DIM, w.qkvb, nullptr, 0, big, 3 * DIM, M, 3 * DIM, DIM);
             a.qscale = qscale; a.qcols = DIM;
-            if (ring_wide) LAUNCH_OK(launch_gemm_ring(a, EPI_BIAS_QSCALE, 4, 1, nullptr, st));
+            // one and two crops: 64 x 48 tiles of 16x16x4 MFMAs (240 / 480 workgroups whose waves walk 12.8 us chains) instead of 64x64
+            // tiles of 32x32x2 (180 / 360 workgroups, 17.1 us chains); another order of the K sum, hence tied to that regime
+            if (B <= kKeysplitMaxB && e->qkv_ring16) LAUNCH_OK(launch_gemm_ring16(a, EPI_BIAS_QSCALE, st));
+            else if (ring_wide) LAUNCH_OK(launch_gemm_ring(a, EPI_BIAS_QSCALE, 4, 1, nullptr, st));
             else LAUNCH_OK(launch_gemm(a, EPI_BIAS_QSCALE, -1, st));
         }
         {
@@ -914,6 +918,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* lg = getenv("THMR_LEGACY_HEAD"); e->legacy_head = lg && lg[0] == '1'; }
     { const char* mc = getenv("THMR_MIXER_CLUSTER"); e->mixer_cluster = !(mc && mc[0] == '0'); }
     { const char* tg = getenv("THMR_TINY_GEMM"); e->tiny_gemm = !(tg && tg[0] == '0'); }
+    { const char* qr = getenv("THMR_QKV_RING16"); e->qkv_ring16 = !(qr && qr[0] == '0'); }
     { const char* ak = getenv("THMR_ATTN_KEYSPLIT"); e->attn_keysplit = !(ak && ak[0] == '0'); }
     { const char* ms = getenv("THMR_MID_SPLIT"); if (ms && ms[0] && ms[1]) { e->mid_split_force[0] = ms[0] - '0'; e->mid_split_force[1] = ms[1] - '0'; } }
     { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
@@ -1306,6 +1311,9 @@ int thmr_op_gemm(const float* A, int64_t lda, const float* W, const float* bias,
         }
         LAUNCH_OK(launch_gemm_splitk(a, tile == 0 ? -1 : tile, ksplit, slot.first, st));
         LAUNCH_OK(launch_splitk_epilogue(a, epi, slot.first, ksplit, st));
+    } else if (variant == 120) {
+        if (epi == EPI_BIAS_POS || epi == EPI_BIAS_RESID) return fail(e, THMR_ERR_INVALID, "ring16 GEMM: epilogues none / bias / gelu / relu / qscale only");
+        LAUNCH_OK(launch_gemm_ring16(a, epi, st));
     } else if (variant == 2) {
         LAUNCH_OK(launch_gemm_skinny(a, epi, st));
     } else {

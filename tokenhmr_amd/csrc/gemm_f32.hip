@@ -694,6 +694,144 @@ int launch_ring(const GemmArgs& a, int epi, int ksplit, float* part, hipStream_t
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Small-M GEMM on 16x16x4 MFMA tiles, for the QKV projection of one and two crops (round 3).
+// The ring kernel above gives the (192, 3840) x 1280 product of one crop 3 x 60 = 180 workgroups = 720 waves for 1024 SIMDs, and a
+// wave's 32x32 tile is ONE dependent chain of 640 MFMAs of 64 cycles = 17.1 us of the launch's 25 us.  With v_mfma_f32_16x16x4_f32
+// (the same 64 flop per cycle) the tile granularity is 16: a workgroup tile of 64 x 48 (4 waves stacked in M, each 16 rows x three
+// 16x16 column tiles) makes 3 x 80 = 240 workgroups = 960 waves, each with 40 K tiles x 24 MFMAs x 32 cycles = 12.8 us.
+// Same staging as the ring kernel (ST-deep LDS ring fed by global_load_lds in the saddr form, identical swizzled LDS image,
+// vmcnt-tracked completion, one barrier per K tile in the middle of its MFMAs); the 14 copies of a K tile (8 for A, 6 for W) are
+// dealt 4 / 4 / 3 / 3 to the waves, so the vmcnt bookkeeping is instantiated for both counts behind a wave-uniform branch.
+// K is summed in a different order than by the 32x32x2 kernels (per 16-k group: MFMA t adds k0 + t, k0 + 4 + t, k0 + 8 + t,
+// k0 + 12 + t), so it serves a layer at EVERY batch size of a regime or not at all: the engine uses it for qkv in its
+// one-and-two-crop regime (kKeysplitMaxB).
+template <int ST, int EPI>
+__global__ __launch_bounds__(256) void gemm_ring16_kernel(GemmArgs a, int tiles_m, int tiles_n) {
+    constexpr int BM = 64, BN = 48;
+    static_assert((ST & (ST - 1)) == 0 && ST >= 4, "ring depth must be a power of two >= 4");
+    __shared__ __attribute__((aligned(16))) float smem[ST * (BM + BN) * LDK];
+    float* As = smem;                       // [ST][BM][LDK]
+    float* Bs = smem + ST * BM * LDK;       // [ST][BN][LDK]
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int gl = within / tiles_m, tile_m = within - gl * tiles_m;
+    const int tile_n = gl * 8 + xcd;
+    if (tile_n >= tiles_n) return;
+    const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+    const int nk = a.K / BK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const bool two_w = wave < 2;            // waves 0, 1 also copy W rows 32 .. 47
+
+    uint32_t Aoff[2], Woff[2];
+    const char* Abase = reinterpret_cast<const char*>(a.A + (int64_t)bm0 * a.lda);
+    const char* Wbase = reinterpret_cast<const char*>(a.W + (int64_t)bn0 * a.ldw);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = (wave + 4 * p) * 8 + (lane >> 3), cs = (lane & 7) ^ ((row >> 1) & 7);
+        Aoff[p] = ((uint32_t)(min(bm0 + row, a.M - 1) - bm0) * (uint32_t)a.lda + (uint32_t)cs * 4u) * 4u;
+        Woff[p] = ((uint32_t)(min(bn0 + min(row, BN - 1), a.N - 1) - bn0) * (uint32_t)a.ldw + (uint32_t)cs * 4u) * 4u;
+    }
+    auto dma_tile = [&](int kt, auto stc) {      // K tile kt -> ring slot stc (an integral constant)
+        const int st = stc;
+        const int64_t k0b = (int64_t)kt * (BK * 4);
+        dma16_saddr(Abase + k0b, Aoff[0], lds_addr(As + (st * BM + wave * 8) * LDK));
+        dma16_saddr(Abase + k0b, Aoff[1], lds_addr(As + (st * BM + (wave + 4) * 8) * LDK));
+        dma16_saddr(Wbase + k0b, Woff[0], lds_addr(Bs + (st * BN + wave * 8) * LDK));
+        if (two_w) dma16_saddr(Wbase + k0b, Woff[1], lds_addr(Bs + (st * BN + (wave + 4) * 8) * LDK));
+    };
+
+    f32x4 acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment of k-group j2 (16 k): lane (row l15, k slot g) reads the 16 bytes at logical slot 4 j2 + g of its row; the swizzle term
+    // (row >> 1) & 7 only depends on l15 because the row tiles start at multiples of 16
+    int koff[2];
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) koff[j2] = (((4 * j2 + g) ^ ((l15 >> 1) & 7)) << 2);
+    f32x4 af[2], bf[2][3];
+    auto read_frags = [&](auto stc, int j2, int slot) {
+        const int st = stc;
+        af[slot] = *reinterpret_cast<const f32x4*>(As + (st * BM + 16 * wave + l15) * LDK + koff[j2]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bf[slot][c] = *reinterpret_cast<const f32x4*>(Bs + (st * BN + 16 * c + l15) * LDK + koff[j2]);
+    };
+    // one k-group = 12 MFMAs: the first, then the fragment reads of the NEXT group, then the other eleven (order pinned as in the ring kernel)
+    auto group = [&](int slot, auto nxt) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[slot][0], bf[slot][0][0], acc[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        nxt();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (t != 0 || c != 0) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[slot][t], bf[slot][c][t], acc[c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto run = [&](auto npc) {              // NPW = copies per K tile of THIS wave (4 or 3): the vmcnt immediates depend on it
+        constexpr int NPW = decltype(npc){};
+        static_for<ST - 1>([&](auto t) {
+            if (t < nk) dma_tile(t, t);
+        });
+        if (nk >= ST - 1) wait_vm_barrier<(ST - 2) * NPW>(); else wait_vm_barrier<0>();
+        read_frags(IntC<0>{}, 0, 0);
+        auto tile = [&](int kt, auto stc, bool last) {      // stc = kt % ST; `last` is a literal at every call site
+            constexpr int S = decltype(stc){};
+            group(0, [&] { read_frags(stc, 1, 1); });
+            if (!last) {
+                // tile kt+1 landed (in-order completion); after the barrier every wave is past tile kt-1, whose slot receives tile kt+ST-1
+                if (kt + ST - 2 < nk) wait_vm_barrier<(ST - 3) * NPW>(); else wait_vm_barrier<0>();
+                if (kt + ST - 1 < nk) dma_tile(kt + ST - 1, IntC<(S + ST - 1) % ST>{});
+            }
+            group(1, [&] { if (!last) read_frags(IntC<(S + 1) % ST>{}, 0, 0); });
+        };
+        int kt = 0;
+        for (; kt + ST <= nk - 1; kt += ST) static_for<ST>([&](auto sc) { tile(kt + sc, sc, false); });
+        static_for<ST>([&](auto sc) {
+            if (kt + sc < nk - 1) tile(kt + sc, sc, false);
+        });
+        static_for<ST>([&](auto sc) {
+            if (((nk - 1) & (ST - 1)) == sc) tile(nk - 1, sc, true);
+        });
+    };
+    if (two_w) run(IntC<4>{}); else run(IntC<3>{});
+
+    // C/D layout of 16x16: col = lane & 15, row = 4 * (lane >> 4) + i
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int n = bn0 + 16 * c + l15;
+        if (n >= a.N) continue;
+        float bias = 0.f;
+        if constexpr (EPI != EPI_NONE) bias = a.bias[n];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = bm0 + 16 * wave + 4 * g + i;
+            if (m >= a.M) continue;
+            float v = acc[c][i] + bias;
+            if constexpr (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+            if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+            if constexpr (EPI == EPI_BIAS_QSCALE) v = (n < a.qcols) ? v * a.qscale : v;
+            a.C[(int64_t)m * a.ldc + n] = v;
+        }
+    }
+}
+
+int launch_ring16(const GemmArgs& a, int epi, hipStream_t s) {
+    const int tiles_m = (a.M + 63) / 64, tiles_n = (a.N + 47) / 48;
+    dim3 grid(8 * tiles_m * ((tiles_n + 7) / 8)), block(256);
+    switch (epi) {
+        case EPI_NONE: hipLaunchKernelGGL((gemm_ring16_kernel<4, EPI_NONE>), grid, block, 0, s, a, tiles_m, tiles_n); break;
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_ring16_kernel<4, EPI_BIAS>), grid, block, 0, s, a, tiles_m, tiles_n); break;
+        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_ring16_kernel<4, EPI_BIAS_GELU>), grid, block, 0, s, a, tiles_m, tiles_n); break;
+        case EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_ring16_kernel<4, EPI_BIAS_RELU>), grid, block, 0, s, a, tiles_m, tiles_n); break;
+        case EPI_BIAS_QSCALE: hipLaunchKernelGGL((gemm_ring16_kernel<4, EPI_BIAS_QSCALE>), grid, block, 0, s, a, tiles_m, tiles_n); break;
+        default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Tiny-M GEMM for the head's dependent chain at up to six crops (soft codebook lookup + the VQ decoder's Conv1d GEMMs: M = 21 ... 160
 // rows per crop, N = 256 / 512, K = 512 ... 2048).  The ring kernel above gives such a product 8-24 workgroups that each walk the
 // WHOLE K: 24-64 K tiles at ~0.5 us = 12-32 us per launch, 13 launches in a row = a third of the head at one crop
@@ -935,6 +1073,13 @@ int launch_gemm_splitk(const GemmArgs& a0, int variant, int ksplit, float* part,
         case 7: return launch_cfg<2, 2, 2, 2, true>(a, EPI_NONE, s);
         default: return -1;
     }
+}
+
+// small-M GEMM on 16x16x4 tiles (64 x 48 workgroup tile); epilogues none / bias / gelu / relu / qscale
+int launch_gemm_ring16(const GemmArgs& a, int epi, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % BK) != 0) return -1;
+    if ((a.lda % 4) != 0 || (a.ldw % 4) != 0 || a.lda >= (1 << 22) || a.ldw >= (1 << 22)) return -1;
+    return launch_ring16(a, epi, s);
 }
 
 // ring = 4 | 8 (LDS ring depth: 64 KB -> 2 blocks/CU, 128 KB -> 1 block/CU with twice the prefetch distance);

@@ -7,7 +7,7 @@ import torch
 from . import _cabi
 
 EPI = {"none": 0, "bias": 1, "bias_gelu": 2, "bias_relu": 3, "bias_resid": 4, "bias_qscale": 5, "bias_pos": 6}
-VARIANT = {"auto": -1, "128x128reg": 0, "128x160reg": 1, "skinny": 2, "128x128": 7, "128x160": 8, "64x64": 9, "128x96": 10, "tiny": 11, "64x128": 12, "128x64": 13}
+VARIANT = {"auto": -1, "128x128reg": 0, "128x160reg": 1, "skinny": 2, "128x128": 7, "128x160": 8, "64x64": 9, "128x96": 10, "tiny": 11, "64x128": 12, "128x64": 13, "ring16": 120}
 # small-M ring kernel: "ring4" / "ring8" = LDS ring depth, optional "/k<S>" = split-K factor (1, 2, 4, 8, 16)
 VARIANT.update({f"ring{r}" + (f"/k{1 << j}" if j else ""): 100 + (10 if r == 8 else 0) + j for r in (4, 8) for j in range(5)})
 # split-K on the big LDS-DMA tiles (mid-size batches): "<tile>/k2", "<tile>/k4", "auto/k2", "auto/k4"
