@@ -817,18 +817,27 @@ __global__ __launch_bounds__(256) void gemm_ring16_kernel(GemmArgs a, int tiles_
     }
 }
 
-int launch_ring16(const GemmArgs& a, int epi, hipStream_t s) {
+template <int ST>
+int launch_ring16_st(const GemmArgs& a, int epi, hipStream_t s) {
     const int tiles_m = (a.M + 63) / 64, tiles_n = (a.N + 47) / 48;
     dim3 grid(8 * tiles_m * ((tiles_n + 7) / 8)), block(256);
     switch (epi) {
-        case EPI_NONE: hipLaunchKernelGGL((gemm_ring16_kernel<4, EPI_NONE>), grid, block, 0, s, a, tiles_m, tiles_n); break;
-        case EPI_BIAS: hipLaunchKernelGGL((gemm_ring16_kernel<4, EPI_BIAS>), grid, block, 0, s, a, tiles_m, tiles_n); break;
-        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_ring16_kernel<4, EPI_BIAS_GELU>), grid, block, 0, s, a, tiles_m, tiles_n); break;
-        case EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_ring16_kernel<4, EPI_BIAS_RELU>), grid, block, 0, s, a, tiles_m, tiles_n); break;
-        case EPI_BIAS_QSCALE: hipLaunchKernelGGL((gemm_ring16_kernel<4, EPI_BIAS_QSCALE>), grid, block, 0, s, a, tiles_m, tiles_n); break;
+        case EPI_NONE: hipLaunchKernelGGL((gemm_ring16_kernel<ST, EPI_NONE>), grid, block, 0, s, a, tiles_m, tiles_n); break;
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_ring16_kernel<ST, EPI_BIAS>), grid, block, 0, s, a, tiles_m, tiles_n); break;
+        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_ring16_kernel<ST, EPI_BIAS_GELU>), grid, block, 0, s, a, tiles_m, tiles_n); break;
+        case EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_ring16_kernel<ST, EPI_BIAS_RELU>), grid, block, 0, s, a, tiles_m, tiles_n); break;
+        case EPI_BIAS_QSCALE: hipLaunchKernelGGL((gemm_ring16_kernel<ST, EPI_BIAS_QSCALE>), grid, block, 0, s, a, tiles_m, tiles_n); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ring depth: a K tile is only 24 MFMAs x 32 cycles = 0.32 us of matrix work per wave, so 3 tiles in flight (ST = 4) cover less than
+// one HBM round trip; ST = 8 (112 KB of LDS, one workgroup per CU — there is at most one per CU up to one crop anyway) covers 2.2 us.
+// Same arithmetic, bit-identical (THMR_RING16_DEPTH=4|8 for A/B).
+int launch_ring16(const GemmArgs& a, int epi, hipStream_t s) {
+    static const int depth = [] { const char* e = getenv("THMR_RING16_DEPTH"); return e ? atoi(e) : 8; }();
+    return depth == 4 ? launch_ring16_st<4>(a, epi, s) : launch_ring16_st<8>(a, epi, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
