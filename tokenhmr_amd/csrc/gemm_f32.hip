@@ -832,12 +832,13 @@ int launch_ring16_st(const GemmArgs& a, int epi, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-// ring depth: a K tile is only 24 MFMAs x 32 cycles = 0.32 us of matrix work per wave, so 3 tiles in flight (ST = 4) cover less than
-// one HBM round trip; ST = 8 (112 KB of LDS, one workgroup per CU — there is at most one per CU up to one crop anyway) covers 2.2 us.
-// Same arithmetic, bit-identical (THMR_RING16_DEPTH=4|8 for A/B).
+// ring depth: a K tile is only 24 MFMAs x 32 cycles = 0.32 us of matrix work per wave, so the 3 tiles in flight of ST = 4 cover less
+// than one HBM round trip; ST = 8 (112 KB of LDS) covers 2.2 us but allows ONE workgroup per CU: measured -0.3 % per call at one crop
+// (240 workgroups) and +4 % at two (480 workgroups want two per CU), profiles/r3m_ring16_depth_ab.log — ST = 4 it is
+// (THMR_RING16_DEPTH=8 for A/B; same arithmetic, bit-identical).
 int launch_ring16(const GemmArgs& a, int epi, hipStream_t s) {
-    static const int depth = [] { const char* e = getenv("THMR_RING16_DEPTH"); return e ? atoi(e) : 8; }();
-    return depth == 4 ? launch_ring16_st<4>(a, epi, s) : launch_ring16_st<8>(a, epi, s);
+    static const int depth = [] { const char* e = getenv("THMR_RING16_DEPTH"); return e ? atoi(e) : 4; }();
+    return depth == 8 ? launch_ring16_st<8>(a, epi, s) : launch_ring16_st<4>(a, epi, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
