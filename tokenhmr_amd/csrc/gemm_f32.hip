@@ -993,9 +993,13 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         // although 512 blocks are resident.  Since the K loops carry no VALU work all tiles have nearly the same per-area
         // efficiency (fitted on profiles/r1_tile_sweep.log: B = 7 ... 64 on the four ViT shapes) and the choice is mostly tile
         // quantisation; small grids (the VQ decoder's M = B*21 convs) end up on the 64x64 tile.
+        // Round 3: a grid of at most 256 blocks runs ONE block per CU, where nothing hides the 2-buffer pipeline's memory round trip per
+        // K tile once the weights come cold from HBM (in the pipeline they always do): such grids carry a penalty (THMR_ALONE_PENALTY,
+        // default 1.1; measured on qkv / fc1 at 3-5 crops, profiles/r3o_alone_penalty_ab.log).
+        static const double alone = [] { const char* e = getenv("THMR_ALONE_PENALTY"); return e ? atof(e) : 1.1; }();
         auto cost = [&](int BM, int BN, double eff) {
             const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-            return (double)((tiles + 255) / 256) * BM * BN / eff;
+            return (double)((tiles + 255) / 256) * BM * BN / eff * (tiles <= 256 ? alone : 1.0);
         };
         const double c7 = cost(128, 128, 0.99), c8 = cost(128, 160, 1.0), c9 = cost(64, 64, 0.95), c10 = cost(128, 96, 0.985);
         variant = 8;
