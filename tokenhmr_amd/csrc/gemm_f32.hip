@@ -993,10 +993,11 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         // although 512 blocks are resident.  Since the K loops carry no VALU work all tiles have nearly the same per-area
         // efficiency (fitted on profiles/r1_tile_sweep.log: B = 7 ... 64 on the four ViT shapes) and the choice is mostly tile
         // quantisation; small grids (the VQ decoder's M = B*21 convs) end up on the 64x64 tile.
-        // Round 3: a grid of at most 256 blocks runs ONE block per CU, where nothing hides the 2-buffer pipeline's memory round trip per
-        // K tile once the weights come cold from HBM (in the pipeline they always do): such grids carry a penalty (THMR_ALONE_PENALTY,
-        // default 1.1; measured on qkv / fc1 at 3-5 crops, profiles/r3o_alone_penalty_ab.log).
-        static const double alone = [] { const char* e = getenv("THMR_ALONE_PENALTY"); return e ? atof(e) : 1.1; }();
+        // Round 3 experiment (THMR_ALONE_PENALTY, default 1.0 = off): a penalty for grids of at most 256 blocks (one block per CU, where
+        // nothing hides the 2-buffer pipeline's memory round trip per K tile).  It is right for the split-K launcher below, but as a
+        // general rule it is wrong: 1.1 gains 1.6 % per call at 3 crops and LOSES 3 % at 5-6 and 9 % at 20 crops (fc2's 240 tiles of
+        // 128x160 with their 160-tile K loops are the best choice there) — profiles/r3o_alone_penalty_ab.log.
+        static const double alone = [] { const char* e = getenv("THMR_ALONE_PENALTY"); return e ? atof(e) : 1.0; }();
         auto cost = [&](int BM, int BN, double eff) {
             const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
             return (double)((tiles + 255) / 256) * BM * BN / eff * (tiles <= 256 ? alone : 1.0);
