@@ -166,6 +166,21 @@ def test_yaml_cfg_reader(tmp_path):
     assert cfg.MODEL.IMAGE_SIZE == 256 and cfg.MODEL.BACKBONE.TYPE == "vit"
     assert cfg.MODEL.SMPL_HEAD.TRANSFORMER_DECODER.depth == 6
     assert cfg.MODEL.get("BBOX_SHAPE", None) is None
+    # what the reference's callers do with the yacs node (lib/models/__init__.py:9-23, eval.py:119, demo.py:85): membership, mapping
+    # access, assignment, defrost / freeze, dict(), and the defaults get_config merges the file into (lib/configs/__init__.py:15-62)
+    assert "BBOX_SHAPE" not in cfg.MODEL and cfg["MODEL"]["IMAGE_SIZE"] == 256 and cfg.EXTRA.FOCAL_LENGTH == 5000
+    assert cfg.DATASETS.CONFIG.SCALE_FACTOR == 0.3 and cfg.GENERAL.NUM_WORKERS == 4 and cfg.get("ckpt_path", None) is None
+    cfg.defrost()
+    cfg.ckpt_path = "x.ckpt"
+    cfg.MODEL.BBOX_SHAPE = [192, 256]
+    cfg.freeze()
+    assert cfg.get("ckpt_path") == "x.ckpt" and cfg.MODEL.BBOX_SHAPE == [192, 256]
+    assert {k.lower(): v for k, v in dict(cfg.SMPL).items()} == {"gender": "neutral"}
+    with pytest.raises(AttributeError):
+        cfg.MODEL.NOPE
+    c2 = cfg.clone()
+    c2.MODEL.IMAGE_SIZE = 1
+    assert cfg.MODEL.IMAGE_SIZE == 256
 
 
 def test_load_tokenhmr_missing_checkpoint(tmp_path):

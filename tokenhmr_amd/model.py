@@ -128,19 +128,71 @@ def _cat_outputs(outs):
 
 
 # ------------------------------------------------------------------------------------------------
-def _read_yaml_cfg(path):
-    """model_config.yaml reader without yacs (absent offline): nested dict -> attribute namespace."""
+class ConfigNode(dict):
+    """What the callers do with the yacs CfgNode that `get_config` returns (tokenhmr/lib/configs/__init__.py:87-103), without yacs:
+    attribute AND mapping access (`cfg.MODEL.IMAGE_SIZE`, `'BBOX_SHAPE' in cfg.MODEL`, `cfg.get('ckpt_path')`, `dict(cfg.SMPL)` at
+    eval.py:119), assignment (`cfg.ckpt_path = ...`, lib/models/__init__.py:12), and `defrost()` / `freeze()` / `clone()` as no-op-ish
+    calls (`:9,23`)."""
+
+    def __init__(self, d=None):
+        super().__init__()
+        for k, v in (d or {}).items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, ConfigNode(v) if isinstance(v, dict) and not isinstance(v, ConfigNode) else v)
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def defrost(self):
+        return self
+
+    def freeze(self):
+        return self
+
+    def clone(self):
+        import copy
+        return copy.deepcopy(self)
+
+    def merge(self, other):
+        for k, v in other.items():
+            if isinstance(v, dict) and isinstance(self.get(k), ConfigNode):
+                self[k].merge(v)
+            else:
+                self[k] = v
+        return self
+
+
+# the defaults `get_config` merges the file into (tokenhmr/lib/configs/__init__.py:15-62): data, not code
+_REFERENCE_DEFAULTS = {
+    "GENERAL": {"RESUME": True, "TIME_TO_RUN": 3300, "VAL_STEPS": 100, "LOG_STEPS": 100, "CHECKPOINT_STEPS": 20000,
+                "CHECKPOINT_DIR": "checkpoints", "SUMMARY_DIR": "tensorboard", "NUM_GPUS": 1, "NUM_WORKERS": 4, "MIXED_PRECISION": True,
+                "ALLOW_CUDA": True, "PIN_MEMORY": False, "DISTRIBUTED": False, "LOCAL_RANK": 0, "USE_SYNCBN": False, "WORLD_SIZE": 1},
+    "TRAIN": {"NUM_EPOCHS": 100, "BATCH_SIZE": 32, "SHUFFLE": True, "WARMUP": False, "NORMALIZE_PER_IMAGE": False, "CLIP_GRAD": False,
+              "CLIP_GRAD_VALUE": 1.0},
+    "LOSS_WEIGHTS": {},
+    "DATASETS": {"CONFIG": {"SCALE_FACTOR": 0.3, "ROT_FACTOR": 30, "TRANS_FACTOR": 0.02, "COLOR_SCALE": 0.2, "ROT_AUG_RATE": 0.6,
+                            "TRANS_AUG_RATE": 0.5, "DO_FLIP": True, "FLIP_AUG_RATE": 0.5, "EXTREME_CROP_AUG_RATE": 0.10}},
+    "MODEL": {"IMAGE_SIZE": 224},
+    "EXTRA": {"FOCAL_LENGTH": 5000},
+}
+
+
+def _read_yaml_cfg(path, merge=True):
+    """model_config.yaml reader without yacs (absent offline): the reference's defaults with the file merged in, as `get_config(path)`
+    does, returned as a ConfigNode."""
     import yaml
-
-    def ns(d):
-        if isinstance(d, dict):
-            n = types.SimpleNamespace(**{k: ns(v) for k, v in d.items()})
-            n.get = lambda key, default=None, _d=d: ns(_d.get(key, default)) if isinstance(_d.get(key, default), dict) else _d.get(key, default)
-            return n
-        return d
-
+    cfg = ConfigNode(_REFERENCE_DEFAULTS if merge else {})
     with open(path) as f:
-        return ns(yaml.safe_load(f)), yaml
+        cfg.merge(yaml.safe_load(f) or {})
+    return cfg, yaml
 
 
 def load_tokenhmr(checkpoint_path="", model_cfg="", dataset_dir="", is_train_state=False, is_demo=False,
@@ -177,13 +229,13 @@ def read_reference_files(checkpoint_path="", model_cfg="", dataset_dir="", is_tr
     if getattr(cfg.MODEL.SMPL_HEAD, "TYPE", "token") != "token":
         raise ValueError("Unknown SMPL head type for this engine: only 'token' (tokenhmr_release.yaml:65)")
     assert cfg.MODEL.IMAGE_SIZE == 256, f"MODEL.IMAGE_SIZE ({cfg.MODEL.IMAGE_SIZE}) should be 256 for ViT backbone"
-    if not hasattr(cfg.MODEL, "BBOX_SHAPE"):
+    if "BBOX_SHAPE" not in cfg.MODEL:
         cfg.MODEL.BBOX_SHAPE = [192, 256]
     if dataset_dir != "":
         cfg.DATASETS.DATASET_DIR = dataset_dir
     if not os.path.exists(checkpoint_path):
         raise FileNotFoundError(f"Missing full pretrained model from {checkpoint_path}")   # reference: exit(1), misc.py:252-254
-    td = dict(cfg.MODEL.SMPL_HEAD.TRANSFORMER_DECODER.__dict__)
+    td = dict(cfg.MODEL.SMPL_HEAD.TRANSFORMER_DECODER)
     ckpt = ckpt_io.load_checkpoint(checkpoint_path)
     if not isinstance(ckpt, dict) or "state_dict" not in ckpt:
         raise KeyError(f"{checkpoint_path}: no 'state_dict' entry (misc.py:249 reads torch.load(...)['state_dict'])")
