@@ -1,0 +1,77 @@
+"""fp32 GEMM on the bf16 matrix pipe (csrc/gemm_split.hip: three bf16 pieces per operand, six products, fp32 accumulate) beside the
+exact-fp32 MFMA kernel, on the four ViT-H GEMM shapes of the hot path (vit.py:82-87,104-126) at B crops:
+per shape the time of both kernels with the epilogue the engine uses, the time of converting the A operand, the error of both against
+an fp64 product of the same operands (max over the output of |c - c64| / (|a| . |w|)), and fp32-equivalent TFLOP/s (2 M N K / t).
+
+    python scripts/split3_bench.py [--crops 64] [--iters 20]
+"""
+import argparse
+import json
+import math
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from tokenhmr_amd import ops  # noqa: E402
+
+
+def timed(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(iters):
+        fn()
+    t1.record()
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--crops", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--no-error", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    M = args.crops * 192
+    shapes = [("qkv", 3840, 1280, "bias_qscale"), ("proj", 1280, 1280, "bias_resid"), ("fc1", 5120, 1280, "bias_gelu"),
+              ("fc2", 1280, 5120, "bias_resid")]
+    g = torch.Generator(device="cpu").manual_seed(0)
+    rows = []
+    for name, N, K, epi in shapes:
+        a = torch.randn(M, K, generator=g)
+        a[:, ::97] *= 40.0                                        # a few outlier channels, as the ViT residual stream has
+        w = torch.randn(N, K, generator=g) / math.sqrt(K)
+        b = torch.randn(N, generator=g)
+        r = torch.randn(M, N, generator=g)
+        da, dw, db, dr = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
+        kw = dict(qscale=80 ** -0.5, qcols=1280) if epi == "bias_qscale" else {}
+        res = dr if epi == "bias_resid" else None
+        sa, sw = ops.split3(da), ops.split3(dw)
+        flop = 2.0 * M * N * K
+        row = {"gemm": name, "M": M, "N": N, "K": K, "epi": epi}
+        t32 = timed(lambda: ops.gemm(da, dw, db, res, epi=epi, **kw), args.iters)
+        row["f32_mfma"] = {"us": round(t32 * 1e6, 1), "tflops": round(flop / t32 * 1e-12, 1)}
+        row["convert_A_us"] = round(timed(lambda: ops.split3(da), args.iters) * 1e6, 1)
+        for v in ops.SPLIT3_VARIANT:
+            t = timed(lambda: ops.gemm_split3(sa, sw, db, res, epi=epi, variant=v, **kw), args.iters)
+            row["split3 " + v] = {"us": round(t * 1e6, 1), "f32_equiv_tflops": round(flop / t * 1e-12, 1), "vs_f32_mfma": round(t32 / t, 3)}
+        if not args.no_error:
+            c64 = da.double() @ dw.double().t()
+            bound = da.double().abs() @ dw.double().abs().t()
+            e32 = ((ops.gemm(da, dw).double() - c64).abs() / bound)
+            es = ((ops.gemm_split3(sa, sw).double() - c64).abs() / bound)
+            row["err_over_abs_dot"] = {"f32_mfma_max": float(e32.max()), "f32_mfma_rms": float(e32.pow(2).mean().sqrt()),
+                                       "split3_max": float(es.max()), "split3_rms": float(es.pow(2).mean().sqrt())}
+            del c64, bound, e32, es
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+        del da, dw, dr, sa, sw
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -164,6 +164,78 @@ def test_gemm_ring16(built_lib, cuda_dev, shape):
     assert torch.allclose(full, close, atol=2e-5, rtol=1e-5)                         # another order of the K sum, same value to fp32 rounding
 
 
+def _split3_ref(x):
+    """numpy restatement of csrc/gemm_split.hip::split3_kernel: h = bf16_rne(x), m = bf16_rne(x - h), l = bf16_rne(x - h - m),
+    laid out [R][K/8][3][8] (uint16 bit patterns)."""
+    import numpy as np
+
+    def rne(f):
+        u = f.view(np.uint32).astype(np.uint64)
+        return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint32)
+
+    def up(b):
+        return (b << 16).astype(np.uint32).view(np.float32)
+
+    x = x.numpy().astype(np.float32)
+    h = rne(x)
+    r1 = (x - up(h)).astype(np.float32)
+    m = rne(r1)
+    r2 = (r1 - up(m)).astype(np.float32)
+    l = rne(r2)
+    R, K = x.shape
+    out = np.stack([p.reshape(R, K // 8, 8) for p in (h, m, l)], axis=2).astype(np.uint16)         # (R, K/8, 3, 8)
+    return out, (up(h).astype(np.float64) + up(m) + up(l))
+
+
+def test_split3_convert(built_lib, cuda_dev):
+    """fp32 -> three bf16 pieces: bit-identical to the numpy restatement, and h + m + l reproduces x to 2^-24 (it is exact unless the
+    third piece rounds)."""
+    import numpy as np
+    from tokenhmr_amd import ops
+    x = _rand(200, 256, seed=5) * torch.logspace(-6, 6, 256)[None, :]
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, 1e-38, 1e-45, 65504.0])
+    got = ops.split3(x.to(cuda_dev)).cpu().numpy().view(np.uint16)
+    ref, back = _split3_ref(x)
+    assert np.array_equal(got, ref)
+    xd = x.numpy().astype(np.float64)
+    ok = (np.abs(xd) < 1e38) & (np.abs(xd) > 1e-30)
+    assert np.all(np.abs(back - xd)[ok] <= np.abs(xd)[ok] * 2.0 ** -24)
+
+
+SPLIT3_SHAPES = [(384, 512, 256), (200, 300, 96), (128, 256, 32), (1, 8, 64), (1536, 1280, 1280), (777, 3840, 1280), (260, 1280, 5120)]
+
+
+@pytest.mark.parametrize("shape", SPLIT3_SHAPES)
+def test_gemm_split3(built_lib, cuda_dev, shape):
+    """fp32 GEMM on the bf16 matrix pipe (three bf16 pieces per operand, six products, fp32 accumulate) against fp64: every tile
+    variant and epilogue, ragged M / N, one K tile, determinism, tile- and batch-independence of a row's result — and its error
+    measured beside the exact-fp32 MFMA kernel's on the same operands (it must be of the same size)."""
+    from tokenhmr_amd import ops
+    M, N, K = shape
+    a, w, b, r = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(N, seed=3), _rand(M, N, seed=4)
+    a[:, ::7] *= 30.0                                                        # outlier channels, as a ViT residual stream has
+    da, dw, db, dr = a.to(cuda_dev), w.to(cuda_dev), b.to(cuda_dev), r.to(cuda_dev)
+    sa, sw = ops.split3(da), ops.split3(dw)
+    ref64 = a.double() @ w.double().t()
+    bound = (a.double().abs() @ w.double().abs().t())                       # |a| . |w|: what a dot product's rounding error scales with
+    e32 = ((ops.gemm(da, dw, variant="128x160").cpu().double() - ref64).abs() / bound).max().item()
+    outs = {}
+    for variant in ("128x256/w8", "128x256/w4", "128x128/w4"):
+        o = ops.gemm_split3(sa, sw, variant=variant)
+        es = ((o.cpu().double() - ref64).abs() / bound).max().item()
+        assert es <= max(2.0 * e32, 2.0 ** -22), (variant, es, e32)
+        assert torch.equal(o, ops.gemm_split3(sa, sw, variant=variant))
+        outs[variant] = o
+        for epi, kw in (("bias", {}), ("bias_gelu", {}), ("bias_resid", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
+            o = ops.gemm_split3(sa, sw, db, dr if epi == "bias_resid" else None, epi=epi, variant=variant, **kw)
+            ref = _gemm_ref(a, w, b, r, epi, kw.get("qscale", 1.0), kw.get("qcols", 0))
+            assert torch.allclose(o.cpu(), ref, atol=2e-4, rtol=1e-5), (variant, epi, (o.cpu() - ref).abs().max())
+    assert torch.equal(outs["128x256/w4"], outs["128x256/w8"]) and torch.equal(outs["128x128/w4"], outs["128x256/w8"])
+    if M > 2:
+        half = ops.gemm_split3(ops.split3(da[:M // 2].contiguous()), sw)
+        assert torch.equal(half, outs["128x256/w8"][:M // 2])
+
+
 TINY_SHAPES = [(21, 512, 1536), (160, 512, 768), (160, 256, 2048), (126, 6, 1536), (960, 512, 1536), (55, 512, 512), (37, 31, 256)]
 
 

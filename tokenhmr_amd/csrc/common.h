@@ -251,6 +251,9 @@ int launch_gemm_splitk(const GemmArgs& a, int variant, int ksplit, float* part, 
 // applied by launch_splitk_epilogue / launch_splitk_resid_ln)
 int launch_gemm_ring(const GemmArgs& a, int epi, int ring, int ksplit, float* part, hipStream_t s);   // gemm_f32.hip
 int launch_gemm_ring16(const GemmArgs& a, int epi, hipStream_t s);                // gemm_f32.hip: small M on 16x16x4 tiles (64 x 48)
+// gemm_split.hip: fp32 -> three bf16 pieces ("split3"), and the GEMM over split3 operands on the bf16 matrix pipe (a.A / a.W = split3)
+int launch_split3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int K, hipStream_t s);
+int launch_gemm_split3(const GemmArgs& a, int epi, int variant, hipStream_t s);
 int launch_gemm_skinny(const GemmArgs& a, int epi, hipStream_t s);                // gemm_skinny.hip
 int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s);     // attention.hip
 int launch_vit_attention_keysplit(const float* qkv, float* out, int B, hipStream_t s);   // few crops: keys split over the 4 waves

@@ -1322,6 +1322,33 @@ int thmr_op_gemm(const float* A, int64_t lda, const float* W, const float* bias,
     return 0;
 }
 
+int thmr_op_split3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int32_t K, void* stream) {
+    thmr_engine* e = nullptr;
+    if (!src || !dst) return fail(e, THMR_ERR_INVALID, "null buffer");
+    if (rows <= 0 || K <= 0 || (K % 8) != 0 || (ld_src % 4) != 0 || (ld_dst % 8) != 0 || ld_dst < K || ld_src < K)
+        return fail(e, THMR_ERR_INVALID, "split3: K % 8, ld_src % 4, ld_dst % 8 must be 0 and the strides >= K");
+    LAUNCH_OK(launch_split3(src, ld_src, dst, ld_dst, rows, K, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, float* C,
+                        int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi, float qscale, int32_t qcols, int32_t variant,
+                        void* stream) {
+    thmr_engine* e = nullptr;
+    if (!A || !W || !C) return fail(e, THMR_ERR_INVALID, "null buffer");
+    if (epi != EPI_NONE && epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_RESID && epi != EPI_BIAS_QSCALE)
+        return fail(e, THMR_ERR_INVALID, "split3 GEMM: epilogue must be 0, 1, 2, 4 or 5");
+    if (epi != EPI_NONE && !bias) return fail(e, THMR_ERR_INVALID, "epilogue needs bias");
+    if (epi == EPI_BIAS_RESID && !resid) return fail(e, THMR_ERR_INVALID, "epilogue needs resid");
+    if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || ldc < N)
+        return fail(e, THMR_ERR_INVALID, "split3 GEMM: K % 32 == 0, lda / ldw multiples of 8 and >= K, ldc >= N");
+    if (variant < 0 || variant > 2) return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant 0, 1 or 2");
+    GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, resid, ldc, C, ldc, M, N, K);
+    a.qscale = qscale; a.qcols = qcols;
+    LAUNCH_OK(launch_gemm_split3(a, epi, variant, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int thmr_op_layernorm(const float* x, const float* g, const float* b, float* y, int32_t rows, int32_t D, float eps,
                       int32_t relu, void* stream) {
     thmr_engine* e = nullptr;

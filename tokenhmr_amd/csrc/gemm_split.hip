@@ -1,0 +1,266 @@
+// fp32 GEMM on the bf16 matrix pipe:  C[M,N] = epilogue(A[M,K] . W[N,K]^T)  with every fp32 operand carried as THREE bf16 pieces.
+//
+// Why: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, gemm_f32.hip) runs at 1/16 of the bf16 rate on gfx950 (157 vs 2500 TFLOP/s) and the
+// ViT GEMMs of the reference (tokenhmr/lib/models/backbones/vit.py:82-87,104-126) already sit at 0.93 of that peak.  An fp32 number
+// is the exact sum of three bf16 numbers, x = h + m + l (8 + 8 + 8 significand bits, each piece the round-to-nearest bf16 of what
+// the pieces before it left), a product of two bf16 is exact in fp32, and
+//     a.b = hh + (hm + mh) + (mm + hl + lh) + [ml + lm + ll]
+// where the bracket is below 2^-23 of |a.b| — the size of ONE fp32 rounding, which an fp32 dot product of length K commits K times.
+// So six v_mfma_f32_32x32x16_bf16 (fp32 accumulate) per 16 k give an fp32-grade product at 16 / 6 = 2.67 times the matrix rate.
+// This is NOT the product path of the engine (which stays on exact-fp32 MFMA and is bitwise an fmaf chain); it is an op of the C ABI
+// (thmr_op_split3 / thmr_op_gemm_split3) with its own parity tests against an fp64 reference, measured beside the fp32 kernel.
+//
+// Operand format ("split3"): X[R][K] fp32  ->  Xs[R][K/8][3][8] bf16: 8 consecutive k of a row as three adjacent 16-byte chunks
+// (piece h, m, l).  One chunk is exactly one lane's A / B operand of v_mfma_f32_32x32x16_bf16 (8 consecutive k of one row), a row
+// of a 32-deep K tile is 192 contiguous bytes, a row of the matrix is 6 K bytes.
+//
+// Kernel (gfx950): block tile (WM TM 32) x (WN TN 32), 8 waves of 64 x 64 on 128 x 256 by default, ONE workgroup per CU (two LDS
+// stages of 72 KB), two waves per SIMD.
+//   * staging: global_load_lds_dwordx4, saddr form (gemm_device.h); the LDS image of a stage is chunk-linear (row r = 12 chunks), and
+//     since the LDS side of the copy is lane-linear the bank swizzle is applied to the SOURCE: physical slot p of row r holds logical
+//     chunk (p - rot(r)) mod 12 with rot(r) = (r >> 2) & 3.  A row is 192 B = 48 banks, so the 16 lanes of one ds_read_b128 group
+//     (16 consecutive rows, same logical chunk) would collide four ways; with the rotation they cover all 64 banks exactly once.
+//   * per K tile and wave: 2 steps of 16 k; a step = 3 (TM + TN) ds_read_b128 and 6 TM TN MFMAs, accumulators walked round-robin.
+//   * schedule of K tile kt (buffer kt & 1), no VALU instruction in the loop:
+//       step 0 : MFMAs on fragment set 0, the reads of step 1's fragments in their shadow
+//       barrier: this wave's copies of tile kt+1 (issued one step EARLIER, during step 1 of tile kt-1) have landed and its reads of
+//                buffer kt & 1 have returned
+//       step 1 : MFMAs on fragment set 1; in their shadow the reads of tile kt+1's step-0 fragments and the copies of tile kt+2 into
+//                the buffer everybody just finished reading
+//     so a copy has a whole step (>= 24 MFMAs of this wave plus its SIMD partner's) to land and no fragment read is exposed.
+#include <cstdlib>
+
+#include "common.h"
+#include "gemm_device.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SBK = 32;                     // K tile, fp32 elements
+constexpr int SLOTS = SBK / 8 * 3;          // 16-byte chunks per row and K tile
+constexpr int ROWB = SLOTS * 16;            // 192 bytes
+
+// round-to-nearest-even bf16 of x (NaN stays NaN)
+__device__ __forceinline__ uint32_t bf16_rne(float x) {
+    const uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// X[rows][lds] fp32 -> split3 (row stride ldd fp32-equivalents = 6 ldd bytes); thread = 8 consecutive k of one row
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, int64_t lds_, char* __restrict__ dst, int64_t ldd,
+                                                     int64_t rows, int kg) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * kg) return;
+    const int64_t r = idx / kg;
+    const int g = (int)(idx - r * kg);
+    const f32x4* p = reinterpret_cast<const f32x4*>(src + r * lds_ + (int64_t)g * 8);
+    const f32x4 v0 = p[0], v1 = p[1];
+    const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = bf16_rne(x[e]);
+        const float r1 = x[e] - __uint_as_float(h[e] << 16);          // exact: the residual of a rounding fits the format
+        m[e] = bf16_rne(r1);
+        const float r2 = r1 - __uint_as_float(m[e] << 16);            // exact
+        l[e] = bf16_rne(r2);
+    }
+    u32x4* o = reinterpret_cast<u32x4*>(dst + r * ldd * 6 + (int64_t)g * 48);
+    o[0] = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+    o[1] = u32x4{m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16)};
+    o[2] = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+}
+
+__device__ __forceinline__ uint32_t lds_addr_b(const char* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+// the six piece pairs (A piece, W piece) kept, smallest terms first: lh hl mm mh hm hh
+constexpr int NPROD = 6;
+constexpr int piece_a(int p) { return p == 0 ? 2 : (p == 2 || p == 3) ? 1 : 0; }
+constexpr int piece_w(int p) { return p == 1 ? 2 : (p == 2 || p == 4) ? 1 : 0; }
+
+template <int WM, int WN, int TM, int TN, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_split3_kernel(GemmArgs a, int tiles_m, int tiles_n, int nwg) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int A_Q = BM * SLOTS / 64, B_Q = BN * SLOTS / 64;       // wave instructions (1 KiB each) per stage
+    static_assert(A_Q % NW == 0 && B_Q % NW == 0, "tile / waves mismatch");
+    constexpr int A_P = A_Q / NW, B_P = B_Q / NW, NP = A_P + B_P;     // copies per wave and K tile
+    constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * ROWB;
+    static_assert(2 * (A_STAGE + B_STAGE) <= 160 * 1024, "LDS");
+
+    __shared__ __attribute__((aligned(16))) char smem[2 * (A_STAGE + B_STAGE)];
+    char* As = smem;                       // [2][BM][192]
+    char* Bs = smem + 2 * A_STAGE;         // [2][BN][192]
+
+    int tile_m, tile_n;
+    tile_coords(tiles_m, tiles_n, logical_block(nwg, 0), tile_m, tile_n);
+    const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+    const int nk = a.K / SBK;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / WN) * TM * 32;
+    const int wn0 = (wave % WN) * TN * 32;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+
+    // ---- copies: wave instruction q = wave + i NW of an operand fills LDS chunks 64 q ... 64 q + 63 of its stage; lane -> chunk c,
+    // row c / 12, physical slot c % 12, which holds logical chunk (slot - rot(row)) mod 12.  Rows past the edge are clamped.
+    const int64_t arow = a.lda * 6, wrow = a.ldw * 6;                  // bytes per matrix row
+    const char* Abase = reinterpret_cast<const char*>(a.A) + (int64_t)bm0 * arow;
+    const char* Wbase = reinterpret_cast<const char*>(a.W) + (int64_t)bn0 * wrow;
+    uint32_t Aoff[A_P], Woff[B_P];
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+        const int c = (wave + i * NW) * 64 + lane, row = c / SLOTS, slot = c - row * SLOTS;
+        const int j = (slot + SLOTS - ((row >> 2) & 3)) % SLOTS;
+        Aoff[i] = (uint32_t)(min(bm0 + row, a.M - 1) - bm0) * (uint32_t)arow + (uint32_t)j * 16u;
+    }
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) {
+        const int c = (wave + i * NW) * 64 + lane, row = c / SLOTS, slot = c - row * SLOTS;
+        const int j = (slot + SLOTS - ((row >> 2) & 3)) % SLOTS;
+        Woff[i] = (uint32_t)(min(bn0 + row, a.N - 1) - bn0) * (uint32_t)wrow + (uint32_t)j * 16u;
+    }
+    auto dma_piece = [&](int kt, int buf, int p) {                     // p, buf: compile-time after unrolling
+        const int64_t k0b = (int64_t)kt * ROWB;                        // wave-uniform, added on the SALU
+        if (p < A_P) dma16_saddr(Abase + k0b, Aoff[p], lds_addr_b(As + buf * A_STAGE + (wave + p * NW) * 1024));
+        else dma16_saddr(Wbase + k0b, Woff[p - A_P], lds_addr_b(Bs + buf * B_STAGE + (wave + (p - A_P) * NW) * 1024));
+    };
+
+    // ---- fragments: step s of a K tile multiplies k-groups 2 s (lanes 0-31) and 2 s + 1 (lanes 32-63); chunk j = 3 kgroup + piece
+    // sits in physical slot (j + rot(row)) mod 12, rot(row) = (lrow >> 2) & 3 for every row this lane reads (tile offsets are x 32)
+    uint32_t fo[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+            fo[s][pc] = (uint32_t)lrow * ROWB + (uint32_t)((((2 * s + lhalf) * 3 + pc) + ((lrow >> 2) & 3)) % SLOTS) * 16u;
+    const char* Afr = As + wm0 * ROWB;
+    const char* Bfr = Bs + wn0 * ROWB;
+
+    bf16x8 af[2][TM][3], bf[2][TN][3];
+    constexpr int NR = 3 * (TM + TN);                                  // fragment reads per step
+    // read r of step s of the tile in buffer `buf` into fragment set `set`: A pieces first, in the order the products use them
+    auto read_one = [&](int buf, int s, int set, int r) {
+        if (r < 3 * TM) {
+            const int mi = r / 3, pc = r % 3;
+            af[set][mi][pc] = *reinterpret_cast<const bf16x8*>(Afr + buf * A_STAGE + mi * 32 * ROWB + fo[s][pc]);
+        } else {
+            const int q = r - 3 * TM, ni = q / 3, pc = q % 3;
+            bf[set][ni][pc] = *reinterpret_cast<const bf16x8*>(Bfr + buf * B_STAGE + ni * 32 * ROWB + fo[s][pc]);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- prologue: tiles 0 and 1 in flight, tile 0's step-0 fragments in registers
+#pragma unroll
+    for (int p = 0; p < NP; ++p) dma_piece(0, 0, p);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) dma_piece(min(1, nk - 1), 1, p);
+    dma_wait_barrier();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) read_one(0, 0, 0, r);
+
+    constexpr int G = NPROD * TM * TN;                                 // MFMAs per step
+    constexpr int RS0 = G / NR >= 2 ? 2 : 1;                           // step 0: one read every RS0-th MFMA
+    static_assert(NR * RS0 <= G && NR + NP <= G, "tile too small for the staging interleave");
+
+    auto ktile = [&](int kt, auto bufc) {
+        constexpr int buf = decltype(bufc){};
+        const int kt2 = min(kt + 2, nk - 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                dma_wait_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int p = 0; p < NPROD; ++p)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) {
+                        const int idx = (p * TM + mi) * TN + ni;
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][mi][piece_a(p)], bf[s][ni][piece_w(p)],
+                                                                              acc[mi][ni], 0, 0, 0);
+                        bool any = false;
+                        if (s == 0) {
+                            if (idx % RS0 == 0 && idx / RS0 < NR) { read_one(buf, 1, 1, idx / RS0); any = true; }
+                        } else {
+                            if (idx < NR) { read_one(buf ^ 1, 0, 0, idx); any = true; }
+                            else if (idx - NR < NP) { dma_piece(kt2, buf, idx - NR); any = true; }
+                        }
+                        if (any) __builtin_amdgcn_sched_barrier(0);
+                    }
+        }
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        ktile(kt, IntC<0>{});
+        ktile(kt + 1, IntC<1>{});
+    }
+    if (kt < nk) ktile(kt, IntC<0>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no LDS-DMA write may outlive the workgroup's LDS allocation
+
+    store_tile<TM, TN, EPI>(a, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_split3_cfg(const GemmArgs& a, int epi, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, nwg = tiles_m * tiles_n;
+    const dim3 grid(nwg), block(WM * WN * 64);
+#define THMR_SPLIT_CASE(E)                                                                                                  \
+    case E:                                                                                                                 \
+        hipLaunchKernelGGL((gemm_split3_kernel<WM, WN, TM, TN, E>), grid, block, 0, s, a, tiles_m, tiles_n, nwg);    \
+        break;
+    switch (epi) {
+        THMR_SPLIT_CASE(EPI_NONE)
+        THMR_SPLIT_CASE(EPI_BIAS)
+        THMR_SPLIT_CASE(EPI_BIAS_GELU)
+        THMR_SPLIT_CASE(EPI_BIAS_RESID)
+        THMR_SPLIT_CASE(EPI_BIAS_QSCALE)
+        default: return -1;
+    }
+#undef THMR_SPLIT_CASE
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace
+
+int launch_split3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int K, hipStream_t s) {
+    if (rows <= 0 || K <= 0 || (K % 8) != 0 || (ld_src % 4) != 0 || (ld_dst % 8) != 0 || ld_dst < K) return -1;
+    const int kg = K / 8;
+    const int64_t n = rows * kg;
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld_src, reinterpret_cast<char*>(dst), ld_dst,
+                       rows, kg);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// a.A / a.W point at split3 operands (lda / ldw = their row strides in fp32-equivalents, i.e. 6 lda bytes); C, bias, resid are fp32.
+// variant: 0 = 8 waves of 64x64 on 128x256 (default)   1 = 4 waves of 64x128 on 128x256   2 = 4 waves of 64x64 on 128x128
+int launch_gemm_split3(const GemmArgs& a, int epi, int variant, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % SBK) != 0 || (a.lda % 8) != 0 || (a.ldw % 8) != 0) return -1;
+    if (a.lda * 6 * 256 >= (int64_t(1) << 32) || a.ldw * 6 * 256 >= (int64_t(1) << 32)) return -1;     // 32-bit lane offsets within a tile
+    if (a.cs_out != nullptr || a.ksplit > 1) return -1;
+    switch (variant) {
+        case 0: return launch_split3_cfg<2, 4, 2, 2>(a, epi, s);
+        case 1: return launch_split3_cfg<2, 2, 2, 4>(a, epi, s);
+        case 2: return launch_split3_cfg<2, 2, 2, 2>(a, epi, s);
+        default: return -1;
+    }
+}

@@ -41,6 +41,38 @@ def gemm(a, w, bias=None, resid=None, epi="none", qscale=1.0, qcols=0, variant="
     return out
 
 
+SPLIT3_VARIANT = {"128x256/w8": 0, "128x256/w4": 1, "128x128/w4": 2}
+
+
+def split3(x):
+    """fp32 (R,K) -> the "split3" operand of gemm_split3: every element as three bf16 pieces h + m + l, laid out [R][K/8][3][8]
+    (returned as an int16 tensor of shape (R, K/8, 3, 8); see csrc/gemm_split.hip).  K % 8 == 0."""
+    _req(x)
+    R, K = x.shape
+    out = torch.empty(R, K // 8, 3, 8, device=x.device, dtype=torch.int16)
+    with torch.cuda.device(x.device):
+        _cabi.check(_cabi.load().thmr_op_split3(_p(x), K, _p(out), K, R, K, _s(x)))
+    return out
+
+
+def gemm_split3(a_s, w_s, bias=None, resid=None, epi="none", qscale=1.0, qcols=0, variant="128x256/w8"):
+    """C = epilogue(a @ w.T) for split3 operands (`split3(a)`, `split3(w)`) on the bf16 matrix pipe with fp32-grade results: six
+    bf16 products per element pair, fp32 accumulation.  Not the engine's path — an operator measured beside `gemm`."""
+    _req(bias, resid)
+    for t in (a_s, w_s):
+        if not (t.is_cuda and t.dtype == torch.int16 and t.is_contiguous() and t.dim() == 4 and t.shape[2:] == (3, 8)):
+            raise ValueError("gemm_split3 needs split3 operands (int16, (R, K/8, 3, 8))")
+    M, K = a_s.shape[0], a_s.shape[1] * 8
+    N = w_s.shape[0]
+    if w_s.shape[1] * 8 != K:
+        raise ValueError("K mismatch")
+    out = torch.empty(M, N, device=a_s.device, dtype=torch.float32)
+    with torch.cuda.device(a_s.device):
+        _cabi.check(_cabi.load().thmr_op_gemm_split3(_p(a_s), K, _p(w_s), K, _p(bias), _p(resid), _p(out), N, M, N, K, EPI[epi],
+                                                    float(qscale), int(qcols), SPLIT3_VARIANT[variant], _s(a_s)))
+    return out
+
+
 def layernorm(x, gamma, beta, eps, relu=False):
     _req(x, gamma, beta)
     rows, D = x.shape
