@@ -31,7 +31,7 @@ extern "C" {
  * random); the resample tables / padding row / flag words of the weight arena are written by thmr_load_weights on the LOADING
  * engine (round 1: thmr_create on every engine; round 2: thmr_finalize_weights(0)) and validated — not written — by
  * thmr_finalize_weights(assume_all_loaded = 1). */
-#define THMR_ABI_VERSION 2
+#define THMR_ABI_VERSION 3
 
 typedef enum {
     THMR_OK = 0,
@@ -286,6 +286,16 @@ const char* thmr_collective_last_error(void);
  * on = 0 off, 1 every class, 2 only the four ViT GEMM classes, 3 only fc1 (the dominant kernel), sampled.  An event pair costs ~2-3 us
  * of stream time: 128 pairs per call (on = 2) were 0.75 % of a B = 64 step and 20 % of a B = 1 call (round 3: the facade call
  * without events was FASTER than the timed loop), which is why bench.py times with on = 3, which samples every 4th fc1 launch (8 pairs per call; all 32 launches have one shape). */
+/* How the four ViT GEMMs (qkv / proj / fc1 / fc2: 97 % of the path's arithmetic) are multiplied.
+ *   0 (default): exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) — bitwise an fmaf chain; every parity claim and the headline benchmark refer to it.
+ *   1: "split3" — each fp32 operand as three bf16 pieces, six bf16 MFMA products per element pair, fp32 accumulation
+ *      (csrc/gemm_split.hip; thmr_op_gemm_split3 is the same kernel).  fp32-GRADE, not bitwise fp32: the measured error against an fp64
+ *      product is no larger than the exact-fp32 kernel's (tests/test_gpu_ops.py::test_gemm_split3), at ~1.6x its rate.  Applies to calls of at
+ *      least 17 crops (below, the exact-fp32 kernels run regardless); LayerNorm, attention, the epilogues and the head are unchanged.
+ * Setting 1 needs finalized weights; the engine then owns a split3 copy of the ViT weights (1.5x their fp32 bytes) and the operand
+ * buffers, rebuilt by thmr_finalize_weights while the mode is on.  Returns 0 / negative; thmr_get_vit_gemm returns the mode. */
+int thmr_set_vit_gemm(thmr_engine* e, int32_t mode, void* stream);
+int thmr_get_vit_gemm(thmr_engine* e);
 int thmr_prof_enable(thmr_engine* e, int32_t on);
 int thmr_prof_collect(thmr_engine* e, thmr_prof_entry* entries /*[THMR_PROF_NUM]*/, int32_t reset);
 

@@ -194,8 +194,19 @@ def test_b64_tokens_vs_reference_golden(built_lib, cuda_dev):
     img = _inputs(B, seed)
     assert abs(float(img.double().sum()) - g["img_checksum"][0]) < 1e-6
     model = TokenHMR.from_state(RELEASE, sd, tok, smpl, max_batch=64, device=cuda_dev)
-    out = _to_cpu(model({"img": img.to(cuda_dev)}))
-    model.engine.status()
+    for vit_gemm in ("f32", "split3"):
+        # "split3": the ViT GEMMs on the bf16 matrix pipe with fp32 operands as three bf16 pieces (thmr_set_vit_gemm) — held to the SAME
+        # bounds against the reference's own modules as the exact-fp32 path
+        model.engine.set_vit_gemm(vit_gemm)
+        assert model.engine.vit_gemm() == vit_gemm
+        out = _to_cpu(model({"img": img.to(cuda_dev)}))
+        model.engine.status()
+        _check_b64_golden(out, g, vit_gemm)
+    del model
+    torch.cuda.empty_cache()
+
+
+def _check_b64_golden(out, g, tag):
     idx, ref, gap = out["token_idx"].numpy(), g["token_idx"], g["top2_gap"]
     mism = idx != ref
     n_mis, n_safe_mis = int(mism.sum()), int((mism & (gap > 1e-3)).sum())
@@ -205,13 +216,55 @@ def test_b64_tokens_vs_reference_golden(built_lib, cuda_dev):
                rot=np.abs(R - g["rotmat"]).max(), betas=np.abs(out["pred_smpl_params"]["betas"].numpy() - g["betas"]).max(),
                cam=np.abs(out["pred_cam"].numpy() - g["cam"]).max(), kp2d=np.abs(out["pred_keypoints_2d"].numpy() - g["kp2d"]).max(),
                probs_max=np.abs(out["cls_logits_softmax"].max(-1).values.numpy() - g["probs_max"]).max())
-    print(f"[golden full_d32_b64] token-index mismatches: {n_mis} of {idx.size} "
+    print(f"[golden full_d32_b64, ViT GEMMs {tag}] token-index mismatches: {n_mis} of {idx.size} "
           f"({n_safe_mis} where the reference's top-2 gap > 1e-3; gaps at the mismatches: "
           f"{sorted(float(x) for x in gap[mism])[:8]}) " + " ".join(f"{k}={v:.2e}" for k, v in rep.items()))
     assert n_safe_mis == 0, "a token index differs from the reference's where its top-2 logit gap > 1e-3"
     assert n_mis <= 5, f"{n_mis} of {idx.size} token indices differ (all inside the 1e-3 near-tie band, but more than a handful)"
     assert rep["joints"] < 1e-4 and rep["verts"] < 1e-4 and rep["rot"] < 1e-4 and rep["betas"] < 1e-4 and rep["cam"] < 1e-4
     assert rep["kp2d"] < 1e-3 and rep["probs_max"] < 1e-5
+
+
+def test_vit_gemm_split3_mode(built_lib, cuda_dev):
+    """thmr_set_vit_gemm: the split3 mode (ViT GEMMs on the bf16 matrix pipe, fp32 operands as three bf16 pieces) against the exact-fp32
+    mode of the SAME engine and against the oracle: fp32-rounding-close features, equal token indices away from near-ties, vertices
+    within 0.1 mm; deterministic; a crop's result does not depend on the batch it rides in (>= 17 crops); below 17 crops the mode
+    changes nothing (bit-identical to the exact-fp32 path); switching back restores the exact-fp32 results bit for bit."""
+    from oracle import tokenhmr_oracle as O
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd.model import TokenHMR
+    cfg = HMRConfig(vit_depth=2, dec_depth=2)
+    sd, tok, smpl = _assets(cfg)
+    model = TokenHMR.from_state(cfg, sd, tok, smpl, max_batch=24, device=cuda_dev)
+    model.return_taps = True
+    img = _inputs(24, seed=5).to(cuda_dev)
+    f32 = _to_cpu(model({"img": img[:20]}))
+    f32_small = _to_cpu(model({"img": img[:5]}))
+    model.engine.set_vit_gemm("split3")
+    assert model.engine.vit_gemm() == "split3"
+    s3 = _to_cpu(model({"img": img[:20]}))
+    model.engine.status()
+    again = _to_cpu(model({"img": img[:20]}))
+    s3_24 = _to_cpu(model({"img": img}))
+    s3_small = _to_cpu(model({"img": img[:5]}))
+    for k in ("pred_vertices", "cls_logits", "vit_features"):
+        assert torch.equal(s3[k], again[k]), k                                  # deterministic
+        assert torch.equal(s3[k], s3_24[k][:20]), k                             # batch-independent
+        assert torch.equal(s3_small[k], f32_small[k]), k                        # under 17 crops: the exact-fp32 kernels
+    assert not torch.equal(s3["vit_features"], f32["vit_features"])            # the mode really ran
+    assert (s3["vit_features"] - f32["vit_features"]).abs().max() < 2e-4
+    assert (s3["pred_vertices"] - f32["pred_vertices"]).abs().max() < 1e-4 and (s3["cls_logits"] - f32["cls_logits"]).abs().max() < 1e-3
+    with torch.no_grad():
+        orc = O.forward(img[:20].cpu(), sd, tok, smpl, cfg)
+    top2 = orc["cls_logits"].topk(2, dim=-1).values
+    ref = dict(vit_features=orc["vit_features"], token_out=orc["token_out"], cls_logits=orc["cls_logits"],
+               rotmat=torch.cat([orc["pred_smpl_params"]["global_orient"], orc["pred_smpl_params"]["body_pose"]], 1),
+               betas=orc["pred_smpl_params"]["betas"], cam=orc["pred_cam"], verts=orc["pred_vertices"],
+               joints=orc["pred_keypoints_3d"], kp2d=orc["pred_keypoints_2d"], token_idx=orc["token_idx"])
+    _check_against(s3, ref, top2[..., 0] - top2[..., 1], "split3 B=20 vs oracle")
+    model.engine.set_vit_gemm("f32")
+    back = _to_cpu(model({"img": img[:20]}))
+    assert torch.equal(back["pred_vertices"], f32["pred_vertices"]) and torch.equal(back["vit_features"], f32["vit_features"])
     del model
     torch.cuda.empty_cache()
 

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtokenhmr_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "tokenhmr_hip.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PROF_NAMES = ["gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "attention", "layernorm", "patch_embed",
               "dec_kv", "head", "lbs"]
 
@@ -131,6 +131,8 @@ def load():
     lib.thmr_allgather_records.argtypes = [vp, vp, i32, vp, vp]
     lib.thmr_collective_last_error.restype = C.c_char_p
     lib.thmr_prof_enable.argtypes = [vp, i32]
+    lib.thmr_set_vit_gemm.argtypes = [vp, i32, vp]
+    lib.thmr_get_vit_gemm.argtypes = [vp]
     lib.thmr_prof_collect.argtypes = [vp, C.POINTER(ProfEntry), i32]
     for name in declared_symbols():
         fn = getattr(lib, name)

@@ -254,6 +254,8 @@ int launch_gemm_ring16(const GemmArgs& a, int epi, hipStream_t s);              
 // gemm_split.hip: fp32 -> three bf16 pieces ("split3"), and the GEMM over split3 operands on the bf16 matrix pipe (a.A / a.W = split3)
 int launch_split3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int K, hipStream_t s);
 int launch_gemm_split3(const GemmArgs& a, int epi, int variant, hipStream_t s);
+// LayerNorm (D = 1280) whose result is written as a split3 operand [rows][D/8][3][8] instead of fp32 (same arithmetic as launch_layernorm)
+int launch_layernorm_split3(const float* x, const float* g, const float* b, void* y_split, int rows, int D, float eps, hipStream_t s);
 int launch_gemm_skinny(const GemmArgs& a, int epi, hipStream_t s);                // gemm_skinny.hip
 int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s);     // attention.hip
 int launch_vit_attention_keysplit(const float* qkv, float* out, int B, hipStream_t s);   // few crops: keys split over the 4 waves

@@ -41,6 +41,9 @@ constexpr int kKeysplitMaxB = 2;                  // key-split attention kernel:
 // -10 % per call at 9 and 10 crops, -2.5 ... -3.7 % at 11 ... 16, -2 % at 7 and 8 with the 64x128 tile; from 17 on the unsplit launch
 // is the faster one, and 4 ways never beats 2).  That range is its own regime of the K sum.
 constexpr int kMidLoM = 7 * 192, kMidHiM = 16 * 192, kMidSplit = 2;
+// thmr_set_vit_gemm(1): batches of at least this many crops run the ViT GEMMs as split3 products (128 x 256 tiles, one workgroup per
+// CU: below the big-tile regime the exact-fp32 kernels with their smaller tiles and split-K stay in charge)
+constexpr int kSplit3MinB = 17;
 // decoder + mixer stack: the persistent decoder kernel and the one-workgroup-per-crop mixer kernel win while the work is
 // latency-bound (B = 1: 0.96 vs 1.01 ms, B = 64: 1.58 vs 1.93 ms per head); from a few hundred crops on the same products are
 // real GEMMs (M = B and M = 160 B rows) and the tiled MFMA kernels win (B = 512: 6.7 vs 7.5 ms) — profiles/r2e_head_fused_vs_chain.log
@@ -91,6 +94,14 @@ struct thmr_engine {
     bool attn_keysplit = true;        // THMR_ATTN_KEYSPLIT=0: one and two crops keep the 64-query attention workgroups (A/B only)
     int mid_split_force[2] = {-1, -1};   // THMR_MID_SPLIT=<p><f> (digits 0|2|4): force the split factors of proj and fc2 above 6 crops where the partial-sum buffer allows (A/B only)
     bool smpl_loaded = false, finalized = false;
+    // thmr_set_vit_gemm(1): the four ViT GEMMs of batches of at least kSplit3MinB crops run on the bf16 matrix pipe with fp32 operands
+    // carried as three bf16 pieces (csrc/gemm_split.hip).  Engine-owned memory: the split3 copies of the ViT weights (1.5 x their fp32
+    // size) and the split3 activation operands (M x (1280 + 5120) x 6 bytes).  Off (0) = exact-fp32 MFMA everywhere, the default.
+    int vit_gemm_mode = 0;
+    char* split_w = nullptr;
+    char* split_act = nullptr;
+    struct SplitW { const char *qkv, *proj, *fc1, *fc2; };
+    std::vector<SplitW> vitw_s;
     unsigned* host_err = nullptr;     // host-mapped sticky error word of the persistent decoder kernel (hipHostMalloc)
     std::string err;
     // derived / constant regions (float offsets in weight arena)
@@ -459,12 +470,58 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         }
         return 0;
     };
+    const float* lastn_w = e->hot.lastn_w;
+    const float* lastn_b = e->hot.lastn_b;
+    if (e->vit_gemm_mode == 1 && B >= kSplit3MinB) {
+        // The four GEMMs as split3 products on the bf16 matrix pipe (csrc/gemm_split.hip); everything else — patch embed, attention,
+        // LayerNorm arithmetic, epilogues — is the fp32 path's.  A operands: the LayerNorms write their result directly as three bf16
+        // pieces (hs); the attention output and the GELU output are converted by a pass of their own (as, bs).
+        char* hs = e->split_act;                                    // [M][1280] split3: LayerNorm / attention output
+        char* bs = e->split_act + (size_t)M * DIM * 6;              // [M][5120] split3: GELU output
+        auto gemm_s = [&](int cls, const char* A, int K, const char* Wt, const float* bias, const float* resid, float* C, int N, int epi) -> int {
+            ProfScope ps(e, st, cls, 2.0 * M * (double)N * K, 6.0 * ((double)M * K + (double)N * K) + 4.0 * M * N * (resid ? 2.0 : 1.0));
+            GemmArgs a = mk(reinterpret_cast<const float*>(A), K, reinterpret_cast<const float*>(Wt), K, bias, resid, N, C, N, M, N, K);
+            a.qscale = qscale; a.qcols = DIM;
+            return launch_gemm_split3(a, epi, 0, st);
+        };
+        {
+            ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
+            LAUNCH_OK(launch_layernorm_split3(x, e->vitw[0].n1w, e->vitw[0].n1b, hs, M, DIM, VIT_EPS, st));
+        }
+        for (int i = 0; i < e->vit_depth; ++i) {
+            const VitBlockW& w = e->vitw[i];
+            const thmr_engine::SplitW& ws = e->vitw_s[i];
+            const bool last = i + 1 == e->vit_depth;
+            LAUNCH_OK(gemm_s(THMR_PROF_GEMM_QKV, hs, DIM, ws.qkv, w.qkvb, nullptr, big, 3 * DIM, EPI_BIAS_QSCALE));
+            {
+                ProfScope ps(e, st, THMR_PROF_ATTN, 4.0 * B * HEADS * 192.0 * 192.0 * 80.0, 4.0 * (4.0 * M * DIM));
+                LAUNCH_OK(launch_vit_attention(big, h, B, st));
+            }
+            {
+                ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
+                LAUNCH_OK(launch_split3(h, DIM, hs, DIM, M, DIM, st));
+            }
+            LAUNCH_OK(gemm_s(THMR_PROF_GEMM_PROJ, hs, DIM, ws.proj, w.pb, x, x, DIM, EPI_BIAS_RESID));
+            {
+                ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
+                LAUNCH_OK(launch_layernorm_split3(x, w.n2w, w.n2b, hs, M, DIM, VIT_EPS, st));
+            }
+            LAUNCH_OK(gemm_s(THMR_PROF_GEMM_FC1, hs, DIM, ws.fc1, w.f1b, nullptr, big, MLP, EPI_BIAS_GELU));
+            {
+                ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * MLP);
+                LAUNCH_OK(launch_split3(big, MLP, bs, MLP, M, MLP, st));
+            }
+            LAUNCH_OK(gemm_s(THMR_PROF_GEMM_FC2, bs, MLP, ws.fc2, w.f2b, x, x, DIM, EPI_BIAS_RESID));
+            ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
+            if (last) LAUNCH_OK(launch_layernorm(x, lastn_w, lastn_b, feats_out ? feats_out : h, M, DIM, VIT_EPS, 0, st));
+            else LAUNCH_OK(launch_layernorm_split3(x, e->vitw[i + 1].n1w, e->vitw[i + 1].n1b, hs, M, DIM, VIT_EPS, st));
+        }
+        return 0;
+    }
     {
         ProfScope ps(e, st, THMR_PROF_LN, 0, 8.0 * M * DIM);
         LAUNCH_OK(launch_layernorm(x, e->vitw[0].n1w, e->vitw[0].n1b, h, M, DIM, VIT_EPS, 0, st));
     }
-    const float* lastn_w = e->hot.lastn_w;
-    const float* lastn_b = e->hot.lastn_b;
     for (int i = 0; i < e->vit_depth; ++i) {
         const VitBlockW& w = e->vitw[i];
         const bool last = i + 1 == e->vit_depth;
@@ -931,6 +988,8 @@ void thmr_destroy(thmr_engine* e) {
     if (e->counted) { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[e->cfg.device] -= 1; }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->host_err) (void)hipHostFree(e->host_err);
+    if (e->split_w) (void)hipFree(e->split_w);
+    if (e->split_act) (void)hipFree(e->split_act);
     if (e->own_w && e->warena) (void)hipFree(e->warena);
     if (e->own_s && e->sarena) (void)hipFree(e->sarena);
     delete e;
@@ -975,6 +1034,32 @@ int thmr_load_smpl(thmr_engine* e, const thmr_smpl_desc* s, void* stream) {
     HIP_OK(hipMemcpyAsync(ints + 80, &e->hips_host, sizeof(int32_t), hipMemcpyHostToDevice, st));
     e->smpl_loaded = true;
     e->finalized = false;
+    return 0;
+}
+
+// split3 copies of the four ViT GEMM weights of every block (6 bytes per weight) + the activation operand buffers, engine-owned
+static int build_split_weights(thmr_engine* e, hipStream_t st) {
+    const size_t per_block = (size_t)DIM * (3 * DIM) + (size_t)DIM * DIM + 2 * (size_t)DIM * MLP;      // weights of one block
+    if (!e->split_w && hipMalloc(reinterpret_cast<void**>(&e->split_w), per_block * 6 * e->vit_depth) != hipSuccess)
+        return fail(e, THMR_ERR_NOMEM, "hipMalloc(split3 ViT weights) failed");
+    const size_t M = (size_t)e->max_batch * TOK;
+    if (!e->split_act && hipMalloc(reinterpret_cast<void**>(&e->split_act), M * (size_t)(DIM + MLP) * 6) != hipSuccess)
+        return fail(e, THMR_ERR_NOMEM, "hipMalloc(split3 activations) failed");
+    e->vitw_s.resize(e->vit_depth);
+    char* p = e->split_w;
+    for (int i = 0; i < e->vit_depth; ++i) {
+        const VitBlockW& w = e->vitw[i];
+        auto conv = [&](const float* src, int rows, int K, const char*& out) -> int {
+            out = p;
+            const int rc = launch_split3(src, K, p, K, rows, K, st);
+            p += (size_t)rows * K * 6;
+            return rc;
+        };
+        LAUNCH_OK(conv(w.qkvw, 3 * DIM, DIM, e->vitw_s[i].qkv));
+        LAUNCH_OK(conv(w.pw, DIM, DIM, e->vitw_s[i].proj));
+        LAUNCH_OK(conv(w.f1w, MLP, DIM, e->vitw_s[i].fc1));
+        LAUNCH_OK(conv(w.f2w, DIM, MLP, e->vitw_s[i].fc2));
+    }
     return 0;
 }
 
@@ -1095,8 +1180,23 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
         }
     }
     e->finalized = true;
+    if (e->vit_gemm_mode == 1) return build_split_weights(e, st);      // weights were (re)loaded with the split3 mode on
     return 0;
 }
+
+int thmr_set_vit_gemm(thmr_engine* e, int32_t mode, void* stream) {
+    if (!e) return fail(e, THMR_ERR_INVALID, "null engine");
+    if (mode != 0 && mode != 1) return fail(e, THMR_ERR_INVALID, "vit gemm mode must be 0 (exact-fp32 MFMA) or 1 (split3 on the bf16 matrix pipe)");
+    if (mode == 1) {
+        if (!e->finalized) return fail(e, THMR_ERR_STATE, "thmr_set_vit_gemm(1) needs finalized weights (thmr_finalize_weights)");
+        if (hipSetDevice(e->cfg.device) != hipSuccess) return fail(e, THMR_ERR_HIP, "hipSetDevice failed");
+        if (int r = build_split_weights(e, static_cast<hipStream_t>(stream))) return r;
+    }
+    e->vit_gemm_mode = mode;
+    return 0;
+}
+
+int thmr_get_vit_gemm(thmr_engine* e) { return e ? e->vit_gemm_mode : -1; }
 
 int thmr_vq_decode(thmr_engine* e, const float* probs_dev, int32_t B, float* pose6d_dev, void* stream) {
     if (int r = check_ready(e, B)) return r;

@@ -74,6 +74,59 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ s
     o[2] = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
 }
 
+// nn.LayerNorm over D = NV * 256 (vit.py:136,144; the arithmetic of rowops.hip::ln_wave_kernel, one wave per row) with the result
+// written as a split3 operand: lane l holds 4 consecutive elements, so lanes 2 j and 2 j + 1 write the two 8-byte halves of the three
+// chunks of k-group j — the fp32 copy of the normalised row is never written.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_split3_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, char* __restrict__ y, int rows, float eps) {
+    constexpr int D = NV * 256;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (int64_t)row * D;
+    f32x4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
+        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(sum) * (1.0f / D);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            sq += d * d;
+        }
+    const float var = wave_sum(sq) * (1.0f / D);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    char* yr = y + (int64_t)row * D * 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+        uint32_t h[4], m[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float o = (v[i][e] - mean) * rstd * g[e] + b[e];
+            h[e] = bf16_rne(o);
+            const float r1 = o - __uint_as_float(h[e] << 16);
+            m[e] = bf16_rne(r1);
+            const float r2 = r1 - __uint_as_float(m[e] << 16);
+            l[e] = bf16_rne(r2);
+        }
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        char* o8 = yr + (c >> 3) * 48 + (lane & 1) * 8;
+        *reinterpret_cast<u32x2*>(o8) = u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        *reinterpret_cast<u32x2*>(o8 + 16) = u32x2{m[0] | (m[1] << 16), m[2] | (m[3] << 16)};
+        *reinterpret_cast<u32x2*>(o8 + 32) = u32x2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+    }
+}
+
 __device__ __forceinline__ uint32_t lds_addr_b(const char* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -248,6 +301,12 @@ int launch_split3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, i
     const int64_t n = rows * kg;
     hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld_src, reinterpret_cast<char*>(dst), ld_dst,
                        rows, kg);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_layernorm_split3(const float* x, const float* g, const float* b, void* y_split, int rows, int D, float eps, hipStream_t s) {
+    if (rows <= 0 || D != 1280) return -1;
+    hipLaunchKernelGGL(ln_split3_kernel<5>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, reinterpret_cast<char*>(y_split), rows, eps);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

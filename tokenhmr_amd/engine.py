@@ -244,6 +244,18 @@ class Engine:
             _cabi.check(self.lib.thmr_vq_argmin(self.h, _ptr(x), rows, _ptr(idx), _ptr(dist), _stream_ptr(self.device)), self.h)
         return (idx, dist) if want_dist else idx
 
+    # ------------------------------------------------------------------ how the ViT GEMMs are multiplied
+    VIT_GEMM = {"f32": 0, "split3": 1}
+
+    def set_vit_gemm(self, mode="f32"):
+        """"f32" (default): exact-fp32 MFMA.  "split3": fp32 operands as three bf16 pieces on the bf16 matrix pipe (six products, fp32
+        accumulate; fp32-grade, not bitwise fp32) for calls of at least 17 crops — see thmr_set_vit_gemm in the header."""
+        with torch.cuda.device(self.device):
+            _cabi.check(self.lib.thmr_set_vit_gemm(self.h, self.VIT_GEMM[mode], _stream_ptr(self.device)), self.h)
+
+    def vit_gemm(self):
+        return {v: k for k, v in self.VIT_GEMM.items()}[self.lib.thmr_get_vit_gemm(self.h)]
+
     # ------------------------------------------------------------------ profiler
     def prof_enable(self, on=True):
         """on: False / True (every kernel class) / "gemm" (the four ViT GEMM classes) / "fc1" (only the dominant kernel: cheapest,
