@@ -197,11 +197,17 @@ int thmr_op_gemm(const float* A_dev, int64_t lda, const float* W_dev, const floa
  * down to 2^-16 of |a b| (what is dropped is below one fp32 rounding of the product), accumulation is fp32 in the MFMA.
  * thmr_op_split3 converts (K % 8 == 0, ld_dst % 8 == 0, ld_dst >= K, ld_src % 4 == 0).  thmr_op_gemm_split3: A / W split3 with row
  * strides lda / ldw in fp32-equivalents (multiples of 8), K % 32 == 0; bias / resid / C fp32; epi 0, 1, 2, 4, 5 as thmr_op_gemm;
- * variant 0 = 128x256 tile, 8 waves (default); 1 = 128x256, 4 waves; 2 = 128x128, 4 waves. */
+ * variant 0 = 128x256 tile, 8 waves (default); 1 = 128x256, 4 waves; 2 = 128x128, 4 waves (3, 31, 32, 34, 37: schedule experiments
+ * of scripts/split3_bench.py, epilogue 0 only; 31-37 are timing-only and return garbage). */
 int thmr_op_split3(const float* src_dev, int64_t ld_src, void* dst_dev, int64_t ld_dst, int64_t rows, int32_t K, void* stream);
 int thmr_op_gemm_split3(const void* A_split_dev, int64_t lda, const void* W_split_dev, int64_t ldw, const float* bias_dev,
                         const float* resid_dev, float* C_dev, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi,
                         float qscale, int32_t qcols, int32_t variant, void* stream);
+/* the same product with the epilogue's result written as a split3 operand (the next GEMM's A; row stride 6 * ldcs bytes, N % 8 == 0,
+ * ldcs % 8 == 0) instead of fp32: bit-identical to thmr_op_split3 of thmr_op_gemm_split3's output.  epi 0, 1, 2, 5. */
+int thmr_op_gemm_split3_out_split3(const void* A_split_dev, int64_t lda, const void* W_split_dev, int64_t ldw, const float* bias_dev,
+                                   void* C_split_dev, int64_t ldcs, int32_t M, int32_t N, int32_t K, int32_t epi, float qscale,
+                                   int32_t qcols, int32_t variant, void* stream);
 int thmr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,
                       int32_t rows, int32_t D, float eps, int32_t relu, void* stream);
 /* ViT global attention over 192 tokens, 16 heads x 80 (vit.py:113-122); qkv (B,192,3840) with q pre-scaled. */

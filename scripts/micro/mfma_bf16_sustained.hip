@@ -1,0 +1,92 @@
+// Micro-benchmark 9 (round 3): what rate does the bf16 matrix pipe SUSTAIN on this part, and what do the LDS reads of a GEMM loop cost it?
+// Context: the split3 GEMM (csrc/gemm_split.hip) keeps the MFMA pipe 74 % busy in cycles, but its counters show the shader clock at
+// ~1.53 GHz during the kernel (GRBM_GUI_ACTIVE / duration; the exact-fp32 kernel runs at ~2.16 GHz).  Is that a power ceiling of the
+// matrix pipe itself, or the price of the data movement around it?
+//   hipcc --offload-arch=gfx950 -O3 -o build_ab/mfma_bf16_sustained scripts/micro/mfma_bf16_sustained.hip && build_ab/mfma_bf16_sustained
+// Every variant: 256 workgroups (one per CU) of W waves, each wave issues v_mfma_f32_32x32x16_bf16 round-robin over 4 accumulators for
+// ~DUR ms; operands never change (registers).  Variants:
+//   pure      : MFMAs only
+//   lds R     : R conflict-free ds_read_b128 per 24 MFMAs in their shadow (the split3 kernel has 12), results fed to the operands
+//   lds+dma   : plus 9 global_load_lds_dwordx4 (1 KiB each) per 48 MFMAs from an L2-resident buffer (the split3 kernel's copy rate)
+// Prints TFLOP/s (bf16) and the implied average clock = TF / (256 CUs x 4 SIMDs x 1024 flop/clk).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int R, bool DMA>
+__global__ __launch_bounds__(512) void k(float* out, const char* src, int iters) {
+    __shared__ __attribute__((aligned(16))) char lds[144 * 1024];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 144 * 1024 / 4; i += blockDim.x) reinterpret_cast<float*>(lds)[i] = 1e-3f * (i & 255);
+    __syncthreads();
+    f32x16 acc[4];
+    for (int a = 0; a < 4; ++a)
+        for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+    bf16x8 fa[12], fb[2];
+    for (int i = 0; i < 12; ++i)
+        for (int e = 0; e < 8; ++e) fa[i][e] = (__bf16)(0.001f * (lane + i + e));
+    for (int i = 0; i < 2; ++i)
+        for (int e = 0; e < 8; ++e) fb[i][e] = (__bf16)(0.002f * (lane + i - e));
+    // conflict-free: 16 B per lane, lanes consecutive
+    const char* lp = lds + wave * 16384 + lane * 16;
+    const uint32_t voff = lane * 16;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(lds + 128 * 1024 + wave * 1024));
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 48; ++m) {
+            acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m % 12], fb[m & 1], acc[m & 3], 0, 0, 0);
+            if ((m % 24) * R / 24 != ((m % 24) + 1) * R / 24 && R > 0) {
+                const int r = ((m % 24) * R / 24) % 12;
+                fa[r] = *reinterpret_cast<const bf16x8*>(lp + r * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (DMA && m % 5 == 0 && m / 5 < 9) {
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src + (size_t)((it * 9 + m / 5) & 1023) * 1024), "s"(lds_base));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    float s = 0.f;
+    for (int a = 0; a < 4; ++a)
+        for (int e = 0; e < 16; ++e) s += acc[a][e];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+template <int R, bool DMA>
+void run(const char* name, int waves, float* out, const char* src, double ms_target) {
+    int iters = 2000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k<R, DMA>), dim3(256), dim3(waves * 64), 0, 0, out, src, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep == 0) { iters = (int)(iters * ms_target / ms); continue; }
+        const double flop = 256.0 * waves * (double)iters * 48 * 32768.0;
+        const double tf = flop / (ms * 1e-3) / 1e12;
+        printf("%-14s waves/CU %d  %8.2f ms  %8.1f TFLOP/s bf16   implied clock %.2f GHz (if the pipes never idled)\n", name, waves, ms, tf,
+               tf * 1e12 / (256.0 * 4 * 1024) / 1e9);
+    }
+}
+
+int main() {
+    float* out; char* src;
+    hipMalloc(&out, 4096); hipMalloc(&src, 1 << 20);
+    hipMemset(src, 0, 1 << 20);
+    for (int w : {4, 8}) {
+        run<0, false>("pure", w, out, src, 60.0);
+        run<6, false>("lds 6/24", w, out, src, 60.0);
+        run<12, false>("lds 12/24", w, out, src, 60.0);
+        run<12, true>("lds 12 + dma", w, out, src, 60.0);
+    }
+    run<0, false>("pure 300 ms", 8, out, src, 300.0);
+    return 0;
+}

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--crops", type=int, default=64)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--no-error", action="store_true")
+    ap.add_argument("--schedule", action="store_true", help="schedule experiments and timing-only ablations instead of the variant table")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     M = args.crops * 192
@@ -56,7 +57,14 @@ def main():
         t32 = timed(lambda: ops.gemm(da, dw, db, res, epi=epi, **kw), args.iters)
         row["f32_mfma"] = {"us": round(t32 * 1e6, 1), "tflops": round(flop / t32 * 1e-12, 1)}
         row["convert_A_us"] = round(timed(lambda: ops.split3(da), args.iters) * 1e6, 1)
-        for v in ops.SPLIT3_VARIANT:
+        if args.schedule:      # schedule experiments / timing-only ablations of the default tile, without epilogue
+            row = {"gemm": name, "M": M, "N": N, "K": K, "epi": "none"}
+            for v in ("128x256/w8", "exp/reads-every-2nd", "abl/no-copies", "abl/no-barrier", "abl/no-reads", "abl/none"):
+                t = timed(lambda: ops.gemm_split3(sa, sw, variant=v), args.iters)
+                row[v] = {"us": round(t * 1e6, 1), "f32_equiv_tflops": round(flop / t * 1e-12, 1)}
+            print(json.dumps(row), flush=True)
+            continue
+        for v in ("128x256/w8", "128x256/w4", "128x128/w4"):
             t = timed(lambda: ops.gemm_split3(sa, sw, db, res, epi=epi, variant=v, **kw), args.iters)
             row["split3 " + v] = {"us": round(t * 1e6, 1), "f32_equiv_tflops": round(flop / t * 1e-12, 1), "vs_f32_mfma": round(t32 / t, 3)}
         if not args.no_error:

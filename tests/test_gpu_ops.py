@@ -231,6 +231,12 @@ def test_gemm_split3(built_lib, cuda_dev, shape):
             ref = _gemm_ref(a, w, b, r, epi, kw.get("qscale", 1.0), kw.get("qcols", 0))
             assert torch.allclose(o.cpu(), ref, atol=2e-4, rtol=1e-5), (variant, epi, (o.cpu() - ref).abs().max())
     assert torch.equal(outs["128x256/w4"], outs["128x256/w8"]) and torch.equal(outs["128x128/w4"], outs["128x256/w8"])
+    if N % 8 == 0:      # the epilogue's result as the next GEMM's split3 operand: bit-identical to converting the fp32 result
+        for variant in ("128x256/w8", "128x256/w4", "128x128/w4"):
+            for epi, kw in (("none", {}), ("bias", {}), ("bias_gelu", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
+                bb = None if epi == "none" else db
+                fused = ops.gemm_split3(sa, sw, bb, epi=epi, variant=variant, out_split=True, **kw)
+                assert torch.equal(fused, ops.split3(ops.gemm_split3(sa, sw, bb, epi=epi, variant=variant, **kw))), (variant, epi)
     if M > 2:
         half = ops.gemm_split3(ops.split3(da[:M // 2].contiguous()), sw)
         assert torch.equal(half, outs["128x256/w8"][:M // 2])

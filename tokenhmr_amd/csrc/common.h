@@ -45,6 +45,10 @@ struct GemmArgs {
     // grid, copy sp reduces K slice [sp*K/ksplit, (sp+1)*K/ksplit) and stores its RAW partial tile to C + sp*M*ldc (C = the
     // partial-sum buffer part[ksplit][M][N], no epilogue); 0 / 1 = off.
     int ksplit;
+    // split3 GEMM only (gemm_split.hip): c_split != nullptr = the epilogue's result goes out as a split3 operand [M][N/8][3][8] bf16
+    // (row stride 6 * ldcs bytes; N % 8 == 0) INSTEAD of fp32 C — the next GEMM's A operand without a conversion pass
+    void* c_split;
+    int64_t ldcs;
 };
 
 // Branch-free fp32 erf, < 1.5 ulp over the whole line (tests/test_gpu_ops.py::test_gelu_epilogue_ulp): two minimax

@@ -43,7 +43,7 @@ constexpr int kKeysplitMaxB = 2;                  // key-split attention kernel:
 constexpr int kMidLoM = 7 * 192, kMidHiM = 16 * 192, kMidSplit = 2;
 // thmr_set_vit_gemm(1): batches of at least this many crops run the ViT GEMMs as split3 products (128 x 256 tiles, one workgroup per
 // CU: below the big-tile regime the exact-fp32 kernels with their smaller tiles and split-K stay in charge)
-constexpr int kSplit3MinB = 17;
+constexpr int kSplit3MinB = 16;
 // decoder + mixer stack: the persistent decoder kernel and the one-workgroup-per-crop mixer kernel win while the work is
 // latency-bound (B = 1: 0.96 vs 1.01 ms, B = 64: 1.58 vs 1.93 ms per head); from a few hundred crops on the same products are
 // real GEMMs (M = B and M = 160 B rows) and the tiled MFMA kernels win (B = 512: 6.7 vs 7.5 ms) — profiles/r2e_head_fused_vs_chain.log
@@ -98,6 +98,7 @@ struct thmr_engine {
     // carried as three bf16 pieces (csrc/gemm_split.hip).  Engine-owned memory: the split3 copies of the ViT weights (1.5 x their fp32
     // size) and the split3 activation operands (M x (1280 + 5120) x 6 bytes).  Off (0) = exact-fp32 MFMA everywhere, the default.
     int vit_gemm_mode = 0;
+    int split3_min_b = 0;             // THMR_SPLIT3_MIN_B=<n>: A/B knob for the smallest batch the split3 mode serves (0 = kSplit3MinB)
     char* split_w = nullptr;
     char* split_act = nullptr;
     struct SplitW { const char *qkv, *proj, *fc1, *fc2; };
@@ -472,7 +473,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
     };
     const float* lastn_w = e->hot.lastn_w;
     const float* lastn_b = e->hot.lastn_b;
-    if (e->vit_gemm_mode == 1 && B >= kSplit3MinB) {
+    if (e->vit_gemm_mode == 1 && B >= (e->split3_min_b > 0 ? e->split3_min_b : kSplit3MinB)) {
         // The four GEMMs as split3 products on the bf16 matrix pipe (csrc/gemm_split.hip); everything else — patch embed, attention,
         // LayerNorm arithmetic, epilogues — is the fp32 path's.  A operands: the LayerNorms write their result directly as three bf16
         // pieces (hs); the attention output and the GELU output are converted by a pass of their own (as, bs).
@@ -506,10 +507,11 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
                 LAUNCH_OK(launch_layernorm_split3(x, w.n2w, w.n2b, hs, M, DIM, VIT_EPS, st));
             }
-            LAUNCH_OK(gemm_s(THMR_PROF_GEMM_FC1, hs, DIM, ws.fc1, w.f1b, nullptr, big, MLP, EPI_BIAS_GELU));
-            {
-                ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * MLP);
-                LAUNCH_OK(launch_split3(big, MLP, bs, MLP, M, MLP, st));
+            {   // fc1 + exact GELU, written directly as fc2's split3 operand (no fp32 copy of the hidden activations exists)
+                ProfScope ps(e, st, THMR_PROF_GEMM_FC1, 2.0 * M * DIM * (double)MLP, 6.0 * ((double)M * DIM + (double)DIM * MLP + (double)M * MLP));
+                GemmArgs a = mk(reinterpret_cast<const float*>(hs), DIM, reinterpret_cast<const float*>(ws.fc1), DIM, w.f1b, nullptr, 0, nullptr, 0, M, MLP, DIM);
+                a.c_split = bs; a.ldcs = MLP;
+                LAUNCH_OK(launch_gemm_split3(a, EPI_BIAS_GELU, 0, st));
             }
             LAUNCH_OK(gemm_s(THMR_PROF_GEMM_FC2, bs, MLP, ws.fc2, w.f2b, x, x, DIM, EPI_BIAS_RESID));
             ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
@@ -977,6 +979,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* tg = getenv("THMR_TINY_GEMM"); e->tiny_gemm = !(tg && tg[0] == '0'); }
     { const char* qr = getenv("THMR_QKV_RING16"); e->qkv_ring16 = !(qr && qr[0] == '0'); }
     { const char* ak = getenv("THMR_ATTN_KEYSPLIT"); e->attn_keysplit = !(ak && ak[0] == '0'); }
+    { const char* sm = getenv("THMR_SPLIT3_MIN_B"); e->split3_min_b = sm ? atoi(sm) : 0; }
     { const char* ms = getenv("THMR_MID_SPLIT"); if (ms && ms[0] && ms[1]) { e->mid_split_force[0] = ms[0] - '0'; e->mid_split_force[1] = ms[1] - '0'; } }
     { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
     *out = e;
@@ -1442,9 +1445,28 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
     if (epi == EPI_BIAS_RESID && !resid) return fail(e, THMR_ERR_INVALID, "epilogue needs resid");
     if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || ldc < N)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: K % 32 == 0, lda / ldw multiples of 8 and >= K, ldc >= N");
-    if (variant < 0 || variant > 2) return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant 0, 1 or 2");
+    if (!(variant >= 0 && variant <= 3) && variant != 31 && variant != 32 && variant != 34 && variant != 37)
+        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant 0, 1, 2 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, resid, ldc, C, ldc, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
+    LAUNCH_OK(launch_gemm_split3(a, epi, variant, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int thmr_op_gemm_split3_out_split3(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* Cs, int64_t ldcs,
+                                   int32_t M, int32_t N, int32_t K, int32_t epi, float qscale, int32_t qcols, int32_t variant, void* stream) {
+    thmr_engine* e = nullptr;
+    if (!A || !W || !Cs) return fail(e, THMR_ERR_INVALID, "null buffer");
+    if (epi != EPI_NONE && epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_QSCALE)
+        return fail(e, THMR_ERR_INVALID, "split3 GEMM with split3 output: epilogue must be 0, 1, 2 or 5");
+    if (epi != EPI_NONE && !bias) return fail(e, THMR_ERR_INVALID, "epilogue needs bias");
+    if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || (N % 8) != 0 ||
+        (ldcs % 8) != 0 || ldcs < N)
+        return fail(e, THMR_ERR_INVALID, "split3 GEMM: K % 32 == 0, N % 8 == 0, lda / ldw / ldcs multiples of 8 and >= K / K / N");
+    if (variant < 0 || variant > 2) return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant 0, 1 or 2");
+    GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, nullptr, 0, nullptr, 0, M, N, K);
+    a.qscale = qscale; a.qcols = qcols;
+    a.c_split = Cs; a.ldcs = ldcs;
     LAUNCH_OK(launch_gemm_split3(a, epi, variant, static_cast<hipStream_t>(stream)));
     return 0;
 }

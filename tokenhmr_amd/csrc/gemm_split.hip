@@ -136,7 +136,9 @@ constexpr int NPROD = 6;
 constexpr int piece_a(int p) { return p == 0 ? 2 : (p == 2 || p == 3) ? 1 : 0; }
 constexpr int piece_w(int p) { return p == 1 ? 2 : (p == 2 || p == 4) ? 1 : 0; }
 
-template <int WM, int WN, int TM, int TN, int EPI>
+// ABL (timing-only experiments, results are garbage): bit0 no copies in the loop, bit1 no per-tile barrier, bit2 no fragment reads.
+// RS: step 0 issues one fragment read every RS-th MFMA (0 = as early as possible: one per MFMA).
+template <int WM, int WN, int TM, int TN, int EPI, int ABL = 0, int RS = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_split3_kernel(GemmArgs a, int tiles_m, int tiles_n, int nwg) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split3_kernel(GemmArgs a, i
     for (int r = 0; r < NR; ++r) read_one(0, 0, 0, r);
 
     constexpr int G = NPROD * TM * TN;                                 // MFMAs per step
-    constexpr int RS0 = G / NR >= 2 ? 2 : 1;                           // step 0: one read every RS0-th MFMA
+    constexpr int RS0 = RS > 0 ? RS : 1;                               // step 0: one read every RS0-th MFMA
     static_assert(NR * RS0 <= G && NR + NP <= G, "tile too small for the staging interleave");
 
     auto ktile = [&](int kt, auto bufc) {
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split3_kernel(GemmArgs a, i
         const int kt2 = min(kt + 2, nk - 1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            if (s == 1) {
+            if (s == 1 && !(ABL & 2)) {
                 __builtin_amdgcn_sched_barrier(0);
                 dma_wait_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -252,10 +254,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split3_kernel(GemmArgs a, i
                                                                               acc[mi][ni], 0, 0, 0);
                         bool any = false;
                         if (s == 0) {
-                            if (idx % RS0 == 0 && idx / RS0 < NR) { read_one(buf, 1, 1, idx / RS0); any = true; }
+                            if (idx % RS0 == 0 && idx / RS0 < NR && !(ABL & 4)) { read_one(buf, 1, 1, idx / RS0); any = true; }
                         } else {
-                            if (idx < NR) { read_one(buf ^ 1, 0, 0, idx); any = true; }
-                            else if (idx - NR < NP) { dma_piece(kt2, buf, idx - NR); any = true; }
+                            if (idx < NR) { if (!(ABL & 4)) { read_one(buf ^ 1, 0, 0, idx); any = true; } }
+                            else if (idx - NR < NP && !(ABL & 1)) { dma_piece(kt2, buf, idx - NR); any = true; }
                         }
                         if (any) __builtin_amdgcn_sched_barrier(0);
                     }
@@ -267,9 +269,89 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split3_kernel(GemmArgs a, i
         ktile(kt + 1, IntC<1>{});
     }
     if (kt < nk) ktile(kt, IntC<0>{});
+    if constexpr ((ABL & 4) != 0) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) asm volatile("" : "+v"(af[st][i][pc]));
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) asm volatile("" : "+v"(bf[st][i][pc]));
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no LDS-DMA write may outlive the workgroup's LDS allocation
 
+    if (a.c_split) {                        // wave-uniform
+        // The epilogue's result as the NEXT GEMM's split3 operand.  The MFMA leaves a lane with one column and 16 rows; a split3 chunk
+        // is 8 consecutive columns of one row, so the wave tile is transposed through LDS (the stage buffers are dead by now): fp32
+        // tile, row stride WT = 32 TN + 4 floats, then lane (row r, column group q) reads 8 consecutive columns, applies bias +
+        // activation, splits and writes 48 contiguous bytes; the TN * 4 lanes of a row write 192 TN contiguous bytes.
+        constexpr int WT = TN * 32 + 4;
+        constexpr int GQ = TN * 4;                                     // column groups of 8 per wave-tile row
+        constexpr int RP = 64 / GQ;                                    // rows per pass
+        static_assert(NW * TM * 32 * WT * 4 <= 2 * (A_STAGE + B_STAGE), "transpose tile does not fit the stage buffers");
+        __syncthreads();                                               // every wave is done reading the stage buffers
+        float* T = reinterpret_cast<float*>(smem) + wave * (TM * 32 * WT);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    T[(mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf) * WT + ni * 32 + lrow] = acc[mi][ni][e];
+        const int q = lane % GQ, r0 = lane / GQ;
+        const int n = bn0 + wn0 + q * 8;
+        float bias[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bias[u] = (EPI != EPI_NONE && n + u < a.N) ? a.bias[n + u] : 0.f;
+        char* obase = reinterpret_cast<char*>(a.c_split) + (int64_t)(n >> 3) * 48;
+#pragma unroll
+        for (int ps = 0; ps < TM * 32 / RP; ++ps) {
+            const int r = r0 + ps * RP, m = bm0 + wm0 + r;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + r * WT + q * 8);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + r * WT + q * 8 + 4);
+            float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+            if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    const f32x2 gl = gelu_erf2(f32x2{v[u] + bias[u], v[u + 1] + bias[u + 1]});
+                    v[u] = gl.x;
+                    v[u + 1] = gl.y;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = gemm_epilogue<EPI>(a, v[u], bias[u], min(m, a.M - 1), min(n + u, a.N - 1));
+            }
+            uint32_t h[8], mm[8], l[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                h[u] = bf16_rne(v[u]);
+                const float r1 = v[u] - __uint_as_float(h[u] << 16);
+                mm[u] = bf16_rne(r1);
+                const float r2 = r1 - __uint_as_float(mm[u] << 16);
+                l[u] = bf16_rne(r2);
+            }
+            if (m < a.M && n < a.N) {
+                u32x4* o = reinterpret_cast<u32x4*>(obase + (int64_t)m * a.ldcs * 6);
+                o[0] = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+                o[1] = u32x4{mm[0] | (mm[1] << 16), mm[2] | (mm[3] << 16), mm[4] | (mm[5] << 16), mm[6] | (mm[7] << 16)};
+                o[2] = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+            }
+        }
+        return;
+    }
     store_tile<TM, TN, EPI>(a, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
+}
+
+template <int WM, int WN, int TM, int TN, int ABL, int RS>
+int launch_split3_abl(const GemmArgs& a, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, nwg = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm_split3_kernel<WM, WN, TM, TN, EPI_NONE, ABL, RS>), dim3(nwg), dim3(WM * WN * 64), 0, s, a, tiles_m, tiles_n, nwg);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -316,10 +398,18 @@ int launch_gemm_split3(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % SBK) != 0 || (a.lda % 8) != 0 || (a.ldw % 8) != 0) return -1;
     if (a.lda * 6 * 256 >= (int64_t(1) << 32) || a.ldw * 6 * 256 >= (int64_t(1) << 32)) return -1;     // 32-bit lane offsets within a tile
     if (a.cs_out != nullptr || a.ksplit > 1) return -1;
+    if (a.c_split != nullptr && ((a.N % 8) != 0 || (a.ldcs % 8) != 0 || a.ldcs < a.N || epi == EPI_BIAS_RESID)) return -1;
     switch (variant) {
         case 0: return launch_split3_cfg<2, 4, 2, 2>(a, epi, s);
         case 1: return launch_split3_cfg<2, 2, 2, 4>(a, epi, s);
         case 2: return launch_split3_cfg<2, 2, 2, 2>(a, epi, s);
+        // experiments on the default tile, EPI_NONE only: 3 = step-0 fragment reads every 2nd MFMA (the first version's schedule);
+        // 31 / 32 / 34 / 37 = timing-only ablations (no copies / no barrier / no fragment reads / none of the three): garbage results
+        case 3: return epi == EPI_NONE ? launch_split3_abl<2, 4, 2, 2, 0, 2>(a, s) : -1;
+        case 31: return epi == EPI_NONE ? launch_split3_abl<2, 4, 2, 2, 1, 0>(a, s) : -1;
+        case 32: return epi == EPI_NONE ? launch_split3_abl<2, 4, 2, 2, 2, 0>(a, s) : -1;
+        case 34: return epi == EPI_NONE ? launch_split3_abl<2, 4, 2, 2, 4, 0>(a, s) : -1;
+        case 37: return epi == EPI_NONE ? launch_split3_abl<2, 4, 2, 2, 7, 0>(a, s) : -1;
         default: return -1;
     }
 }

@@ -41,7 +41,9 @@ def gemm(a, w, bias=None, resid=None, epi="none", qscale=1.0, qcols=0, variant="
     return out
 
 
-SPLIT3_VARIANT = {"128x256/w8": 0, "128x256/w4": 1, "128x128/w4": 2}
+SPLIT3_VARIANT = {"128x256/w8": 0, "128x256/w4": 1, "128x128/w4": 2,
+                  # schedule experiments (epilogue "none" only; the abl/* ones are timing-only, their results are garbage)
+                  "exp/reads-every-2nd": 3, "abl/no-copies": 31, "abl/no-barrier": 32, "abl/no-reads": 34, "abl/none": 37}
 
 
 def split3(x):
@@ -55,9 +57,10 @@ def split3(x):
     return out
 
 
-def gemm_split3(a_s, w_s, bias=None, resid=None, epi="none", qscale=1.0, qcols=0, variant="128x256/w8"):
+def gemm_split3(a_s, w_s, bias=None, resid=None, epi="none", qscale=1.0, qcols=0, variant="128x256/w8", out_split=False):
     """C = epilogue(a @ w.T) for split3 operands (`split3(a)`, `split3(w)`) on the bf16 matrix pipe with fp32-grade results: six
-    bf16 products per element pair, fp32 accumulation.  Not the engine's path — an operator measured beside `gemm`."""
+    bf16 products per element pair, fp32 accumulation.  `out_split`: the result as a split3 operand (what the engine's fc1 hands fc2).
+    The engine runs it only in its opt-in mode `Engine.set_vit_gemm("split3")`."""
     _req(bias, resid)
     for t in (a_s, w_s):
         if not (t.is_cuda and t.dtype == torch.int16 and t.is_contiguous() and t.dim() == 4 and t.shape[2:] == (3, 8)):
@@ -66,6 +69,12 @@ def gemm_split3(a_s, w_s, bias=None, resid=None, epi="none", qscale=1.0, qcols=0
     N = w_s.shape[0]
     if w_s.shape[1] * 8 != K:
         raise ValueError("K mismatch")
+    if out_split:
+        out = torch.empty(M, N // 8, 3, 8, device=a_s.device, dtype=torch.int16)
+        with torch.cuda.device(a_s.device):
+            _cabi.check(_cabi.load().thmr_op_gemm_split3_out_split3(_p(a_s), K, _p(w_s), K, _p(bias), _p(out), N, M, N, K, EPI[epi],
+                                                                   float(qscale), int(qcols), SPLIT3_VARIANT[variant], _s(a_s)))
+        return out
     out = torch.empty(M, N, device=a_s.device, dtype=torch.float32)
     with torch.cuda.device(a_s.device):
         _cabi.check(_cabi.load().thmr_op_gemm_split3(_p(a_s), K, _p(w_s), K, _p(bias), _p(resid), _p(out), N, M, N, K, EPI[epi],
