@@ -202,6 +202,18 @@ def test_split3_convert(built_lib, cuda_dev):
     assert np.all(np.abs(back - xd)[ok] <= np.abs(xd)[ok] * 2.0 ** -24)
 
 
+@pytest.mark.parametrize("B", [1, 3, 16, 20, 30])
+def test_vit_attention_split3_output(built_lib, cuda_dev, B):
+    """Attention with its output written as the proj GEMM's split3 operand (64-query kernel up to 10 and for 17-24 crops, persistent
+    kernel otherwise — with its own vmcnt bookkeeping for 45 instead of 15 stores per item): bit-identical to converting the fp32 output."""
+    from tokenhmr_amd import ops
+    qkv = _rand(B, 192, 3840, seed=B).to(cuda_dev)
+    ref = ops.split3(ops.vit_attention(qkv).reshape(B * 192, 1280))
+    got = ops.vit_attention_split3(qkv)
+    assert torch.equal(got, ref)
+    assert torch.equal(got, ops.vit_attention_split3(qkv))
+
+
 SPLIT3_SHAPES = [(384, 512, 256), (200, 300, 96), (128, 256, 32), (1, 8, 64), (1536, 1280, 1280), (777, 3840, 1280), (260, 1280, 5120)]
 
 

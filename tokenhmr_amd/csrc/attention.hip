@@ -105,7 +105,9 @@ struct AttnDbg {
 // (crop, head) (batched path); (1, 4): three workgroups of 64 queries each, all staging the same K / V (few crops: B*16
 // workgroups cannot occupy 256 CUs); (1, 12): one 768-thread workgroup, 12 waves of 16 queries, K / V staged once.  Every query
 // is computed by the same instruction sequence in all of them, so the variants are bit-identical.
-template <int QT, int NW, int DBG = 0>
+// SPLIT: `out` is a split3 operand [B*192][1280/8][3][8] bf16 (gemm_split.hip) instead of fp32 — the same values, each written as three
+// bf16 pieces (a lane's 4 consecutive d are the 8-byte half of the three chunks of one k-group)
+template <int QT, int NW, int DBG = 0, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 2) void vit_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, AttnDbg dbg) {
     constexpr int QB = 12 / (QT * NW);      // query blocks per (crop, head)
     static_assert(QB * QT * NW == 12, "192 queries = QB workgroups x NW waves x QT tiles of 16");
@@ -277,8 +279,13 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 2) void vit_attention_kerne
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int dt = 0; dt < 5; ++dt)
-            *reinterpret_cast<f32x4*>(obase + (int64_t)(q0 + qt * 16 + l15) * DIM + dt * 16 + g * 4) = o[qt][dt] * inv[qt];
+        for (int dt = 0; dt < 5; ++dt) {
+            if constexpr (SPLIT)
+                store_split3_quad(reinterpret_cast<char*>(out) + ((int64_t)b * NTOK + q0 + qt * 16 + l15) * (DIM * 6), h * HD + dt * 16 + g * 4,
+                                  o[qt][dt] * inv[qt]);
+            else
+                *reinterpret_cast<f32x4*>(obase + (int64_t)(q0 + qt * 16 + l15) * DIM + dt * 16 + g * 4) = o[qt][dt] * inv[qt];
+        }
     if constexpr ((DBG & 1) != 0) {
         if (tid == 0) {
             unsigned long long* t = dbg.tl + (size_t)blockIdx.x * 16;
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 2) void vit_attention_kerne
 constexpr int kAttnDephaseUs = 0;     // start-up delay of the odd threadgroup slot's workgroup (see the kernel)
 __device__ __forceinline__ void barrier_only() { asm volatile("s_barrier" ::: "memory"); }
 
-template <int DBG = 0>
+template <int DBG = 0, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void vit_attention_persistent_kernel(const float* __restrict__ qkv, float* __restrict__ out, int nitems, AttnDbg dbg) {
     constexpr int QT = 3, NW = 4;
     // LDS image (K halves, later the V halves): rows of PS = 84 floats = 21 slots of 16 B (20 data + 1 pad) — conflict-free both for the
@@ -494,8 +501,13 @@ __global__ __launch_bounds__(256, 2) void vit_attention_persistent_kernel(const 
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-                for (int dt = 0; dt < 5; ++dt)
-                    *reinterpret_cast<f32x4*>(obase + (int64_t)(q0 + qt * 16 + l15) * DIM + dt * 16 + g * 4) = o[qt][dt] * inv[qt];
+                for (int dt = 0; dt < 5; ++dt) {
+                    if constexpr (SPLIT)      // three 8-byte stores per tile instead of one 16-byte store: 45 stores per item (see the wait below)
+                        store_split3_quad(reinterpret_cast<char*>(out) + ((int64_t)(bh / NH) * NTOK + q0 + qt * 16 + l15) * (DIM * 6),
+                                          (bh % NH) * HD + dt * 16 + g * 4, o[qt][dt] * inv[qt]);
+                    else
+                        *reinterpret_cast<f32x4*>(obase + (int64_t)(q0 + qt * 16 + l15) * DIM + dt * 16 + g * 4) = o[qt][dt] * inv[qt];
+                }
         }
         if constexpr ((DBG & 1) != 0) {
             if (tid == 0 && it == within) {          // timeline of the first item only
@@ -519,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void vit_attention_persistent_kernel(const 
             for (int j = 0; j < 5; ++j)
                 qf[qt][j] = *reinterpret_cast<const f32x4*>(nbase + (int64_t)(q0 + qt * 16 + l15) * QKV_LD + j * 16 + g * 4);
         asm volatile("" ::: "memory");
-        wait_vm_barrier<30>();             // this wave's K'[0:96] and K'[96:192] copies landed: only the 15 stores and the 15 Q' loads are younger
+        wait_vm_barrier<SPLIT ? 60 : 30>();   // this wave's K'[0:96] and K'[96:192] copies landed: only the 15 (split3: 45) stores and the 15 Q' loads are younger
         it += wpx;
         base = nbase;
     }
@@ -669,6 +681,20 @@ int launch_vit_attention_keysplit(const float* qkv, float* out, int B, hipStream
 int launch_vit_attention_variant(const float* qkv, float* out, int B, int variant, hipStream_t s);
 
 int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s) { return launch_vit_attention_variant(qkv, out, B, 0, s); }
+
+// split3 output (the engine's split3 mode, 16 crops and more): the batch-size rule of launch_vit_attention_variant's kernels 1 and 5
+int launch_vit_attention_split3(const float* qkv, void* out_split, int B, hipStream_t s) {
+    if (B <= 0) return -1;
+    float* out = reinterpret_cast<float*>(out_split);
+    const AttnDbg nodbg{nullptr, 0, 0};
+    if (B <= 10 || (B >= 17 && B <= 24)) {
+        hipLaunchKernelGGL((vit_attention_kernel<1, 4, 0, true>), dim3(B * NH * 3), dim3(256), 0, s, qkv, out, nodbg);
+    } else {
+        const AttnDbg dph{nullptr, kAttnDephaseUs * 100, 0};
+        hipLaunchKernelGGL((vit_attention_persistent_kernel<0, true>), dim3(min(B * NH, 512)), dim3(256), 0, s, qkv, out, B * NH, dph);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 // variant 0 = the rule below (or THMR_ATTN_VARIANT); 1 / 3 / 5 / 12 / 6 force a kernel (unit tests, A/B)
 int launch_vit_attention_variant(const float* qkv, float* out, int B, int want, hipStream_t s) {

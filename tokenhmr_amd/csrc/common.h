@@ -175,6 +175,33 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& a, float acc, flo
     return v;
 }
 
+// ---- "split3": an fp32 value as three bf16 pieces h + m + l (gemm_split.hip) ----
+// round-to-nearest-even bf16 of x (NaN stays NaN), as the 16-bit pattern
+__device__ __forceinline__ uint32_t bf16_rne(float x) {
+    const uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split3_of(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = bf16_rne(x);
+    const float r1 = x - __uint_as_float(h << 16);            // exact: the residual of a rounding fits the format
+    m = bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float(m << 16);           // exact
+    l = bf16_rne(r2);
+}
+// 4 consecutive columns c ... c + 3 (c % 4 == 0) of one row of a split3 operand [rows][D/8][3][8]: the 8-byte half (c & 4) of the three
+// chunks of k-group c / 8.  `row` points at the row's first byte.
+__device__ __forceinline__ void store_split3_quad(char* row, int c, f32x4 v) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    uint32_t h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3_of(v[e], h[e], m[e], l[e]);
+    char* o = row + (c >> 3) * 48 + (c & 4) * 2;
+    *reinterpret_cast<u32x2*>(o) = u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+    *reinterpret_cast<u32x2*>(o + 16) = u32x2{m[0] | (m[1] << 16), m[2] | (m[3] << 16)};
+    *reinterpret_cast<u32x2*>(o + 32) = u32x2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -262,6 +289,8 @@ int launch_gemm_split3(const GemmArgs& a, int epi, int variant, hipStream_t s);
 int launch_layernorm_split3(const float* x, const float* g, const float* b, void* y_split, int rows, int D, float eps, hipStream_t s);
 int launch_gemm_skinny(const GemmArgs& a, int epi, hipStream_t s);                // gemm_skinny.hip
 int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s);     // attention.hip
+// the same with the output written as a split3 operand [B*192][1280/8][3][8] (the proj GEMM's A in the split3 mode) instead of fp32
+int launch_vit_attention_split3(const float* qkv, void* out_split, int B, hipStream_t s);
 int launch_vit_attention_keysplit(const float* qkv, float* out, int B, hipStream_t s);   // few crops: keys split over the 4 waves
 int launch_vit_attention_variant(const float* qkv, float* out, int B, int variant, hipStream_t s);   // 0 = rule; 1 / 3 / 5 / 12 / 6
 // rowops.hip

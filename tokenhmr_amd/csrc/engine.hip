@@ -475,15 +475,15 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
     const float* lastn_b = e->hot.lastn_b;
     if (e->vit_gemm_mode == 1 && B >= (e->split3_min_b > 0 ? e->split3_min_b : kSplit3MinB)) {
         // The four GEMMs as split3 products on the bf16 matrix pipe (csrc/gemm_split.hip); everything else — patch embed, attention,
-        // LayerNorm arithmetic, epilogues — is the fp32 path's.  A operands: the LayerNorms write their result directly as three bf16
-        // pieces (hs); the attention output and the GELU output are converted by a pass of their own (as, bs).
+        // LayerNorm arithmetic, epilogues — is the fp32 path's.  A operands: the LayerNorms, the attention kernel and fc1's GELU epilogue
+        // write their results directly as three bf16 pieces (hs, bs): no conversion pass, no fp32 copy of those activations.
         char* hs = e->split_act;                                    // [M][1280] split3: LayerNorm / attention output
         char* bs = e->split_act + (size_t)M * DIM * 6;              // [M][5120] split3: GELU output
         auto gemm_s = [&](int cls, const char* A, int K, const char* Wt, const float* bias, const float* resid, float* C, int N, int epi) -> int {
             ProfScope ps(e, st, cls, 2.0 * M * (double)N * K, 6.0 * ((double)M * K + (double)N * K) + 4.0 * M * N * (resid ? 2.0 : 1.0));
             GemmArgs a = mk(reinterpret_cast<const float*>(A), K, reinterpret_cast<const float*>(Wt), K, bias, resid, N, C, N, M, N, K);
             a.qscale = qscale; a.qcols = DIM;
-            return launch_gemm_split3(a, epi, 0, st);
+            return launch_gemm_split3(a, epi, -1, st);
         };
         {
             ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
@@ -494,13 +494,9 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             const thmr_engine::SplitW& ws = e->vitw_s[i];
             const bool last = i + 1 == e->vit_depth;
             LAUNCH_OK(gemm_s(THMR_PROF_GEMM_QKV, hs, DIM, ws.qkv, w.qkvb, nullptr, big, 3 * DIM, EPI_BIAS_QSCALE));
-            {
-                ProfScope ps(e, st, THMR_PROF_ATTN, 4.0 * B * HEADS * 192.0 * 192.0 * 80.0, 4.0 * (4.0 * M * DIM));
-                LAUNCH_OK(launch_vit_attention(big, h, B, st));
-            }
-            {
-                ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
-                LAUNCH_OK(launch_split3(h, DIM, hs, DIM, M, DIM, st));
+            {   // attention, its output written directly as proj's split3 operand
+                ProfScope ps(e, st, THMR_PROF_ATTN, 4.0 * B * HEADS * 192.0 * 192.0 * 80.0, 4.0 * (3.0 * M * DIM) + 6.0 * M * DIM);
+                LAUNCH_OK(launch_vit_attention_split3(big, hs, B, st));
             }
             LAUNCH_OK(gemm_s(THMR_PROF_GEMM_PROJ, hs, DIM, ws.proj, w.pb, x, x, DIM, EPI_BIAS_RESID));
             {
@@ -511,7 +507,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 ProfScope ps(e, st, THMR_PROF_GEMM_FC1, 2.0 * M * DIM * (double)MLP, 6.0 * ((double)M * DIM + (double)DIM * MLP + (double)M * MLP));
                 GemmArgs a = mk(reinterpret_cast<const float*>(hs), DIM, reinterpret_cast<const float*>(ws.fc1), DIM, w.f1b, nullptr, 0, nullptr, 0, M, MLP, DIM);
                 a.c_split = bs; a.ldcs = MLP;
-                LAUNCH_OK(launch_gemm_split3(a, EPI_BIAS_GELU, 0, st));
+                LAUNCH_OK(launch_gemm_split3(a, EPI_BIAS_GELU, -1, st));
             }
             LAUNCH_OK(gemm_s(THMR_PROF_GEMM_FC2, bs, MLP, ws.fc2, w.f2b, x, x, DIM, EPI_BIAS_RESID));
             ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
@@ -1483,6 +1479,13 @@ int thmr_op_vit_attention(const float* qkv, float* out, int32_t B, void* stream)
     thmr_engine* e = nullptr;
     if (!qkv || !out) return fail(e, THMR_ERR_INVALID, "null buffer");
     LAUNCH_OK(launch_vit_attention(qkv, out, B, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int thmr_op_vit_attention_split3(const float* qkv, void* out_split, int32_t B, void* stream) {
+    thmr_engine* e = nullptr;
+    if (!qkv || !out_split || B <= 0) return fail(e, THMR_ERR_INVALID, "bad argument");
+    LAUNCH_OK(launch_vit_attention_split3(qkv, out_split, B, static_cast<hipStream_t>(stream)));
     return 0;
 }
 

@@ -42,13 +42,6 @@ constexpr int SBK = 32;                     // K tile, fp32 elements
 constexpr int SLOTS = SBK / 8 * 3;          // 16-byte chunks per row and K tile
 constexpr int ROWB = SLOTS * 16;            // 192 bytes
 
-// round-to-nearest-even bf16 of x (NaN stays NaN)
-__device__ __forceinline__ uint32_t bf16_rne(float x) {
-    const uint32_t u = __float_as_uint(x);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-
 // X[rows][lds] fp32 -> split3 (row stride ldd fp32-equivalents = 6 ldd bytes); thread = 8 consecutive k of one row
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, int64_t lds_, char* __restrict__ dst, int64_t ldd,
                                                      int64_t rows, int kg) {
@@ -393,12 +386,18 @@ int launch_layernorm_split3(const float* x, const float* g, const float* b, void
 }
 
 // a.A / a.W point at split3 operands (lda / ldw = their row strides in fp32-equivalents, i.e. 6 lda bytes); C, bias, resid are fp32.
-// variant: 0 = 8 waves of 64x64 on 128x256 (default)   1 = 4 waves of 64x128 on 128x256   2 = 4 waves of 64x64 on 128x128
+// variant: -1 = rule below   0 = 8 waves of 64x64 on 128x256   1 = 4 waves of 64x128 on 128x256   2 = 4 waves of 64x64 on 128x128
 int launch_gemm_split3(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % SBK) != 0 || (a.lda % 8) != 0 || (a.ldw % 8) != 0) return -1;
     if (a.lda * 6 * 256 >= (int64_t(1) << 32) || a.ldw * 6 * 256 >= (int64_t(1) << 32)) return -1;     // 32-bit lane offsets within a tile
     if (a.cs_out != nullptr || a.ksplit > 1) return -1;
     if (a.c_split != nullptr && ((a.N % 8) != 0 || (a.ldcs % 8) != 0 || a.ldcs < a.N || epi == EPI_BIAS_RESID)) return -1;
+    if (variant < 0) {
+        // the tiles are bit-identical (same K order per element), so the choice is purely a matter of time: 128 x 256 (8 waves) unless
+        // the whole grid of 128 x 128 tiles still fits one round of 256 CUs — the N = 1280 GEMMs at 16 crops: 240 tiles instead of 120
+        const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+        variant = t128 <= 256 ? 2 : 0;
+    }
     switch (variant) {
         case 0: return launch_split3_cfg<2, 4, 2, 2>(a, epi, s);
         case 1: return launch_split3_cfg<2, 2, 2, 4>(a, epi, s);

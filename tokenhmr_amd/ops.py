@@ -107,6 +107,16 @@ def vit_attention(qkv, variant="auto"):
     return out
 
 
+def vit_attention_split3(qkv):
+    """vit_attention with the output as a split3 operand (int16 (B*192, 160, 3, 8)): what the engine's split3 mode hands the proj GEMM."""
+    _req(qkv)
+    B = qkv.shape[0]
+    out = torch.empty(B * 192, 160, 3, 8, device=qkv.device, dtype=torch.int16)
+    with torch.cuda.device(qkv.device):
+        _cabi.check(_cabi.load().thmr_op_vit_attention_split3(_p(qkv), _p(out), B, _s(qkv)))
+    return out
+
+
 def rot6d_to_rotmat(x):
     _req(x)
     x2 = x.reshape(-1, 6).contiguous()
