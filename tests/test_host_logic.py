@@ -236,17 +236,20 @@ def test_gemm_k_loops_carry_no_valu_instruction(built_lib, tmp_path):
     import shutil
     import subprocess
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    obj = os.path.join(os.path.dirname(_cabi.LIB_PATH), "gemm_f32.o")
-    if not (os.path.exists(objdump) and os.path.exists(obj)):
-        pytest.skip("llvm-objdump or the GEMM object file is not available")
-    work = str(tmp_path / "gemm_f32.o")
-    shutil.copy(obj, work)
-    subprocess.run([objdump, "-d", "--offloading", work], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=str(tmp_path), check=False)
-    cos = glob.glob(work + "*gfx950*")
-    assert cos, "no gfx950 code object inside gemm_f32.o"
-    text = subprocess.run([objdump, "-d", cos[0]], capture_output=True, text=True, check=True).stdout.split("\n")
+    texts = {}
+    for name in ("gemm_f32.o", "gemm_split.o"):
+        obj = os.path.join(os.path.dirname(_cabi.LIB_PATH), name)
+        if not (os.path.exists(objdump) and os.path.exists(obj)):
+            pytest.skip("llvm-objdump or the GEMM object file is not available")
+        work = str(tmp_path / name)
+        shutil.copy(obj, work)
+        subprocess.run([objdump, "-d", "--offloading", work], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=str(tmp_path), check=False)
+        cos = glob.glob(work + "*gfx950*")
+        assert cos, "no gfx950 code object inside " + name
+        texts[name] = subprocess.run([objdump, "-d", cos[0]], capture_output=True, text=True, check=True).stdout.split("\n")
 
-    def k_loop(symbol_re, min_mfma):
+    def k_loop(name, symbol_re, min_mfma):
+        text = texts[name]
         start = [i for i, l in enumerate(text) if re.match(r"^[0-9a-f]+ <.*" + symbol_re, l)]
         assert start, symbol_re
         end = next(i for i in range(start[0], len(text)) if "s_endpgm" in text[i])
@@ -271,8 +274,11 @@ def test_gemm_k_loops_carry_no_valu_instruction(built_lib, tmp_path):
         assert loops, "no MFMA loop found in " + symbol_re
         return min(loops, key=len)                      # the innermost loop with that many MFMAs
 
-    for sym, min_mfma in ((r"gemm_f32_kernelILi4ELi1ELi1ELi5ELb1ELi2", 160), (r"gemm_ring_kernelILi4ELi5ELb0", 64)):
-        seg = k_loop(sym, min_mfma)
+    # ... and the split3 GEMM (gemm_split.hip: bf16 MFMAs, whose issue slots are half as long): default tile, fc1 epilogue and the plain one
+    for name, sym, min_mfma in (("gemm_f32.o", r"gemm_f32_kernelILi4ELi1ELi1ELi5ELb1ELi2", 160), ("gemm_f32.o", r"gemm_ring_kernelILi4ELi5ELb0", 64),
+                                ("gemm_split.o", r"gemm_split3_kernelILi2ELi4ELi2ELi2ELi2ELi0ELi0E", 96),
+                                ("gemm_split.o", r"gemm_split3_kernelILi2ELi4ELi2ELi2ELi4ELi0ELi0E", 96)):
+        seg = k_loop(name, sym, min_mfma)
         valu = [op for _, op, _ in seg if op.startswith("v_") and not op.startswith("v_mfma")]
         dma = [(op, args) for _, op, args in seg if op.startswith("global_load_lds")]
         assert not valu, (sym, valu[:8])
@@ -310,6 +316,7 @@ def test_attention_lds_dma_copies_keep_their_m0(built_lib, tmp_path):
     text = subprocess.run([objdump, "-d", cos[0]], capture_output=True, text=True, check=True).stdout.split("\n")
     starts = [i for i, l in enumerate(text) if re.match(r"^[0-9a-f]+ <.*vit_attention_(persistent_)?kernel", l)]
     assert len(starts) >= 3 and any("persistent" in text[i] for i in starts)
+    assert sum(1 for i in starts if "persistent" in text[i]) == 2          # the fp32-output and the split3-output instantiation
     for st in starts:
         end = next(i for i in range(st, len(text)) if "s_endpgm" in text[i])
         ins = []
@@ -328,11 +335,14 @@ def test_attention_lds_dma_copies_keep_their_m0(built_lib, tmp_path):
             # waits with vmcnt(30) for the K' copies, i.e. it RELIES on exactly 15 output stores + 15 Q' loads being the only younger
             # operations of the wave.  Fewer (a toolchain that merges stores, or spill traffic moved elsewhere) would make the wait too
             # weak: check the instruction stream between the last copy and that wait, and that the kernel has no scratch traffic.
-            w30 = [i for i, (op, a) in enumerate(ins) if op == "s_waitcnt" and a.replace(" ", "") == "vmcnt(30)"]
+            # The SPLIT instantiation (output as a split3 operand: three 8-byte stores per tile) waits with vmcnt(60) for 45 stores + 15 loads.
+            split = "Lb1E" in text[st]
+            n_wait, store_op, n_stores = (60, "global_store_dwordx2", 45) if split else (30, "global_store_dwordx4", 15)
+            w30 = [i for i, (op, a) in enumerate(ins) if op == "s_waitcnt" and a.replace(" ", "") == f"vmcnt({n_wait})"]
             assert len(w30) == 1, [a for op, a in ins if op == "s_waitcnt" and "vmcnt" in a]
             last_dma = max(i for i in dma if i < w30[0])
             between = [op for op, _ in ins[last_dma + 1:w30[0]]]
-            assert between.count("global_store_dwordx4") == 15 and between.count("global_load_dwordx4") == 15, between
-            assert not any(op.startswith(("global_", "buffer_", "scratch_", "flat_")) and op not in ("global_store_dwordx4", "global_load_dwordx4")
+            assert between.count(store_op) == n_stores and between.count("global_load_dwordx4") == 15, between
+            assert not any(op.startswith(("global_", "buffer_", "scratch_", "flat_")) and op not in (store_op, "global_load_dwordx4")
                            for op in between), between
             assert not any(op.startswith("scratch_") for op, _ in ins), "register spills in the persistent attention kernel"
