@@ -30,7 +30,8 @@ extern "C" {
 /* 2 (round 3): thmr_smpl_desc.reserved became update_hips (a round-1 host that left it uninitialised would get the hip shift at
  * random); the resample tables / padding row / flag words of the weight arena are written by thmr_load_weights on the LOADING
  * engine (round 1: thmr_create on every engine; round 2: thmr_finalize_weights(0)) and validated — not written — by
- * thmr_finalize_weights(assume_all_loaded = 1). */
+ * thmr_finalize_weights(assume_all_loaded = 1).
+ * 3 (round 3): thmr_set_vit_gemm / thmr_get_vit_gemm and the split3 operators added (no struct changed). */
 #define THMR_ABI_VERSION 3
 
 typedef enum {
@@ -197,14 +198,16 @@ int thmr_op_gemm(const float* A_dev, int64_t lda, const float* W_dev, const floa
  * down to 2^-16 of |a b| (what is dropped is below one fp32 rounding of the product), accumulation is fp32 in the MFMA.
  * thmr_op_split3 converts (K % 8 == 0, ld_dst % 8 == 0, ld_dst >= K, ld_src % 4 == 0).  thmr_op_gemm_split3: A / W split3 with row
  * strides lda / ldw in fp32-equivalents (multiples of 8), K % 32 == 0; bias / resid / C fp32; epi 0, 1, 2, 4, 5 as thmr_op_gemm;
- * variant 0 = 128x256 tile, 8 waves (default); 1 = 128x256, 4 waves; 2 = 128x128, 4 waves (3, 31, 32, 34, 37: schedule experiments
- * of scripts/split3_bench.py, epilogue 0 only; 31-37 are timing-only and return garbage). */
+ * variant -1 = the engine's rule; 0 = 128x256 tile, 8 waves; 1 = 128x256, 4 waves; 2 = 128x128, 4 waves (bit-identical to each
+ * other); 100 + j = the small-M ring kernel (64x64 tiles, 4-deep LDS-DMA ring) with split-K 2^j, j <= 2 — 100 is bit-identical to the big
+ * tiles, the split ones associate K differently; (3, 31, 32, 34, 37: schedule experiments of scripts/split3_bench.py, epilogue 0 only;
+ * 31-37 are timing-only and return garbage). */
 int thmr_op_split3(const float* src_dev, int64_t ld_src, void* dst_dev, int64_t ld_dst, int64_t rows, int32_t K, void* stream);
 int thmr_op_gemm_split3(const void* A_split_dev, int64_t lda, const void* W_split_dev, int64_t ldw, const float* bias_dev,
                         const float* resid_dev, float* C_dev, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi,
                         float qscale, int32_t qcols, int32_t variant, void* stream);
 /* the same product with the epilogue's result written as a split3 operand (the next GEMM's A; row stride 6 * ldcs bytes, N % 8 == 0,
- * ldcs % 8 == 0) instead of fp32: bit-identical to thmr_op_split3 of thmr_op_gemm_split3's output.  epi 0, 1, 2, 5. */
+ * ldcs % 8 == 0) instead of fp32: bit-identical to thmr_op_split3 of thmr_op_gemm_split3's output.  epi 0, 1, 2, 5; variant -1, 0, 1, 2 or 100 (the ring kernel). */
 int thmr_op_gemm_split3_out_split3(const void* A_split_dev, int64_t lda, const void* W_split_dev, int64_t ldw, const float* bias_dev,
                                    void* C_split_dev, int64_t ldcs, int32_t M, int32_t N, int32_t K, int32_t epi, float qscale,
                                    int32_t qcols, int32_t variant, void* stream);

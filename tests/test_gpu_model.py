@@ -228,8 +228,8 @@ def _check_b64_golden(out, g, tag):
 def test_vit_gemm_split3_mode(built_lib, cuda_dev):
     """thmr_set_vit_gemm: the split3 mode (ViT GEMMs on the bf16 matrix pipe, fp32 operands as three bf16 pieces) against the exact-fp32
     mode of the SAME engine and against the oracle: fp32-rounding-close features, equal token indices away from near-ties, vertices
-    within 0.1 mm; deterministic; a crop's result does not depend on the batch it rides in (>= 17 crops); below 17 crops the mode
-    changes nothing (bit-identical to the exact-fp32 path); switching back restores the exact-fp32 results bit for bit."""
+    within 0.1 mm; deterministic; a crop's result does not depend on the batch it rides in (>= 16 crops); below 16
+    crops the mode changes nothing (bit-identical to the exact-fp32 path); switching back restores the exact-fp32 results bit for bit."""
     from oracle import tokenhmr_oracle as O
     from tokenhmr_amd.config import HMRConfig
     from tokenhmr_amd.model import TokenHMR
@@ -240,6 +240,7 @@ def test_vit_gemm_split3_mode(built_lib, cuda_dev):
     img = _inputs(24, seed=5).to(cuda_dev)
     f32 = _to_cpu(model({"img": img[:20]}))
     f32_small = _to_cpu(model({"img": img[:5]}))
+    f32_mid = _to_cpu(model({"img": img[:9]}))
     model.engine.set_vit_gemm("split3")
     assert model.engine.vit_gemm() == "split3"
     s3 = _to_cpu(model({"img": img[:20]}))
@@ -247,10 +248,13 @@ def test_vit_gemm_split3_mode(built_lib, cuda_dev):
     again = _to_cpu(model({"img": img[:20]}))
     s3_24 = _to_cpu(model({"img": img}))
     s3_small = _to_cpu(model({"img": img[:5]}))
+    s3_mid = _to_cpu(model({"img": img[:9]}))
     for k in ("pred_vertices", "cls_logits", "vit_features"):
         assert torch.equal(s3[k], again[k]), k                                  # deterministic
         assert torch.equal(s3[k], s3_24[k][:20]), k                             # batch-independent
-        assert torch.equal(s3_small[k], f32_small[k]), k                        # under 17 crops: the exact-fp32 kernels
+    for k in ("pred_vertices", "cls_logits", "vit_features"):
+        assert torch.equal(s3_mid[k], f32_mid[k]), k                            # under 16 crops: the exact-fp32 kernels whatever the mode
+        assert torch.equal(s3_small[k], f32_small[k]), k
     assert not torch.equal(s3["vit_features"], f32["vit_features"])            # the mode really ran
     assert (s3["vit_features"] - f32["vit_features"]).abs().max() < 2e-4
     assert (s3["pred_vertices"] - f32["pred_vertices"]).abs().max() < 1e-4 and (s3["cls_logits"] - f32["cls_logits"]).abs().max() < 1e-3

@@ -202,13 +202,13 @@ def test_split3_convert(built_lib, cuda_dev):
     assert np.all(np.abs(back - xd)[ok] <= np.abs(xd)[ok] * 2.0 ** -24)
 
 
-@pytest.mark.parametrize("B", [1, 3, 16, 20, 30])
+@pytest.mark.parametrize("B", [1, 2, 3, 16, 20, 30])
 def test_vit_attention_split3_output(built_lib, cuda_dev, B):
-    """Attention with its output written as the proj GEMM's split3 operand (64-query kernel up to 10 and for 17-24 crops, persistent
-    kernel otherwise — with its own vmcnt bookkeeping for 45 instead of 15 stores per item): bit-identical to converting the fp32 output."""
+    """Attention with its output written as the proj GEMM's split3 operand (key-split kernel for one and two crops, 64-query kernel up to 10
+    and for 17-24 crops, persistent kernel otherwise — with its own vmcnt bookkeeping for 45 instead of 15 stores per item): bit-identical to converting the fp32 output."""
     from tokenhmr_amd import ops
     qkv = _rand(B, 192, 3840, seed=B).to(cuda_dev)
-    ref = ops.split3(ops.vit_attention(qkv).reshape(B * 192, 1280))
+    ref = ops.split3(ops.vit_attention(qkv, variant="keysplit" if B <= 2 else "auto").reshape(B * 192, 1280))
     got = ops.vit_attention_split3(qkv)
     assert torch.equal(got, ref)
     assert torch.equal(got, ops.vit_attention_split3(qkv))
@@ -243,8 +243,23 @@ def test_gemm_split3(built_lib, cuda_dev, shape):
             ref = _gemm_ref(a, w, b, r, epi, kw.get("qscale", 1.0), kw.get("qcols", 0))
             assert torch.allclose(o.cpu(), ref, atol=2e-4, rtol=1e-5), (variant, epi, (o.cpu() - ref).abs().max())
     assert torch.equal(outs["128x256/w4"], outs["128x256/w8"]) and torch.equal(outs["128x128/w4"], outs["128x256/w8"])
+    # the small-M ring kernel: without split-K bit-identical to the big tiles (same K order per element); with split-K another association
+    ring = ops.gemm_split3(sa, sw, variant="ring")
+    assert torch.equal(ring, outs["128x256/w8"]) and torch.equal(ops.gemm_split3(sa, sw, variant="auto"), outs["128x256/w8"])
+    for epi, kw in (("bias", {}), ("bias_gelu", {}), ("bias_resid", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
+        o = ops.gemm_split3(sa, sw, db, dr if epi == "bias_resid" else None, epi=epi, variant="ring", **kw)
+        assert torch.equal(o, ops.gemm_split3(sa, sw, db, dr if epi == "bias_resid" else None, epi=epi, variant="128x256/w8", **kw)), epi
+    for ks, name in ((2, "ring/k2"), (4, "ring/k4")):
+        if K % (32 * ks):
+            continue
+        o = ops.gemm_split3(sa, sw, db, dr, epi="bias_resid", variant=name)
+        assert torch.allclose(o.cpu(), _gemm_ref(a, w, b, r, "bias_resid", 1.0, 0), atol=2e-4, rtol=1e-5), name
+        assert torch.equal(o, ops.gemm_split3(sa, sw, db, dr, epi="bias_resid", variant=name))
+        if M > 2:
+            half = ops.gemm_split3(ops.split3(da[:M // 2].contiguous()), sw, db, dr[:M // 2].contiguous(), epi="bias_resid", variant=name)
+            assert torch.equal(half, o[:M // 2]), name
     if N % 8 == 0:      # the epilogue's result as the next GEMM's split3 operand: bit-identical to converting the fp32 result
-        for variant in ("128x256/w8", "128x256/w4", "128x128/w4"):
+        for variant in ("128x256/w8", "128x256/w4", "128x128/w4", "ring"):
             for epi, kw in (("none", {}), ("bias", {}), ("bias_gelu", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
                 bb = None if epi == "none" else db
                 fused = ops.gemm_split3(sa, sw, bb, epi=epi, variant=variant, out_split=True, **kw)

@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void vit_attention_persistent_kernel(const 
 // QT = 16-query tiles per workgroup (1, 2, 3): every query is computed by the same instruction sequence whatever QT, so the
 // variants are bit-identical and the choice per batch size is free.  QT = 1 has the shortest chain (one crop: 192 workgroups);
 // larger QT re-reads K / V less often (12 / QT workgroups per (crop, head) each fetch all of K and V).
-template <int QT>
+template <int QT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void vit_attention_keysplit_kernel(const float* __restrict__ qkv, float* __restrict__ out) {
     constexpr int OS = 84;                                   // row stride of the partial-output tile in LDS (floats)
     constexpr int QB = 12 / QT;                              // workgroups per (crop, head)
@@ -647,6 +647,27 @@ __global__ __launch_bounds__(256) void vit_attention_keysplit_kernel(const float
         for (int dt = 0; dt < 5; ++dt) *reinterpret_cast<f32x4*>(&so[wave][qt * 16 + l15][dt * 16 + g * 4]) = o[qt][dt];
     }
     __syncthreads();
+    if constexpr (SPLIT) {
+        // the same merge, four consecutive d per thread, written as the 8-byte halves of the three split3 chunks (out = split3 operand)
+        for (int idx = tid; idx < 16 * QT * (HD / 4); idx += 256) {
+            const int q = idx / (HD / 4), d = (idx - q * (HD / 4)) * 4;
+            const float M = fmaxf(fmaxf(sm[0][q], sm[1][q]), fmaxf(sm[2][q], sm[3][q]));
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            float L = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float a = __builtin_amdgcn_exp2f((sm[w][q] - M) * LOG2E);
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(&so[w][q][d]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(pv[e], a, acc[e]);
+                L = fmaf(sl[w][q], a, L);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = acc[e] / L;
+            store_split3_quad(reinterpret_cast<char*>(out) + ((int64_t)b * NTOK + q0 + q) * (DIM * 6), h * HD + d, acc);
+        }
+        return;
+    }
     // merge the four partial results in wave order; 16 QT queries x 80 outputs, 5 QT per thread, consecutive threads = consecutive d
 #pragma unroll
     for (int jj = 0; jj < 5 * QT; ++jj) {
@@ -682,11 +703,19 @@ int launch_vit_attention_variant(const float* qkv, float* out, int B, int varian
 
 int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s) { return launch_vit_attention_variant(qkv, out, B, 0, s); }
 
-// split3 output (the engine's split3 mode, 16 crops and more): the batch-size rule of launch_vit_attention_variant's kernels 1 and 5
+// split3 output (the engine's split3 mode): the engine's batch-size rule — key-split kernel for one and two crops, else kernels 1 / 5
 int launch_vit_attention_split3(const float* qkv, void* out_split, int B, hipStream_t s) {
     if (B <= 0) return -1;
     float* out = reinterpret_cast<float*>(out_split);
     const AttnDbg nodbg{nullptr, 0, 0};
+    if (B == 1) {
+        hipLaunchKernelGGL((vit_attention_keysplit_kernel<1, true>), dim3(B * NH * 12), dim3(256), 0, s, qkv, out);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    if (B == 2) {
+        hipLaunchKernelGGL((vit_attention_keysplit_kernel<2, true>), dim3(B * NH * 6), dim3(256), 0, s, qkv, out);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (B <= 10 || (B >= 17 && B <= 24)) {
         hipLaunchKernelGGL((vit_attention_kernel<1, 4, 0, true>), dim3(B * NH * 3), dim3(256), 0, s, qkv, out, nodbg);
     } else {

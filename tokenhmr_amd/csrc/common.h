@@ -285,6 +285,8 @@ int launch_gemm_ring16(const GemmArgs& a, int epi, hipStream_t s);              
 // gemm_split.hip: fp32 -> three bf16 pieces ("split3"), and the GEMM over split3 operands on the bf16 matrix pipe (a.A / a.W = split3)
 int launch_split3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int K, hipStream_t s);
 int launch_gemm_split3(const GemmArgs& a, int epi, int variant, hipStream_t s);
+// small-M split3 GEMM (64x64 tiles, LDS-DMA ring, optional split-K into part[ksplit][M][N] without epilogue)
+int launch_gemm_split3_ring(const GemmArgs& a, int epi, int ksplit, float* part, hipStream_t s);
 // LayerNorm (D = 1280) whose result is written as a split3 operand [rows][D/8][3][8] instead of fp32 (same arithmetic as launch_layernorm)
 int launch_layernorm_split3(const float* x, const float* g, const float* b, void* y_split, int rows, int D, float eps, hipStream_t s);
 int launch_gemm_skinny(const GemmArgs& a, int epi, hipStream_t s);                // gemm_skinny.hip
@@ -298,7 +300,7 @@ int launch_layernorm(const float* x, const float* g, const float* b, float* y, i
                      hipStream_t s);
 int launch_splitk_epilogue(const GemmArgs& a, int epi, const float* part, int S, hipStream_t s);
 int launch_splitk_resid_ln(const float* part, int S, int rows, int D, const float* bias, const float* resid, float* xout,
-                           const float* gamma, const float* beta, float* y, float eps, hipStream_t s);
+                           const float* gamma, const float* beta, float* y, float eps, hipStream_t s, bool y_is_split3 = false);
 int launch_add_ln64(const float* x, const float* y, const float* g, const float* b, float* s_out, float* z_out, int rows,
                     float eps, hipStream_t s);
 int launch_im2col_patch(const float* img, float* A, int B, hipStream_t s);

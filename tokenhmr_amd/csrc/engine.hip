@@ -98,6 +98,7 @@ struct thmr_engine {
     // carried as three bf16 pieces (csrc/gemm_split.hip).  Engine-owned memory: the split3 copies of the ViT weights (1.5 x their fp32
     // size) and the split3 activation operands (M x (1280 + 5120) x 6 bytes).  Off (0) = exact-fp32 MFMA everywhere, the default.
     int vit_gemm_mode = 0;
+    bool split3_small = false;        // THMR_SPLIT3_SMALL=1: the split3 mode also serves up to six crops (ring kernel on split3 operands) — measured SLOWER, A/B only
     int split3_min_b = 0;             // THMR_SPLIT3_MIN_B=<n>: A/B knob for the smallest batch the split3 mode serves (0 = kSplit3MinB)
     char* split_w = nullptr;
     char* split_act = nullptr;
@@ -513,6 +514,65 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
             if (last) LAUNCH_OK(launch_layernorm(x, lastn_w, lastn_b, feats_out ? feats_out : h, M, DIM, VIT_EPS, 0, st));
             else LAUNCH_OK(launch_layernorm_split3(x, e->vitw[i + 1].n1w, e->vitw[i + 1].n1b, hs, M, DIM, VIT_EPS, st));
+        }
+        return 0;
+    }
+    if (e->vit_gemm_mode == 1 && small && e->split3_small) {
+        // EXPERIMENT (THMR_SPLIT3_SMALL=1, off by default): a small-batch regime (up to six crops) of the split3 mode — the ring kernel
+        // on split3 operands (64 x 64 tiles, 4-deep LDS-DMA ring; proj / fc2 split K four ways into `part`, reduced by the residual +
+        // LayerNorm kernel as in the fp32 regime), producers writing split3 operands directly.  A wave's MFMA chain per K tile shrinks from
+        // 16 x 64 to 12 x 32 cycles, but the call gets SLOWER: 4.28 vs 3.89 ms at one crop, 6.88 vs 5.84 at two, 16.3 vs 14.1 at six
+        // (profiles/r3y_split3_small_batch_regime_ab.log).  At these sizes the GEMMs are bound by the bytes a CU can keep in flight
+        // (three 24 KB stages) against a ~4 us loaded memory round trip, not by the matrix pipe, and split3 operands are 1.5x the bytes.
+        char* hs = e->split_act;
+        char* bs = e->split_act + (size_t)M * DIM * 6;
+        auto sgemm = [&](const char* A, int K, const char* Wt, const float* bias, float* C, int N) {
+            return mk(reinterpret_cast<const float*>(A), K, reinterpret_cast<const float*>(Wt), K, bias, nullptr, 0, C, N, M, N, K);
+        };
+        {
+            ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
+            LAUNCH_OK(launch_layernorm_split3(x, e->vitw[0].n1w, e->vitw[0].n1b, hs, M, DIM, VIT_EPS, st));
+        }
+        for (int i = 0; i < e->vit_depth; ++i) {
+            const VitBlockW& w = e->vitw[i];
+            const thmr_engine::SplitW& ws = e->vitw_s[i];
+            const bool last = i + 1 == e->vit_depth;
+            {
+                ProfScope ps(e, st, THMR_PROF_GEMM_QKV, 2.0 * M * DIM * 3.0 * DIM, 6.0 * ((double)M * DIM + 3.0 * DIM * DIM) + 12.0 * M * DIM);
+                GemmArgs a = sgemm(hs, DIM, ws.qkv, w.qkvb, big, 3 * DIM);
+                a.qscale = qscale; a.qcols = DIM;
+                LAUNCH_OK(launch_gemm_split3_ring(a, EPI_BIAS_QSCALE, 1, nullptr, st));
+            }
+            {
+                ProfScope ps(e, st, THMR_PROF_ATTN, 4.0 * B * HEADS * 192.0 * 192.0 * 80.0, 4.0 * (3.0 * M * DIM) + 6.0 * M * DIM);
+                LAUNCH_OK(launch_vit_attention_split3(big, hs, B, st));
+            }
+            {
+                ProfScope ps(e, st, THMR_PROF_GEMM_PROJ, 2.0 * M * DIM * (double)DIM, 6.0 * ((double)M * DIM + (double)DIM * DIM) + 4.0 * kSplitKMax * M * DIM);
+                GemmArgs a = sgemm(hs, DIM, ws.proj, nullptr, x, DIM);
+                LAUNCH_OK(launch_gemm_split3_ring(a, EPI_NONE, kSplitKMax, part, st));
+            }
+            {
+                ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (kSplitKMax + 2.0) * M * DIM + 6.0 * M * DIM);
+                LAUNCH_OK(launch_splitk_resid_ln(part, kSplitKMax, M, DIM, w.pb, x, x, w.n2w, w.n2b, reinterpret_cast<float*>(hs), VIT_EPS, st, true));
+            }
+            {
+                ProfScope ps(e, st, THMR_PROF_GEMM_FC1, 2.0 * M * DIM * (double)MLP, 6.0 * ((double)M * DIM + (double)DIM * MLP + (double)M * MLP), (i & 3) == 0);
+                GemmArgs a = sgemm(hs, DIM, ws.fc1, w.f1b, nullptr, MLP);
+                a.c_split = bs; a.ldcs = MLP;
+                LAUNCH_OK(launch_gemm_split3_ring(a, EPI_BIAS_GELU, 1, nullptr, st));
+            }
+            {
+                ProfScope ps(e, st, THMR_PROF_GEMM_FC2, 2.0 * M * DIM * (double)MLP, 6.0 * ((double)M * MLP + (double)DIM * MLP) + 4.0 * kSplitKMax * M * DIM);
+                GemmArgs a = sgemm(bs, MLP, ws.fc2, nullptr, x, DIM);
+                LAUNCH_OK(launch_gemm_split3_ring(a, EPI_NONE, kSplitKMax, part, st));
+            }
+            ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (kSplitKMax + 3.0) * M * DIM);
+            if (last)
+                LAUNCH_OK(launch_splitk_resid_ln(part, kSplitKMax, M, DIM, w.f2b, x, x, lastn_w, lastn_b, feats_out ? feats_out : h, VIT_EPS, st));
+            else
+                LAUNCH_OK(launch_splitk_resid_ln(part, kSplitKMax, M, DIM, w.f2b, x, x, e->vitw[i + 1].n1w, e->vitw[i + 1].n1b,
+                                                 reinterpret_cast<float*>(hs), VIT_EPS, st, true));
         }
         return 0;
     }
@@ -975,6 +1035,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* tg = getenv("THMR_TINY_GEMM"); e->tiny_gemm = !(tg && tg[0] == '0'); }
     { const char* qr = getenv("THMR_QKV_RING16"); e->qkv_ring16 = !(qr && qr[0] == '0'); }
     { const char* ak = getenv("THMR_ATTN_KEYSPLIT"); e->attn_keysplit = !(ak && ak[0] == '0'); }
+    { const char* ss = getenv("THMR_SPLIT3_SMALL"); e->split3_small = ss && ss[0] == '1'; }
     { const char* sm = getenv("THMR_SPLIT3_MIN_B"); e->split3_min_b = sm ? atoi(sm) : 0; }
     { const char* ms = getenv("THMR_MID_SPLIT"); if (ms && ms[0] && ms[1]) { e->mid_split_force[0] = ms[0] - '0'; e->mid_split_force[1] = ms[1] - '0'; } }
     { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
@@ -1441,11 +1502,39 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
     if (epi == EPI_BIAS_RESID && !resid) return fail(e, THMR_ERR_INVALID, "epilogue needs resid");
     if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || ldc < N)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: K % 32 == 0, lda / ldw multiples of 8 and >= K, ldc >= N");
-    if (!(variant >= 0 && variant <= 3) && variant != 31 && variant != 32 && variant != 34 && variant != 37)
-        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant 0, 1, 2 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
+    if (!(variant >= -1 && variant <= 3) && variant != 31 && variant != 32 && variant != 34 && variant != 37 && !(variant >= 100 && variant <= 102))
+        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 1, 2, 100-102 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, resid, ldc, C, ldc, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
-    LAUNCH_OK(launch_gemm_split3(a, epi, variant, static_cast<hipStream_t>(stream)));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (variant >= 100) {
+        // small-M ring kernel, split-K 2^(variant - 100); partial sums in a grow-only workspace per (device, stream), then the fixed-order
+        // reduce + epilogue (the engine fuses that into its residual + LayerNorm kernel)
+        const int ksplit = 1 << (variant - 100);
+        if ((K % (32 * ksplit)) != 0) return fail(e, THMR_ERR_INVALID, "split3 ring GEMM: K must be a multiple of 32 * ksplit");
+        float* ws = nullptr;
+        static std::mutex mu3;
+        static std::map<std::pair<int, void*>, std::pair<float*, size_t>> pool3;
+        std::unique_lock<std::mutex> lk(mu3, std::defer_lock);
+        if (ksplit > 1) {
+            int dev = 0;
+            HIP_OK(hipGetDevice(&dev));
+            lk.lock();
+            auto& slot = pool3[{dev, stream}];
+            const size_t need = (size_t)ksplit * M * N;
+            if (need > slot.second) {
+                if (slot.first) { HIP_OK(hipDeviceSynchronize()); HIP_OK(hipFree(slot.first)); slot = {nullptr, 0}; }
+                float* p = nullptr;
+                HIP_OK(hipMalloc(&p, need * sizeof(float)));
+                slot = {p, need};
+            }
+            ws = slot.first;
+        }
+        LAUNCH_OK(launch_gemm_split3_ring(a, epi, ksplit, ws, st));
+        if (ksplit > 1) LAUNCH_OK(launch_splitk_epilogue(a, epi, ws, ksplit, st));
+        return 0;
+    }
+    LAUNCH_OK(launch_gemm_split3(a, epi, variant, st));
     return 0;
 }
 
@@ -1459,11 +1548,12 @@ int thmr_op_gemm_split3_out_split3(const void* A, int64_t lda, const void* W, in
     if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || (N % 8) != 0 ||
         (ldcs % 8) != 0 || ldcs < N)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: K % 32 == 0, N % 8 == 0, lda / ldw / ldcs multiples of 8 and >= K / K / N");
-    if (variant < 0 || variant > 2) return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant 0, 1 or 2");
+    if ((variant < -1 || variant > 2) && variant != 100) return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 1, 2 or 100 (small-M ring kernel)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, nullptr, 0, nullptr, 0, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
     a.c_split = Cs; a.ldcs = ldcs;
-    LAUNCH_OK(launch_gemm_split3(a, epi, variant, static_cast<hipStream_t>(stream)));
+    if (variant == 100) LAUNCH_OK(launch_gemm_split3_ring(a, epi, 1, nullptr, static_cast<hipStream_t>(stream)));
+    else LAUNCH_OK(launch_gemm_split3(a, epi, variant, static_cast<hipStream_t>(stream)));
     return 0;
 }
 

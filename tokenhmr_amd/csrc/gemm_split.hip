@@ -120,8 +120,65 @@ __global__ __launch_bounds__(256) void ln_split3_kernel(const float* __restrict_
     }
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 __device__ __forceinline__ uint32_t lds_addr_b(const char* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+// The epilogue's result as the NEXT GEMM's split3 operand (GemmArgs::c_split).  The MFMA leaves a lane with one column and 16 rows; a
+// split3 chunk is 8 consecutive columns of one row, so the wave tile is transposed through LDS (T: wave-private, TM*32 rows of
+// WT = 32 TN + 4 floats, in stage buffers that are dead by now): lane (row r, column group q) reads 8 consecutive columns, applies bias +
+// activation, splits and writes 48 contiguous bytes; the 4 TN lanes of a row write 192 TN contiguous bytes.
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void store_tile_split3(const GemmArgs& a, f32x16 (&acc)[TM][TN], float* T, int m0, int n0, int lane) {
+    constexpr int WT = TN * 32 + 4;
+    constexpr int GQ = TN * 4;                                     // column groups of 8 per wave-tile row
+    constexpr int RP = 64 / GQ;                                    // rows per pass
+    const int lrow = lane & 31, lhalf = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                T[(mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf) * WT + ni * 32 + lrow] = acc[mi][ni][e];
+    const int q = lane % GQ, r0 = lane / GQ;
+    const int n = n0 + q * 8;
+    float bias[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) bias[u] = (EPI != EPI_NONE && n + u < a.N) ? a.bias[n + u] : 0.f;
+    char* obase = reinterpret_cast<char*>(a.c_split) + (int64_t)(n >> 3) * 48;
+#pragma unroll
+    for (int ps = 0; ps < TM * 32 / RP; ++ps) {
+        const int r = r0 + ps * RP, m = m0 + r;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + r * WT + q * 8);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + r * WT + q * 8 + 4);
+        float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                const f32x2 gl = gelu_erf2(f32x2{v[u] + bias[u], v[u + 1] + bias[u + 1]});
+                v[u] = gl.x;
+                v[u + 1] = gl.y;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = gemm_epilogue<EPI>(a, v[u], bias[u], min(m, a.M - 1), min(n + u, a.N - 1));
+        }
+        uint32_t h[8], mm[8], l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) split3_of(v[u], h[u], mm[u], l[u]);
+        if (m < a.M && n < a.N) {
+            u32x4* o = reinterpret_cast<u32x4*>(obase + (int64_t)m * a.ldcs * 6);
+            o[0] = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+            o[1] = u32x4{mm[0] | (mm[1] << 16), mm[2] | (mm[3] << 16), mm[4] | (mm[5] << 16), mm[6] | (mm[7] << 16)};
+            o[2] = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+        }
+    }
 }
 
 // the six piece pairs (A piece, W piece) kept, smallest terms first: lh hl mm mh hm hh
@@ -277,66 +334,138 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split3_kernel(GemmArgs a, i
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no LDS-DMA write may outlive the workgroup's LDS allocation
 
-    if (a.c_split) {                        // wave-uniform
-        // The epilogue's result as the NEXT GEMM's split3 operand.  The MFMA leaves a lane with one column and 16 rows; a split3 chunk
-        // is 8 consecutive columns of one row, so the wave tile is transposed through LDS (the stage buffers are dead by now): fp32
-        // tile, row stride WT = 32 TN + 4 floats, then lane (row r, column group q) reads 8 consecutive columns, applies bias +
-        // activation, splits and writes 48 contiguous bytes; the TN * 4 lanes of a row write 192 TN contiguous bytes.
+    if (a.c_split) {                        // wave-uniform: the result as the next GEMM's split3 operand
         constexpr int WT = TN * 32 + 4;
-        constexpr int GQ = TN * 4;                                     // column groups of 8 per wave-tile row
-        constexpr int RP = 64 / GQ;                                    // rows per pass
         static_assert(NW * TM * 32 * WT * 4 <= 2 * (A_STAGE + B_STAGE), "transpose tile does not fit the stage buffers");
         __syncthreads();                                               // every wave is done reading the stage buffers
-        float* T = reinterpret_cast<float*>(smem) + wave * (TM * 32 * WT);
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    T[(mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf) * WT + ni * 32 + lrow] = acc[mi][ni][e];
-        const int q = lane % GQ, r0 = lane / GQ;
-        const int n = bn0 + wn0 + q * 8;
-        float bias[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) bias[u] = (EPI != EPI_NONE && n + u < a.N) ? a.bias[n + u] : 0.f;
-        char* obase = reinterpret_cast<char*>(a.c_split) + (int64_t)(n >> 3) * 48;
-#pragma unroll
-        for (int ps = 0; ps < TM * 32 / RP; ++ps) {
-            const int r = r0 + ps * RP, m = bm0 + wm0 + r;
-            const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + r * WT + q * 8);
-            const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + r * WT + q * 8 + 4);
-            float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-            if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                for (int u = 0; u < 8; u += 2) {
-                    const f32x2 gl = gelu_erf2(f32x2{v[u] + bias[u], v[u + 1] + bias[u + 1]});
-                    v[u] = gl.x;
-                    v[u + 1] = gl.y;
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = gemm_epilogue<EPI>(a, v[u], bias[u], min(m, a.M - 1), min(n + u, a.N - 1));
-            }
-            uint32_t h[8], mm[8], l[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                h[u] = bf16_rne(v[u]);
-                const float r1 = v[u] - __uint_as_float(h[u] << 16);
-                mm[u] = bf16_rne(r1);
-                const float r2 = r1 - __uint_as_float(mm[u] << 16);
-                l[u] = bf16_rne(r2);
-            }
-            if (m < a.M && n < a.N) {
-                u32x4* o = reinterpret_cast<u32x4*>(obase + (int64_t)m * a.ldcs * 6);
-                o[0] = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-                o[1] = u32x4{mm[0] | (mm[1] << 16), mm[2] | (mm[3] << 16), mm[4] | (mm[5] << 16), mm[6] | (mm[7] << 16)};
-                o[2] = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
-            }
-        }
+        store_tile_split3<TM, TN, EPI>(a, acc, reinterpret_cast<float*>(smem) + wave * (TM * 32 * WT), bm0 + wm0, bn0 + wn0, lane);
         return;
     }
     store_tile<TM, TN, EPI>(a, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Small-M split3 GEMM (few crops: the engine's split3 mode up to six crops) — the ring kernel of gemm_f32.hip on split3 operands:
+// 64 x 64 tiles (2 x 2 waves of 32 x 32), ST-deep LDS ring of 24 KB stages fed by global_load_lds whose completion is tracked with
+// s_waitcnt vmcnt(N), ONE barrier per 32-deep K tile in the middle of its 12 MFMAs, optional split-K into part[ksplit][M][N] (raw fp32
+// partial tiles, summed in a fixed order by the residual + LayerNorm kernel that follows proj / fc2 anyway).  Per element K is summed
+// in the order of gemm_split3_kernel (per 16 k: lh hl mm mh hm hh), so without split-K the two kernels are bit-identical.  A wave's
+// chain is 12 MFMAs of 32 cycles per K tile instead of the fp32 ring kernel's 16 of 64: 0.375 of its matrix time.
+template <int ST, int EPI, bool PARTIAL>
+__global__ __launch_bounds__(256) void gemm_split3_ring_kernel(GemmArgs a, int tiles_m, int groups, int ksplit, float* part) {
+    constexpr int NPW = 6;                                  // copies per wave and K tile (3 for A, 3 for W)
+    constexpr int STAGE = 64 * ROWB;                        // 12 KB per operand and stage
+    static_assert((ST & (ST - 1)) == 0 && ST >= 4, "ring depth must be a power of two >= 4");
+    __shared__ __attribute__((aligned(16))) char smem[ST * 2 * STAGE];
+    char* As = smem;                       // [ST][64][192]
+    char* Bs = smem + ST * STAGE;          // [ST][64][192]
+
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int gl = within / tiles_m, tile_m = within - gl * tiles_m;
+    const int g = gl * 8 + xcd;
+    if (g >= groups) return;
+    const int tile_n = g / ksplit, sp = g - tile_n * ksplit;
+    const int bm0 = tile_m * 64, bn0 = tile_n * 64;
+    const int kper = a.K / ksplit, kbeg = sp * kper, nk = kper / SBK;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+
+    const int64_t arow = a.lda * 6, wrow = a.ldw * 6;
+    const char* Abase = reinterpret_cast<const char*>(a.A) + (int64_t)bm0 * arow + (int64_t)(kbeg >> 3) * 48;
+    const char* Wbase = reinterpret_cast<const char*>(a.W) + (int64_t)bn0 * wrow + (int64_t)(kbeg >> 3) * 48;
+    uint32_t Aoff[3], Woff[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int c = (wave + 4 * p) * 64 + lane, row = c / SLOTS, slot = c - row * SLOTS;
+        const int j = (slot + SLOTS - ((row >> 2) & 3)) % SLOTS;
+        Aoff[p] = (uint32_t)(min(bm0 + row, a.M - 1) - bm0) * (uint32_t)arow + (uint32_t)j * 16u;
+        Woff[p] = (uint32_t)(min(bn0 + row, a.N - 1) - bn0) * (uint32_t)wrow + (uint32_t)j * 16u;
+    }
+    auto dma_tile = [&](int kt, auto stc) {      // K tile kt -> ring slot stc (= kt % ST, an integral constant)
+        constexpr int st = decltype(stc){};
+        const int64_t k0b = (int64_t)kt * ROWB;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            dma16_saddr(Abase + k0b, Aoff[p], lds_addr_b(As + st * STAGE + (wave + 4 * p) * 1024));
+            dma16_saddr(Wbase + k0b, Woff[p], lds_addr_b(Bs + st * STAGE + (wave + 4 * p) * 1024));
+        }
+    };
+    uint32_t fo[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+            fo[s][pc] = (uint32_t)lrow * ROWB + (uint32_t)((((2 * s + lhalf) * 3 + pc) + ((lrow >> 2) & 3)) % SLOTS) * 16u;
+    const char* Afr = As + wm0 * ROWB;
+    const char* Bfr = Bs + wn0 * ROWB;
+    bf16x8 af[2][3], bf[2][3];
+    auto read_frags = [&](auto stc, int s, int set) {
+        constexpr int st = decltype(stc){};
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            af[set][pc] = *reinterpret_cast<const bf16x8*>(Afr + st * STAGE + fo[s][pc]);
+            bf[set][pc] = *reinterpret_cast<const bf16x8*>(Bfr + st * STAGE + fo[s][pc]);
+        }
+    };
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
+    // one step of 16 k: product 0, then the fragment reads of the NEXT step (nxt() may be empty) in the shadow of products 1-5
+    auto step = [&](int set, auto nxt) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][piece_a(0)], bf[set][piece_w(0)], acc[0][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        nxt();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 1; p < NPROD; ++p)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][piece_a(p)], bf[set][piece_w(p)], acc[0][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // prologue: K tiles 0 .. ST-2 in flight; tile 0 must have landed (for every wave) before the first fragment read
+    static_for<ST - 1>([&](auto t) {
+        if (t < nk) dma_tile(t, t);
+    });
+    if (nk >= ST - 1) wait_vm_barrier<(ST - 2) * NPW>(); else wait_vm_barrier<0>();
+    read_frags(IntC<0>{}, 0, 0);
+
+    auto tile = [&](int kt, auto stc, bool last) {      // stc = kt % ST; `last` is a literal at every call site
+        constexpr int S = decltype(stc){};
+        step(0, [&] { read_frags(stc, 1, 1); });
+        if (!last) {
+            // tile kt+1 landed (in-order completion: at most the ST-3 younger tiles may still be in flight); after the barrier every
+            // wave is past tile kt-1, whose ring slot receives tile kt+ST-1
+            if (kt + ST - 2 < nk) wait_vm_barrier<(ST - 3) * NPW>(); else wait_vm_barrier<0>();
+            if (kt + ST - 1 < nk) dma_tile(kt + ST - 1, IntC<(S + ST - 1) % ST>{});
+        }
+        step(1, [&] { if (!last) read_frags(IntC<(S + 1) % ST>{}, 0, 0); });
+    };
+    int kt = 0;
+    for (; kt + ST <= nk - 1; kt += ST) static_for<ST>([&](auto sc) { tile(kt + sc, sc, false); });
+    static_for<ST>([&](auto sc) {            // < ST tiles left before the last one; kt is a multiple of ST
+        if (kt + sc < nk - 1) tile(kt + sc, sc, false);
+    });
+    static_for<ST>([&](auto sc) {
+        if (((nk - 1) & (ST - 1)) == sc) tile(nk - 1, sc, true);
+    });
+
+    if constexpr (PARTIAL) {
+        GemmArgs pa = a;
+        pa.C = part + (int64_t)sp * a.M * a.N;
+        pa.ldc = a.N;
+        store_tile<1, 1, EPI_NONE>(pa, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
+    } else {
+        if (a.c_split) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                           // every wave is done reading the ring
+            store_tile_split3<1, 1, EPI>(a, acc, reinterpret_cast<float*>(smem) + wave * (32 * 36), bm0 + wm0, bn0 + wn0, lane);
+            return;
+        }
+        store_tile<1, 1, EPI>(a, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
+    }
 }
 
 template <int WM, int WN, int TM, int TN, int ABL, int RS>
@@ -411,4 +540,34 @@ int launch_gemm_split3(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         case 37: return epi == EPI_NONE ? launch_split3_abl<2, 4, 2, 2, 7, 0>(a, s) : -1;
         default: return -1;
     }
+}
+
+// small-M split3 GEMM: 64x64 tiles on a 4-deep LDS-DMA ring; ksplit > 1 writes raw partial sums to part[ksplit][M][N] and applies NO
+// epilogue (launch_splitk_resid_ln / launch_splitk_epilogue then do)
+int launch_gemm_split3_ring(const GemmArgs& a, int epi, int ksplit, float* part, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || ksplit < 1 || (a.K % (SBK * ksplit)) != 0 || (a.lda % 8) != 0 || (a.ldw % 8) != 0) return -1;
+    if (a.lda * 6 * 64 >= (int64_t(1) << 32) || a.ldw * 6 * 64 >= (int64_t(1) << 32) || (ksplit > 1 && part == nullptr)) return -1;
+    if (a.cs_out != nullptr || a.ksplit > 1) return -1;
+    if (a.c_split != nullptr && ((a.N % 8) != 0 || (a.ldcs % 8) != 0 || a.ldcs < a.N || epi == EPI_BIAS_RESID || ksplit > 1)) return -1;
+    const int tiles_m = (a.M + 63) / 64, tiles_n = (a.N + 63) / 64;
+    const int groups = tiles_n * ksplit;
+    dim3 grid(8 * tiles_m * ((groups + 7) / 8)), block(256);
+    if (ksplit > 1) {
+        hipLaunchKernelGGL((gemm_split3_ring_kernel<4, EPI_NONE, true>), grid, block, 0, s, a, tiles_m, groups, ksplit, part);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+#define THMR_SRING_CASE(E)                                                                                              \
+    case E:                                                                                                             \
+        hipLaunchKernelGGL((gemm_split3_ring_kernel<4, E, false>), grid, block, 0, s, a, tiles_m, groups, 1, nullptr);   \
+        break;
+    switch (epi) {
+        THMR_SRING_CASE(EPI_NONE)
+        THMR_SRING_CASE(EPI_BIAS)
+        THMR_SRING_CASE(EPI_BIAS_GELU)
+        THMR_SRING_CASE(EPI_BIAS_RESID)
+        THMR_SRING_CASE(EPI_BIAS_QSCALE)
+        default: return -1;
+    }
+#undef THMR_SRING_CASE
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }

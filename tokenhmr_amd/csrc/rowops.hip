@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs a, const 
 //   x_new = resid + (sum_s part[s] + bias);  y = LayerNorm(x_new)        one wave per row, D = NV*256
 // ST > 0: the split factor is a compile-time constant, so all ST*NV partial loads of a lane are issued before the first add
 // (the engine's factor 4: 8.8 -> ~5 us at 192 rows, where the kernel is one dependent-load chain per wave); ST = 0: runtime S.
-template <int NV, int ST>
+// SPLIT: y is a split3 operand [rows][D/8][3][8] bf16 (gemm_split.hip) instead of fp32 — the same values as three bf16 pieces each
+template <int NV, int ST, bool SPLIT = false>
 __global__ __launch_bounds__(256) void splitk_resid_ln_kernel(const float* __restrict__ part, int S, int64_t mn,
                                                               const float* __restrict__ bias, const float* resid, float* xout,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -340,7 +341,8 @@ __global__ __launch_bounds__(256) void splitk_resid_ln_kernel(const float* __res
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-        *reinterpret_cast<f32x4*>(y + ro + c) = o;
+        if constexpr (SPLIT) store_split3_quad(reinterpret_cast<char*>(y) + ro * 6, c, o);
+        else *reinterpret_cast<f32x4*>(y + ro + c) = o;
     }
 }
 
@@ -379,8 +381,14 @@ int launch_splitk_epilogue(const GemmArgs& a, int epi, const float* part, int S,
 }
 
 int launch_splitk_resid_ln(const float* part, int S, int rows, int D, const float* bias, const float* resid, float* xout,
-                           const float* gamma, const float* beta, float* y, float eps, hipStream_t s) {
+                           const float* gamma, const float* beta, float* y, float eps, hipStream_t s, bool y_is_split3) {
     if (rows <= 0 || S < 1 || D != 1280) return -1;
+    if (y_is_split3) {
+        if (S != 4) return -1;      // the split3 mode's small-batch regime: one factor
+        hipLaunchKernelGGL((splitk_resid_ln_kernel<5, 4, true>), dim3((rows + 3) / 4), dim3(256), 0, s, part, S, (int64_t)rows * D, bias,
+                           resid, xout, gamma, beta, y, rows, eps);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (S == 4)
         hipLaunchKernelGGL((splitk_resid_ln_kernel<5, 4>), dim3((rows + 3) / 4), dim3(256), 0, s, part, S, (int64_t)rows * D, bias,
                            resid, xout, gamma, beta, y, rows, eps);
