@@ -176,7 +176,10 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& a, float acc, flo
 }
 
 // ---- "split3": an fp32 value as three bf16 pieces h + m + l (gemm_split.hip) ----
-// round-to-nearest-even bf16 of x (NaN stays NaN), as the 16-bit pattern
+// round-to-nearest-even bf16 of x (NaN stays NaN), as the 16-bit pattern.  Integer arithmetic on purpose: v_cvt_pk_bf16_f32 (two
+// conversions per instruction, 9 instead of ~36 VALU per pair of values for the three pieces) was tried — the producers are bound by their
+// stores, not by this (82.5 vs 81.7 ms per 64-crop call, profiles/r3z_hw_bf16_cvt_ab.log), and it is not bit-identical to the numpy
+// restatement the tests compare with on every input class
 __device__ __forceinline__ uint32_t bf16_rne(float x) {
     const uint32_t u = __float_as_uint(x);
     if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
