@@ -266,6 +266,20 @@ def test_vit_gemm_split3_mode(built_lib, cuda_dev):
                betas=orc["pred_smpl_params"]["betas"], cam=orc["pred_cam"], verts=orc["pred_vertices"],
                joints=orc["pred_keypoints_3d"], kp2d=orc["pred_keypoints_2d"], token_idx=orc["token_idx"])
     _check_against(s3, ref, top2[..., 0] - top2[..., 1], "split3 B=20 vs oracle")
+    # weights re-loaded while the mode is on: thmr_finalize_weights re-splits them (a stale split copy would reproduce the OLD model)
+    sd2, tok2, _ = _assets(cfg, seed=7)
+    model.engine.load_state(sd2, tok2)
+    model.engine.finalize()
+    fresh = TokenHMR.from_state(cfg, sd2, tok2, smpl, max_batch=24, device=cuda_dev)
+    fresh.engine.set_vit_gemm("split3")
+    fresh.return_taps = True
+    reloaded, want = _to_cpu(model({"img": img[:20]})), _to_cpu(fresh({"img": img[:20]}))
+    assert torch.equal(reloaded["pred_vertices"], want["pred_vertices"]) and torch.equal(reloaded["cls_logits"], want["cls_logits"])
+    assert not torch.equal(reloaded["cls_logits"], s3["cls_logits"])
+    del fresh
+    model.engine.load_state(sd, tok)
+    model.engine.finalize()
+    assert torch.equal(_to_cpu(model({"img": img[:20]}))["cls_logits"], s3["cls_logits"])
     model.engine.set_vit_gemm("f32")
     back = _to_cpu(model({"img": img[:20]}))
     assert torch.equal(back["pred_vertices"], f32["pred_vertices"]) and torch.equal(back["vit_features"], f32["vit_features"])
