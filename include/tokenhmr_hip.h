@@ -200,7 +200,8 @@ int thmr_op_gemm(const float* A_dev, int64_t lda, const float* W_dev, const floa
  * strides lda / ldw in fp32-equivalents (multiples of 8), K % 32 == 0; bias / resid / C fp32; epi 0, 1, 2, 4, 5 as thmr_op_gemm;
  * variant -1 = the engine's rule; 0 = 128x256 tile, 8 waves; 1 = 128x256, 4 waves; 2 = 128x128, 4 waves (bit-identical to each
  * other); 100 + j = the small-M ring kernel (64x64 tiles, 4-deep LDS-DMA ring) with split-K 2^j, j <= 2 — 100 is bit-identical to the big
- * tiles, the split ones associate K differently; (3, 31, 32, 34, 37: schedule experiments of scripts/split3_bench.py, epilogue 0 only;
+ * tiles, the split ones associate K differently; 202 / 204 = split-K 2 / 4 on the big tiles (the engine's 7 ... 15 crops use 2);
+ * (3, 31, 32, 34, 37: schedule experiments of scripts/split3_bench.py, epilogue 0 only;
  * 31-37 are timing-only and return garbage). */
 int thmr_op_split3(const float* src_dev, int64_t ld_src, void* dst_dev, int64_t ld_dst, int64_t rows, int32_t K, void* stream);
 int thmr_op_gemm_split3(const void* A_split_dev, int64_t lda, const void* W_split_dev, int64_t ldw, const float* bias_dev,
@@ -303,7 +304,8 @@ const char* thmr_collective_last_error(void);
  *   1: "split3" — each fp32 operand as three bf16 pieces, six bf16 MFMA products per element pair, fp32 accumulation
  *      (csrc/gemm_split.hip; thmr_op_gemm_split3 is the same kernel).  fp32-GRADE, not bitwise fp32: the measured error against an fp64
  *      product is no larger than the exact-fp32 kernel's (tests/test_gpu_ops.py::test_gemm_split3), at ~1.6x its rate.  Applies to calls of at
- *      least 17 crops (below, the exact-fp32 kernels run regardless); LayerNorm, attention, the epilogues and the head are unchanged.
+ *      least 7 crops (below, the exact-fp32 kernels run regardless; 7 ... 15 crops split the K sums of proj / fc2 two ways, 16 and more do
+ *      not: two ranges, a crop's result is batch-independent within each); LayerNorm, attention, the epilogues and the head are unchanged.
  * Setting 1 needs finalized weights; the engine then owns a split3 copy of the ViT weights (1.5x their fp32 bytes) and the operand
  * buffers, rebuilt by thmr_finalize_weights while the mode is on.  Returns 0 / negative; thmr_get_vit_gemm returns the mode. */
 int thmr_set_vit_gemm(thmr_engine* e, int32_t mode, void* stream);

@@ -249,7 +249,7 @@ def test_gemm_split3(built_lib, cuda_dev, shape):
     for epi, kw in (("bias", {}), ("bias_gelu", {}), ("bias_resid", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
         o = ops.gemm_split3(sa, sw, db, dr if epi == "bias_resid" else None, epi=epi, variant="ring", **kw)
         assert torch.equal(o, ops.gemm_split3(sa, sw, db, dr if epi == "bias_resid" else None, epi=epi, variant="128x256/w8", **kw)), epi
-    for ks, name in ((2, "ring/k2"), (4, "ring/k4")):
+    for ks, name in ((2, "ring/k2"), (4, "ring/k4"), (2, "auto/k2"), (4, "auto/k4")):
         if K % (32 * ks):
             continue
         o = ops.gemm_split3(sa, sw, db, dr, epi="bias_resid", variant=name)

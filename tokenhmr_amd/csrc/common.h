@@ -288,6 +288,8 @@ int launch_gemm_ring16(const GemmArgs& a, int epi, hipStream_t s);              
 // gemm_split.hip: fp32 -> three bf16 pieces ("split3"), and the GEMM over split3 operands on the bf16 matrix pipe (a.A / a.W = split3)
 int launch_split3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int K, hipStream_t s);
 int launch_gemm_split3(const GemmArgs& a, int epi, int variant, hipStream_t s);
+// split-K on the split3 big tiles: ksplit copies of the tile grid in one launch, raw partial sums into part[ksplit][M][N]
+int launch_gemm_split3_splitk(const GemmArgs& a, int ksplit, float* part, hipStream_t s);
 // small-M split3 GEMM (64x64 tiles, LDS-DMA ring, optional split-K into part[ksplit][M][N] without epilogue)
 int launch_gemm_split3_ring(const GemmArgs& a, int epi, int ksplit, float* part, hipStream_t s);
 // LayerNorm (D = 1280) whose result is written as a split3 operand [rows][D/8][3][8] instead of fp32 (same arithmetic as launch_layernorm)

@@ -44,6 +44,8 @@ constexpr int kMidLoM = 7 * 192, kMidHiM = 16 * 192, kMidSplit = 2;
 // thmr_set_vit_gemm(1): batches of at least this many crops run the ViT GEMMs as split3 products (128 x 256 tiles, one workgroup per
 // CU: below the big-tile regime the exact-fp32 kernels with their smaller tiles and split-K stay in charge)
 constexpr int kSplit3MinB = 16;
+// ... and 7 ... 15 crops run them with proj / fc2 split K two ways (60-120 tiles of 128 x 256 otherwise): the mode's own mid regime
+constexpr int kSplit3MidMinB = 7, kSplit3MidSplit = 2;
 // decoder + mixer stack: the persistent decoder kernel and the one-workgroup-per-crop mixer kernel win while the work is
 // latency-bound (B = 1: 0.96 vs 1.01 ms, B = 64: 1.58 vs 1.93 ms per head); from a few hundred crops on the same products are
 // real GEMMs (M = B and M = 160 B rows) and the tiled MFMA kernels win (B = 512: 6.7 vs 7.5 ms) — profiles/r2e_head_fused_vs_chain.log
@@ -474,7 +476,11 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
     };
     const float* lastn_w = e->hot.lastn_w;
     const float* lastn_b = e->hot.lastn_b;
-    if (e->vit_gemm_mode == 1 && B >= (e->split3_min_b > 0 ? e->split3_min_b : kSplit3MinB)) {
+    const int s3_min = e->split3_min_b > 0 ? e->split3_min_b : kSplit3MidMinB;
+    if (e->vit_gemm_mode == 1 && B >= s3_min) {
+        // 7 ... 15 crops: proj / fc2 split K two ways into `part`, reduced (in a fixed order) by the residual + LayerNorm kernel, as in the
+        // exact-fp32 path's mid regime; 16 crops and more: unsplit.  One factor per range: a crop's result is batch-independent within it.
+        const int s3_split = B < kSplit3MinB ? kSplit3MidSplit : 1;
         // The four GEMMs as split3 products on the bf16 matrix pipe (csrc/gemm_split.hip); everything else — patch embed, attention,
         // LayerNorm arithmetic, epilogues — is the fp32 path's.  A operands: the LayerNorms, the attention kernel and fc1's GELU epilogue
         // write their results directly as three bf16 pieces (hs, bs): no conversion pass, no fp32 copy of those activations.
@@ -499,8 +505,16 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 ProfScope ps(e, st, THMR_PROF_ATTN, 4.0 * B * HEADS * 192.0 * 192.0 * 80.0, 4.0 * (3.0 * M * DIM) + 6.0 * M * DIM);
                 LAUNCH_OK(launch_vit_attention_split3(big, hs, B, st));
             }
-            LAUNCH_OK(gemm_s(THMR_PROF_GEMM_PROJ, hs, DIM, ws.proj, w.pb, x, x, DIM, EPI_BIAS_RESID));
-            {
+            if (s3_split > 1) {
+                {
+                    ProfScope ps(e, st, THMR_PROF_GEMM_PROJ, 2.0 * M * DIM * (double)DIM, 6.0 * ((double)M * DIM + (double)DIM * DIM) + 4.0 * s3_split * M * DIM);
+                    GemmArgs a = mk(reinterpret_cast<const float*>(hs), DIM, reinterpret_cast<const float*>(ws.proj), DIM, nullptr, nullptr, 0, x, DIM, M, DIM, DIM);
+                    LAUNCH_OK(launch_gemm_split3_splitk(a, s3_split, part, st));
+                }
+                ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (s3_split + 2.0) * M * DIM + 6.0 * M * DIM);
+                LAUNCH_OK(launch_splitk_resid_ln(part, s3_split, M, DIM, w.pb, x, x, w.n2w, w.n2b, reinterpret_cast<float*>(hs), VIT_EPS, st, true));
+            } else {
+                LAUNCH_OK(gemm_s(THMR_PROF_GEMM_PROJ, hs, DIM, ws.proj, w.pb, x, x, DIM, EPI_BIAS_RESID));
                 ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
                 LAUNCH_OK(launch_layernorm_split3(x, w.n2w, w.n2b, hs, M, DIM, VIT_EPS, st));
             }
@@ -510,10 +524,24 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 a.c_split = bs; a.ldcs = MLP;
                 LAUNCH_OK(launch_gemm_split3(a, EPI_BIAS_GELU, -1, st));
             }
-            LAUNCH_OK(gemm_s(THMR_PROF_GEMM_FC2, bs, MLP, ws.fc2, w.f2b, x, x, DIM, EPI_BIAS_RESID));
-            ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
-            if (last) LAUNCH_OK(launch_layernorm(x, lastn_w, lastn_b, feats_out ? feats_out : h, M, DIM, VIT_EPS, 0, st));
-            else LAUNCH_OK(launch_layernorm_split3(x, e->vitw[i + 1].n1w, e->vitw[i + 1].n1b, hs, M, DIM, VIT_EPS, st));
+            if (s3_split > 1) {
+                {
+                    ProfScope ps(e, st, THMR_PROF_GEMM_FC2, 2.0 * M * DIM * (double)MLP, 6.0 * ((double)M * MLP + (double)DIM * MLP) + 4.0 * s3_split * M * DIM);
+                    GemmArgs a = mk(reinterpret_cast<const float*>(bs), MLP, reinterpret_cast<const float*>(ws.fc2), MLP, nullptr, nullptr, 0, x, DIM, M, DIM, MLP);
+                    LAUNCH_OK(launch_gemm_split3_splitk(a, s3_split, part, st));
+                }
+                ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (s3_split + 3.0) * M * DIM);
+                if (last)
+                    LAUNCH_OK(launch_splitk_resid_ln(part, s3_split, M, DIM, w.f2b, x, x, lastn_w, lastn_b, feats_out ? feats_out : h, VIT_EPS, st));
+                else
+                    LAUNCH_OK(launch_splitk_resid_ln(part, s3_split, M, DIM, w.f2b, x, x, e->vitw[i + 1].n1w, e->vitw[i + 1].n1b,
+                                                     reinterpret_cast<float*>(hs), VIT_EPS, st, true));
+            } else {
+                LAUNCH_OK(gemm_s(THMR_PROF_GEMM_FC2, bs, MLP, ws.fc2, w.f2b, x, x, DIM, EPI_BIAS_RESID));
+                ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
+                if (last) LAUNCH_OK(launch_layernorm(x, lastn_w, lastn_b, feats_out ? feats_out : h, M, DIM, VIT_EPS, 0, st));
+                else LAUNCH_OK(launch_layernorm_split3(x, e->vitw[i + 1].n1w, e->vitw[i + 1].n1b, hs, M, DIM, VIT_EPS, st));
+            }
         }
         return 0;
     }
@@ -1502,11 +1530,33 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
     if (epi == EPI_BIAS_RESID && !resid) return fail(e, THMR_ERR_INVALID, "epilogue needs resid");
     if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || ldc < N)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: K % 32 == 0, lda / ldw multiples of 8 and >= K, ldc >= N");
-    if (!(variant >= -1 && variant <= 3) && variant != 31 && variant != 32 && variant != 34 && variant != 37 && !(variant >= 100 && variant <= 102))
-        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 1, 2, 100-102 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
+    if (!(variant >= -1 && variant <= 3) && variant != 31 && variant != 32 && variant != 34 && variant != 37 && !(variant >= 100 && variant <= 102) &&
+        variant != 202 && variant != 204)
+        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 1, 2, 100-102, 202, 204 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, resid, ldc, C, ldc, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (variant == 202 || variant == 204) {
+        // split-K 2 / 4 on the big tiles; partial sums in a grow-only workspace per (device, stream), then the fixed-order reduce + epilogue
+        const int ksplit = variant - 200;
+        if ((K % (32 * ksplit)) != 0) return fail(e, THMR_ERR_INVALID, "split3 split-K GEMM: K must be a multiple of 32 * ksplit");
+        static std::mutex mu4;
+        static std::map<std::pair<int, void*>, std::pair<float*, size_t>> pool4;
+        int dev = 0;
+        HIP_OK(hipGetDevice(&dev));
+        std::unique_lock<std::mutex> lk(mu4);
+        auto& slot = pool4[{dev, stream}];
+        const size_t need = (size_t)ksplit * M * N;
+        if (need > slot.second) {
+            if (slot.first) { HIP_OK(hipDeviceSynchronize()); HIP_OK(hipFree(slot.first)); slot = {nullptr, 0}; }
+            float* p = nullptr;
+            HIP_OK(hipMalloc(&p, need * sizeof(float)));
+            slot = {p, need};
+        }
+        LAUNCH_OK(launch_gemm_split3_splitk(a, ksplit, slot.first, st));
+        LAUNCH_OK(launch_splitk_epilogue(a, epi, slot.first, ksplit, st));
+        return 0;
+    }
     if (variant >= 100) {
         // small-M ring kernel, split-K 2^(variant - 100); partial sums in a grow-only workspace per (device, stream), then the fixed-order
         // reduce + epilogue (the engine fuses that into its residual + LayerNorm kernel)

@@ -203,9 +203,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split3_kernel(GemmArgs a, i
     char* Bs = smem + 2 * A_STAGE;         // [2][BN][192]
 
     int tile_m, tile_n;
-    tile_coords(tiles_m, tiles_n, logical_block(nwg, 0), tile_m, tile_n);
+    int logical = logical_block(nwg, 0);
+    int nk = a.K / SBK;
+    int ksp = 0;
+    if (a.ksplit > 1) {      // split-K: this block belongs to copy ksp of the tile grid and reduces K slice ksp into part[ksp] (wave-uniform)
+        const int tiles = tiles_m * tiles_n;
+        ksp = logical / tiles;
+        logical -= ksp * tiles;
+        nk /= a.ksplit;
+        a.C += (int64_t)ksp * a.M * a.ldc;
+    }
+    tile_coords(tiles_m, tiles_n, logical, tile_m, tile_n);
     const int bm0 = tile_m * BM, bn0 = tile_n * BN;
-    const int nk = a.K / SBK;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -217,8 +226,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split3_kernel(GemmArgs a, i
     // ---- copies: wave instruction q = wave + i NW of an operand fills LDS chunks 64 q ... 64 q + 63 of its stage; lane -> chunk c,
     // row c / 12, physical slot c % 12, which holds logical chunk (slot - rot(row)) mod 12.  Rows past the edge are clamped.
     const int64_t arow = a.lda * 6, wrow = a.ldw * 6;                  // bytes per matrix row
-    const char* Abase = reinterpret_cast<const char*>(a.A) + (int64_t)bm0 * arow;
-    const char* Wbase = reinterpret_cast<const char*>(a.W) + (int64_t)bn0 * wrow;
+    const char* Abase = reinterpret_cast<const char*>(a.A) + (int64_t)bm0 * arow + (int64_t)ksp * nk * ROWB;
+    const char* Wbase = reinterpret_cast<const char*>(a.W) + (int64_t)bn0 * wrow + (int64_t)ksp * nk * ROWB;
     uint32_t Aoff[A_P], Woff[B_P];
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
@@ -479,7 +488,7 @@ int launch_split3_abl(const GemmArgs& a, hipStream_t s) {
 template <int WM, int WN, int TM, int TN>
 int launch_split3_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, nwg = tiles_m * tiles_n;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, nwg = tiles_m * tiles_n * (a.ksplit > 1 ? a.ksplit : 1);
     const dim3 grid(nwg), block(WM * WN * 64);
 #define THMR_SPLIT_CASE(E)                                                                                                  \
     case E:                                                                                                                 \
@@ -514,6 +523,8 @@ int launch_layernorm_split3(const float* x, const float* g, const float* b, void
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStream_t s);
+
 // a.A / a.W point at split3 operands (lda / ldw = their row strides in fp32-equivalents, i.e. 6 lda bytes); C, bias, resid are fp32.
 // variant: -1 = rule below   0 = 8 waves of 64x64 on 128x256   1 = 4 waves of 64x128 on 128x256   2 = 4 waves of 64x64 on 128x128
 int launch_gemm_split3(const GemmArgs& a, int epi, int variant, hipStream_t s) {
@@ -521,10 +532,32 @@ int launch_gemm_split3(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.lda * 6 * 256 >= (int64_t(1) << 32) || a.ldw * 6 * 256 >= (int64_t(1) << 32)) return -1;     // 32-bit lane offsets within a tile
     if (a.cs_out != nullptr || a.ksplit > 1) return -1;
     if (a.c_split != nullptr && ((a.N % 8) != 0 || (a.ldcs % 8) != 0 || a.ldcs < a.N || epi == EPI_BIAS_RESID)) return -1;
+    return launch_split3_tiles(a, epi, variant, s);
+}
+
+// Split-K on the split3 big tiles (the mode's 7 ... 15 crops: the N = 1280 GEMMs have 60-120 tiles of 128 x 256): `ksplit` copies of the tile
+// grid in ONE launch, copy sp reducing K slice sp into part[sp][M][N] (raw fp32 partial tiles, no epilogue), summed in a fixed order by the
+// residual + LayerNorm kernel that follows proj / fc2 anyway.  Tile by the same rule over tiles * ksplit (bit-identical either way).
+int launch_gemm_split3_splitk(const GemmArgs& a0, int ksplit, float* part, hipStream_t s) {
+    if (ksplit < 2 || part == nullptr) return -1;
+    if (a0.M <= 0 || a0.N <= 0 || a0.K <= 0 || (a0.K % (SBK * ksplit)) != 0 || (a0.lda % 8) != 0 || (a0.ldw % 8) != 0) return -1;
+    if (a0.lda * 6 * 256 >= (int64_t(1) << 32) || a0.ldw * 6 * 256 >= (int64_t(1) << 32) || a0.cs_out != nullptr || a0.c_split != nullptr) return -1;
+    GemmArgs a = a0;
+    a.ksplit = ksplit;
+    a.C = part; a.ldc = a.N;
+    a.bias = nullptr; a.resid = nullptr; a.ldr = 0;
+    return launch_split3_tiles(a, EPI_NONE, -1, s);
+}
+
+static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (variant < 0) {
-        // the tiles are bit-identical (same K order per element), so the choice is purely a matter of time: 128 x 256 (8 waves) unless
-        // the whole grid of 128 x 128 tiles still fits one round of 256 CUs — the N = 1280 GEMMs at 16 crops: 240 tiles instead of 120
-        const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+        // the tiles are bit-identical (same K order per element), so the choice is purely a matter of time:
+        // 128 x 256 (8 waves) unless the whole grid of 128 x 128 tiles still fits ONE round of 256 CUs (the N = 1280 GEMMs at 16 crops, and
+        // at 7-8 crops with their K split two ways: 240 workgroups instead of 120).  A rounds x tile-time model over both shapes (a
+        // 128 x 128 tile takes 0.55 of a 128 x 256 one) was tried and is worse wherever it differs — 640 vs 669 crops/s at 15 crops, 665 vs
+        // 707 at 48: a partly filled last round of big tiles costs less than a full round (profiles/r3ae_split3_tile_rule_ab.log)
+        const long ks = a.ksplit > 1 ? a.ksplit : 1;
+        const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * ks;
         variant = t128 <= 256 ? 2 : 0;
     }
     switch (variant) {
