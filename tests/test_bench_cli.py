@@ -146,8 +146,7 @@ def test_two_ranks_with_real_engines_on_one_gpu(built_lib, cuda_dev, extra):
     tensors through the host).  Rank 0 loads, the arena is broadcast BEFORE rank 0 finalizes, rank 1 finalizes with
     assume_all_loaded, both run their shard, records are gathered, and rank 0 recomputes rank 1's seeded shard on its own engine:
     bit-identical or the receiver's model is wrong (the round-2 regression: uninitialised resample tables on ranks != 0).
-    In the split3 mode every rank builds its own split copy of the ViT weights from the broadcast arena (16 crops per rank: the mode's
-    smallest batch); the receiver's results must again be rank 0's bit for bit."""
+    In the split3 mode every rank builds its own split copy of the ViT weights from the broadcast arena (16 crops per rank: its unsplit range); the receiver's results must again be rank 0's bit for bit."""
     n = 16 if extra else 5
     j = _line(_run(["--gpus", "2", "--backend", "gloo", "--single-device", "--vit-depth", "2", "--batch", str(n), "--steps", "3", "--warmup", "1",
                     "--no-cpu-baseline"] + extra, timeout=900))
