@@ -46,6 +46,13 @@ constexpr int kMidLoM = 7 * 192, kMidHiM = 16 * 192, kMidSplit = 2;
 constexpr int kSplit3MinB = 16;
 // ... and 7 ... 15 crops run them with proj / fc2 split K two ways (60-120 tiles of 128 x 256 otherwise): the mode's own mid regime
 constexpr int kSplit3MidMinB = 7, kSplit3MidSplit = 2;
+// fc2 (K = 5120) splits K two ways up to 55 crops: 128 x 256 tiles of K = 5120 are ~400 us blocks, and halving them shortens the ragged
+// last round — op level 198 vs 229 us at 16 crops, 547 vs 666 at 40, 596 vs 741 at 48 incl. the reduce
+// (profiles/r3af_split3_n1280_tile_splitk_sweep.log); per call 702 vs 658 crops/s at 16 crops, 756 vs 707 at 48 — but 773 vs 784 at 32 and
+// 775 vs 784 at 64, whose 240 / 480 tiles fill the rounds anyway and where the LayerNorm kernel then reads two partial planes for nothing
+// (profiles/r3ag_split3_fc2_splitk_all_batches.log).  One factor per RANGE (batch invariance): split up to 55 crops, unsplit from 56 on.
+// proj (K = 1280) splits only up to 15 crops.
+constexpr int kSplit3Fc2Split = 2, kSplit3Fc2MaxB = 55;
 // decoder + mixer stack: the persistent decoder kernel and the one-workgroup-per-crop mixer kernel win while the work is
 // latency-bound (B = 1: 0.96 vs 1.01 ms, B = 64: 1.58 vs 1.93 ms per head); from a few hundred crops on the same products are
 // real GEMMs (M = B and M = 160 B rows) and the tiled MFMA kernels win (B = 512: 6.7 vs 7.5 ms) — profiles/r2e_head_fused_vs_chain.log
@@ -101,6 +108,7 @@ struct thmr_engine {
     // size) and the split3 activation operands (M x (1280 + 5120) x 6 bytes).  Off (0) = exact-fp32 MFMA everywhere, the default.
     int vit_gemm_mode = 0;
     bool split3_small = false;        // THMR_SPLIT3_SMALL=1: the split3 mode also serves up to six crops (ring kernel on split3 operands) — measured SLOWER, A/B only
+    int split3_fc2_split = 2;         // THMR_SPLIT3_FC2_SPLIT=1: fc2 of the split3 mode unsplit from 16 crops on (A/B only)
     int split3_min_b = 0;             // THMR_SPLIT3_MIN_B=<n>: A/B knob for the smallest batch the split3 mode serves (0 = kSplit3MinB)
     char* split_w = nullptr;
     char* split_act = nullptr;
@@ -481,6 +489,8 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         // 7 ... 15 crops: proj / fc2 split K two ways into `part`, reduced (in a fixed order) by the residual + LayerNorm kernel, as in the
         // exact-fp32 path's mid regime; 16 crops and more: unsplit.  One factor per range: a crop's result is batch-independent within it.
         const int s3_split = B < kSplit3MinB ? kSplit3MidSplit : 1;
+        const int s3_fc2 = B <= kSplit3Fc2MaxB ? e->split3_fc2_split : 1;
+        float* part2 = reinterpret_cast<float*>(e->split_act + (size_t)e->max_batch * TOK * (DIM + MLP) * 6);      // fc2's partial sums (any batch size)
         // The four GEMMs as split3 products on the bf16 matrix pipe (csrc/gemm_split.hip); everything else — patch embed, attention,
         // LayerNorm arithmetic, epilogues — is the fp32 path's.  A operands: the LayerNorms, the attention kernel and fc1's GELU epilogue
         // write their results directly as three bf16 pieces (hs, bs): no conversion pass, no fp32 copy of those activations.
@@ -524,17 +534,17 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 a.c_split = bs; a.ldcs = MLP;
                 LAUNCH_OK(launch_gemm_split3(a, EPI_BIAS_GELU, -1, st));
             }
-            if (s3_split > 1) {
+            if (s3_fc2 > 1) {
                 {
-                    ProfScope ps(e, st, THMR_PROF_GEMM_FC2, 2.0 * M * DIM * (double)MLP, 6.0 * ((double)M * MLP + (double)DIM * MLP) + 4.0 * s3_split * M * DIM);
+                    ProfScope ps(e, st, THMR_PROF_GEMM_FC2, 2.0 * M * DIM * (double)MLP, 6.0 * ((double)M * MLP + (double)DIM * MLP) + 4.0 * s3_fc2 * M * DIM);
                     GemmArgs a = mk(reinterpret_cast<const float*>(bs), MLP, reinterpret_cast<const float*>(ws.fc2), MLP, nullptr, nullptr, 0, x, DIM, M, DIM, MLP);
-                    LAUNCH_OK(launch_gemm_split3_splitk(a, s3_split, part, st));
+                    LAUNCH_OK(launch_gemm_split3_splitk(a, s3_fc2, part2, st));
                 }
-                ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (s3_split + 3.0) * M * DIM);
+                ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (s3_fc2 + 3.0) * M * DIM);
                 if (last)
-                    LAUNCH_OK(launch_splitk_resid_ln(part, s3_split, M, DIM, w.f2b, x, x, lastn_w, lastn_b, feats_out ? feats_out : h, VIT_EPS, st));
+                    LAUNCH_OK(launch_splitk_resid_ln(part2, s3_fc2, M, DIM, w.f2b, x, x, lastn_w, lastn_b, feats_out ? feats_out : h, VIT_EPS, st));
                 else
-                    LAUNCH_OK(launch_splitk_resid_ln(part, s3_split, M, DIM, w.f2b, x, x, e->vitw[i + 1].n1w, e->vitw[i + 1].n1b,
+                    LAUNCH_OK(launch_splitk_resid_ln(part2, s3_fc2, M, DIM, w.f2b, x, x, e->vitw[i + 1].n1w, e->vitw[i + 1].n1b,
                                                      reinterpret_cast<float*>(hs), VIT_EPS, st, true));
             } else {
                 LAUNCH_OK(gemm_s(THMR_PROF_GEMM_FC2, bs, MLP, ws.fc2, w.f2b, x, x, DIM, EPI_BIAS_RESID));
@@ -1064,6 +1074,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* qr = getenv("THMR_QKV_RING16"); e->qkv_ring16 = !(qr && qr[0] == '0'); }
     { const char* ak = getenv("THMR_ATTN_KEYSPLIT"); e->attn_keysplit = !(ak && ak[0] == '0'); }
     { const char* ss = getenv("THMR_SPLIT3_SMALL"); e->split3_small = ss && ss[0] == '1'; }
+    { const char* fs = getenv("THMR_SPLIT3_FC2_SPLIT"); e->split3_fc2_split = (fs && fs[0] == '1') ? 1 : kSplit3Fc2Split; }
     { const char* sm = getenv("THMR_SPLIT3_MIN_B"); e->split3_min_b = sm ? atoi(sm) : 0; }
     { const char* ms = getenv("THMR_MID_SPLIT"); if (ms && ms[0] && ms[1]) { e->mid_split_force[0] = ms[0] - '0'; e->mid_split_force[1] = ms[1] - '0'; } }
     { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
@@ -1131,7 +1142,8 @@ static int build_split_weights(thmr_engine* e, hipStream_t st) {
     if (!e->split_w && hipMalloc(reinterpret_cast<void**>(&e->split_w), per_block * 6 * e->vit_depth) != hipSuccess)
         return fail(e, THMR_ERR_NOMEM, "hipMalloc(split3 ViT weights) failed");
     const size_t M = (size_t)e->max_batch * TOK;
-    if (!e->split_act && hipMalloc(reinterpret_cast<void**>(&e->split_act), M * (size_t)(DIM + MLP) * 6) != hipSuccess)
+    // activations: [M][1280] + [M][5120] split3 operands, then the two fp32 partial-sum planes of fc2's split-K ([2][M][1280])
+    if (!e->split_act && hipMalloc(reinterpret_cast<void**>(&e->split_act), M * (size_t)(DIM + MLP) * 6 + (size_t)kSplit3Fc2Split * M * DIM * 4) != hipSuccess)
         return fail(e, THMR_ERR_NOMEM, "hipMalloc(split3 activations) failed");
     e->vitw_s.resize(e->vit_depth);
     char* p = e->split_w;

@@ -550,6 +550,8 @@ int launch_gemm_split3_splitk(const GemmArgs& a0, int ksplit, float* part, hipSt
 }
 
 static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStream_t s) {
+    static const int forced = [] { const char* e = getenv("THMR_SPLIT3_TILE"); return e ? atoi(e) : -1; }();     // A/B knob (0 / 2)
+    if (variant < 0 && forced >= 0) variant = forced;
     if (variant < 0) {
         // the tiles are bit-identical (same K order per element), so the choice is purely a matter of time:
         // 128 x 256 (8 waves) unless the whole grid of 128 x 128 tiles still fits ONE round of 256 CUs (the N = 1280 GEMMs at 16 crops, and
