@@ -305,7 +305,7 @@ const char* thmr_collective_last_error(void);
  *      (csrc/gemm_split.hip; thmr_op_gemm_split3 is the same kernel).  fp32-GRADE, not bitwise fp32: the measured error against an fp64
  *      product is no larger than the exact-fp32 kernel's (tests/test_gpu_ops.py::test_gemm_split3), at ~1.6x its rate.  Applies to calls of at
  *      least 7 crops (below, the exact-fp32 kernels run regardless).  Three ranges, a crop's result is batch-independent within each:
- *      7 ... 15 crops split the K sums of proj and fc2 two ways, 16 ... 55 only fc2's, 56 and more neither; LayerNorm, attention, the epilogues and the head are unchanged.
+ *      7 ... 15 crops split the K sums of proj and fc2 two ways, 16 ... 31 only fc2's, 32 and more neither; LayerNorm, attention, the epilogues and the head are unchanged.
  * Setting 1 needs finalized weights; the engine then owns a split3 copy of the ViT weights (1.5x their fp32 bytes) and the operand
  * buffers, rebuilt by thmr_finalize_weights while the mode is on.  Returns 0 / negative; thmr_get_vit_gemm returns the mode. */
 int thmr_set_vit_gemm(thmr_engine* e, int32_t mode, void* stream);

@@ -228,7 +228,7 @@ def _check_b64_golden(out, g, tag):
 def test_vit_gemm_split3_mode(built_lib, cuda_dev):
     """thmr_set_vit_gemm: the split3 mode (ViT GEMMs on the bf16 matrix pipe, fp32 operands as three bf16 pieces) against the exact-fp32
     mode of the SAME engine and against the oracle: fp32-rounding-close features, equal token indices away from near-ties, vertices
-    within 0.1 mm; deterministic; a crop's result does not depend on the batch it rides in (within 7 ... 15, 16 ... 55 and >= 56
+    within 0.1 mm; deterministic; a crop's result does not depend on the batch it rides in (within 7 ... 15, 16 ... 31 and >= 32
     crops); below 7 crops the mode changes nothing (bit-identical to the exact-fp32 path); switching back restores the exact-fp32 results bit for bit."""
     from oracle import tokenhmr_oracle as O
     from tokenhmr_amd.config import HMRConfig

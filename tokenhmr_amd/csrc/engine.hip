@@ -46,13 +46,14 @@ constexpr int kMidLoM = 7 * 192, kMidHiM = 16 * 192, kMidSplit = 2;
 constexpr int kSplit3MinB = 16;
 // ... and 7 ... 15 crops run them with proj / fc2 split K two ways (60-120 tiles of 128 x 256 otherwise): the mode's own mid regime
 constexpr int kSplit3MidMinB = 7, kSplit3MidSplit = 2;
-// fc2 (K = 5120) splits K two ways up to 55 crops: 128 x 256 tiles of K = 5120 are ~400 us blocks, and halving them shortens the ragged
+// fc2 (K = 5120) splits K two ways up to 31 crops: 128 x 256 tiles of K = 5120 are ~400 us blocks, and halving them shortens the ragged
 // last round — op level 198 vs 229 us at 16 crops, 547 vs 666 at 40, 596 vs 741 at 48 incl. the reduce
 // (profiles/r3af_split3_n1280_tile_splitk_sweep.log); per call 702 vs 658 crops/s at 16 crops, 756 vs 707 at 48 — but 773 vs 784 at 32 and
 // 775 vs 784 at 64, whose 240 / 480 tiles fill the rounds anyway and where the LayerNorm kernel then reads two partial planes for nothing
-// (profiles/r3ag_split3_fc2_splitk_all_batches.log).  One factor per RANGE (batch invariance): split up to 55 crops, unsplit from 56 on.
+// (profiles/r3ag_split3_fc2_splitk_all_batches.log).  One factor per RANGE (batch invariance): split up to 31 crops, unsplit from 32 on —
+// the boundary keeps the reference README's batch of 32 at its best (784) and gives up the 7 % at 40-48 crops.
 // proj (K = 1280) splits only up to 15 crops.
-constexpr int kSplit3Fc2Split = 2, kSplit3Fc2MaxB = 55;
+constexpr int kSplit3Fc2Split = 2, kSplit3Fc2MaxB = 31;
 // decoder + mixer stack: the persistent decoder kernel and the one-workgroup-per-crop mixer kernel win while the work is
 // latency-bound (B = 1: 0.96 vs 1.01 ms, B = 64: 1.58 vs 1.93 ms per head); from a few hundred crops on the same products are
 // real GEMMs (M = B and M = 160 B rows) and the tiled MFMA kernels win (B = 512: 6.7 vs 7.5 ms) — profiles/r2e_head_fused_vs_chain.log
