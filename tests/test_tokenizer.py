@@ -89,3 +89,61 @@ def test_gpu_encode_and_decode(built_lib, cuda_dev):
     assert torch.equal(e2.encode_tokens(pose), idx)
     e2.close()
     eng.close()
+
+
+def _write_tokenizer_file(tmp_path, cfg, with_encoder=True, arch_overrides=None):
+    """tokenizer.pth exactly as the reference writes it ({'net', 'hparams': yacs CfgNode}, eval_poseVQ.py:118-125), yacs absent at read time"""
+    from _ref_files import write_reference_files
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    sd, tok, smpl = W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0), make_synthetic_smpl(cfg, 0)
+    net = dict(tok)
+    if with_encoder:
+        net.update(W.make_synthetic_encoder(cfg, 0))
+    write_reference_files(tmp_path, cfg, sd, net, smpl, arch_overrides=arch_overrides)
+    return str(tmp_path / "tokenizer.pth"), tok
+
+
+def test_tokenizer_dropins_reject_bad_files_before_touching_a_gpu(tmp_path):
+    """DecodeTokens / EncodeTokens (tokenhmr_amd/tokenizer.py) read hparams.ARCH where the reference does (vanilla_pose_vqvae.py:265-278) and
+    refuse a tokenizer of another architecture, a file without 'net', and — EncodeTokens — a file without the encoder half."""
+    from tokenhmr_amd.tokenizer import DecodeTokens, EncodeTokens
+    cfg = HMRConfig(vit_depth=1, dec_depth=1)
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir(); (tmp_path / "c").mkdir()
+    path, _ = _write_tokenizer_file(tmp_path / "a", cfg, arch_overrides={"NB_CODE": 1024})
+    with pytest.raises(ValueError, match="NB_CODE"):
+        DecodeTokens(path)
+    path, _ = _write_tokenizer_file(tmp_path / "b", cfg, with_encoder=False)
+    with pytest.raises(KeyError, match="encoder"):
+        EncodeTokens(path)
+    torch.save({"state_dict": {}}, tmp_path / "c" / "x.pth")
+    with pytest.raises(KeyError, match="net"):
+        DecodeTokens(str(tmp_path / "c" / "x.pth"))
+
+
+@pytest.mark.gpu
+def test_gpu_tokenizer_dropins(built_lib, cuda_dev, tmp_path):
+    """The reference's stand-alone tokenizer classes as drop-ins: same constructor, same call, same result layout — against the oracle
+    (pinned to the reference's own PoseSPEncoderV1 / PoseSPDecoderV1 / QuantizeEMAReset) on a file in the reference's format."""
+    from tokenhmr_amd.tokenizer import DecodeTokens, EncodeTokens
+    cfg = HMRConfig(vit_depth=1, dec_depth=1)
+    path, tok = _write_tokenizer_file(tmp_path, cfg)
+    dec = DecodeTokens(path, device=cuda_dev, max_batch=4).eval().to(cuda_dev)
+    g = torch.Generator().manual_seed(3)
+    probs = torch.softmax(4.0 * torch.randn(9, 160, 2048, generator=g), -1)           # 9 > max_batch: chunked
+    out = dec(probs.to(cuda_dev))
+    assert out.shape == (9, 21, 6) and out.dtype == torch.float32 and out.is_cuda
+    with torch.no_grad():
+        ref = O.vq_decode(probs, tok, cfg)
+    assert (out.cpu() - ref).abs().max() < 1e-4
+    enc = EncodeTokens(path, device=cuda_dev, max_batch=4)
+    pose = make_pose()
+    idx = enc(pose.to(cuda_dev))
+    with torch.no_grad():
+        ridx, _, _ = O.vq_encode(pose, W.make_synthetic_encoder(cfg, 0), tok["quantizer.codebook"])
+    assert idx.dtype == torch.int64 and idx.shape == (pose.shape[0] * 160,)
+    assert torch.equal(idx.cpu().view(pose.shape[0], -1), ridx.view(pose.shape[0], -1).long())
+    # sharing a loaded model's engine instead of building one
+    shared = DecodeTokens(engine=dec.engine)
+    assert torch.equal(shared(probs[:3].to(cuda_dev)), out[:3])
+    with pytest.raises(ValueError):
+        dec(torch.zeros(2, 160, 100, device=cuda_dev))
