@@ -307,7 +307,9 @@ const char* thmr_collective_last_error(void);
  *      least 7 crops (below, the exact-fp32 kernels run regardless).  Three ranges, a crop's result is batch-independent within each:
  *      7 ... 15 crops split the K sums of proj and fc2 two ways, 16 ... 31 only fc2's, 32 and more neither; LayerNorm, attention, the epilogues and the head are unchanged.
  * Setting 1 needs finalized weights; the engine then owns a split3 copy of the ViT weights (1.5x their fp32 bytes) and the operand
- * buffers, rebuilt by thmr_finalize_weights while the mode is on.  Returns 0 / negative; thmr_get_vit_gemm returns the mode. */
+ * buffers (+ the partial-sum planes of its split-K ranges), rebuilt by thmr_finalize_weights while the mode is on and kept until
+ * thmr_destroy (setting 0 again does not free them).  Like thmr_forward it allocates nothing per call, so a call in either mode can be
+ * captured in a hipGraph.  Returns 0 / negative; thmr_get_vit_gemm returns the mode. */
 int thmr_set_vit_gemm(thmr_engine* e, int32_t mode, void* stream);
 int thmr_get_vit_gemm(thmr_engine* e);
 int thmr_prof_enable(thmr_engine* e, int32_t on);
