@@ -17,7 +17,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int R, bool DMA>
+// AGPR: the accumulators are forced into the AGPR half of the register file (inline-asm MFMA with "+a" operands) — does the matrix pipe
+// then share less with the VGPR writes of the LDS reads?
+template <int R, bool DMA, bool AGPR = false>
 __global__ __launch_bounds__(512) void k(float* out, const char* src, int iters) {
     __shared__ __attribute__((aligned(16))) char lds[144 * 1024];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -38,7 +40,8 @@ __global__ __launch_bounds__(512) void k(float* out, const char* src, int iters)
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int m = 0; m < 48; ++m) {
-            acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m % 12], fb[m & 1], acc[m & 3], 0, 0, 0);
+            if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[m & 3]) : "v"(fa[m % 12]), "v"(fb[m & 1]));
+            else acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m % 12], fb[m & 1], acc[m & 3], 0, 0, 0);
             if ((m % 24) * R / 24 != ((m % 24) + 1) * R / 24 && R > 0) {
                 const int r = ((m % 24) * R / 24) % 12;
                 fa[r] = *reinterpret_cast<const bf16x8*>(lp + r * 1024);
@@ -51,20 +54,21 @@ __global__ __launch_bounds__(512) void k(float* out, const char* src, int iters)
         }
         if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    if constexpr (AGPR) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // the compiler cannot see the MFMAs inside the asm: no hazard handling
     float s = 0.f;
     for (int a = 0; a < 4; ++a)
         for (int e = 0; e < 16; ++e) s += acc[a][e];
     if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
-template <int R, bool DMA>
+template <int R, bool DMA, bool AGPR = false>
 void run(const char* name, int waves, float* out, const char* src, double ms_target) {
     int iters = 2000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<R, DMA>), dim3(256), dim3(waves * 64), 0, 0, out, src, iters);
+        hipLaunchKernelGGL((k<R, DMA, AGPR>), dim3(256), dim3(waves * 64), 0, 0, out, src, iters);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms = 0;
@@ -87,6 +91,9 @@ int main() {
         run<12, false>("lds 12/24", w, out, src, 60.0);
         run<12, true>("lds 12 + dma", w, out, src, 60.0);
     }
+    run<0, false, true>("pure agpr", 8, out, src, 60.0);
+    run<12, false, true>("lds 12 agpr", 8, out, src, 60.0);
+    run<12, true, true>("lds12+dma agpr", 8, out, src, 60.0);
     run<0, false>("pure 300 ms", 8, out, src, 300.0);
     return 0;
 }
