@@ -198,8 +198,8 @@ int thmr_op_gemm(const float* A_dev, int64_t lda, const float* W_dev, const floa
  * down to 2^-16 of |a b| (what is dropped is below one fp32 rounding of the product), accumulation is fp32 in the MFMA.
  * thmr_op_split3 converts (K % 8 == 0, ld_dst % 8 == 0, ld_dst >= K, ld_src % 4 == 0).  thmr_op_gemm_split3: A / W split3 with row
  * strides lda / ldw in fp32-equivalents (multiples of 8), K % 32 == 0; bias / resid / C fp32; epi 0, 1, 2, 4, 5 as thmr_op_gemm;
- * variant -1 = the engine's rule; 0 = 128x256 tile, 8 waves; 1 = 128x256, 4 waves; 2 = 128x128, 4 waves (bit-identical to each
- * other); 100 + j = the small-M ring kernel (64x64 tiles, 4-deep LDS-DMA ring) with split-K 2^j, j <= 2 — 100 is bit-identical to the big
+ * variant -1 = the engine's rule; 0 = 128x256 tile, 8 waves; 1 = 128x256, 4 waves; 2 = 128x128, 4 waves; 4 = 256x256, 4 waves of
+ * 128x128 (all bit-identical to each other); 100 + j = the small-M ring kernel (64x64 tiles, 4-deep LDS-DMA ring) with split-K 2^j, j <= 2 — 100 is bit-identical to the big
  * tiles, the split ones associate K differently; 202 / 204 = split-K 2 / 4 on the big tiles (the engine's 7 ... 15 crops use 2);
  * (3, 31, 32, 34, 37: schedule experiments of scripts/split3_bench.py, epilogue 0 only;
  * 31-37 are timing-only and return garbage). */

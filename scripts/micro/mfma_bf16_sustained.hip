@@ -19,7 +19,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // AGPR: the accumulators are forced into the AGPR half of the register file (inline-asm MFMA with "+a" operands) — does the matrix pipe
 // then share less with the VGPR writes of the LDS reads?
-template <int R, bool DMA, bool AGPR = false>
+template <int R, bool DMA, bool AGPR = false, bool RND = false>
 __global__ __launch_bounds__(512) void k(float* out, const char* src, int iters) {
     __shared__ __attribute__((aligned(16))) char lds[144 * 1024];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -29,10 +29,20 @@ __global__ __launch_bounds__(512) void k(float* out, const char* src, int iters)
     for (int a = 0; a < 4; ++a)
         for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
     bf16x8 fa[12], fb[2];
+    // RND: operands with random bits in every position (what real activations / weights look like to the multiplier array) instead of
+    // the smooth ramps — is the sustained rate a power limit that depends on the data?
     for (int i = 0; i < 12; ++i)
-        for (int e = 0; e < 8; ++e) fa[i][e] = (__bf16)(0.001f * (lane + i + e));
+        for (int e = 0; e < 8; ++e) {
+            unsigned h = (lane * 2654435761u) ^ ((i * 8 + e + 1) * 40503u) ^ (blockIdx.x * 97u);
+            h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+            fa[i][e] = RND ? (__bf16)(((int)(h & 0xffff) - 32768) * (1.0f / 32768.0f)) : (__bf16)(0.001f * (lane + i + e));
+        }
     for (int i = 0; i < 2; ++i)
-        for (int e = 0; e < 8; ++e) fb[i][e] = (__bf16)(0.002f * (lane + i - e));
+        for (int e = 0; e < 8; ++e) {
+            unsigned h = (lane * 40503u) ^ ((i * 8 + e + 7) * 2654435761u);
+            h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+            fb[i][e] = RND ? (__bf16)(((int)(h & 0xffff) - 32768) * (1.0f / 32768.0f)) : (__bf16)(0.002f * (lane + i - e));
+        }
     // conflict-free: 16 B per lane, lanes consecutive
     const char* lp = lds + wave * 16384 + lane * 16;
     const uint32_t voff = lane * 16;
@@ -61,14 +71,14 @@ __global__ __launch_bounds__(512) void k(float* out, const char* src, int iters)
     if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
-template <int R, bool DMA, bool AGPR = false>
+template <int R, bool DMA, bool AGPR = false, bool RND = false>
 void run(const char* name, int waves, float* out, const char* src, double ms_target) {
     int iters = 2000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<R, DMA, AGPR>), dim3(256), dim3(waves * 64), 0, 0, out, src, iters);
+        hipLaunchKernelGGL((k<R, DMA, AGPR, RND>), dim3(256), dim3(waves * 64), 0, 0, out, src, iters);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms = 0;
@@ -94,6 +104,9 @@ int main() {
     run<0, false, true>("pure agpr", 8, out, src, 60.0);
     run<12, false, true>("lds 12 agpr", 8, out, src, 60.0);
     run<12, true, true>("lds12+dma agpr", 8, out, src, 60.0);
+    run<0, false, false, true>("pure random", 8, out, src, 60.0);
+    run<12, true, false, true>("lds12+dma rnd", 8, out, src, 60.0);
+    run<0, false, false, true>("pure rnd 300", 8, out, src, 300.0);
     run<0, false>("pure 300 ms", 8, out, src, 300.0);
     return 0;
 }

@@ -64,7 +64,7 @@ def main():
                 row[v] = {"us": round(t * 1e6, 1), "f32_equiv_tflops": round(flop / t * 1e-12, 1)}
             print(json.dumps(row), flush=True)
             continue
-        for v in ("128x256/w8", "128x256/w4", "128x128/w4"):
+        for v in ("128x256/w8", "128x256/w4", "128x128/w4", "256x256/w4"):
             t = timed(lambda: ops.gemm_split3(sa, sw, db, res, epi=epi, variant=v, **kw), args.iters)
             row["split3 " + v] = {"us": round(t * 1e6, 1), "f32_equiv_tflops": round(flop / t * 1e-12, 1), "vs_f32_mfma": round(t32 / t, 3)}
         if not args.no_error:

@@ -232,7 +232,7 @@ def test_gemm_split3(built_lib, cuda_dev, shape):
     bound = (a.double().abs() @ w.double().abs().t())                       # |a| . |w|: what a dot product's rounding error scales with
     e32 = ((ops.gemm(da, dw, variant="128x160").cpu().double() - ref64).abs() / bound).max().item()
     outs = {}
-    for variant in ("128x256/w8", "128x256/w4", "128x128/w4"):
+    for variant in ("128x256/w8", "128x256/w4", "128x128/w4", "256x256/w4"):
         o = ops.gemm_split3(sa, sw, variant=variant)
         es = ((o.cpu().double() - ref64).abs() / bound).max().item()
         assert es <= max(2.0 * e32, 2.0 ** -22), (variant, es, e32)
@@ -243,6 +243,7 @@ def test_gemm_split3(built_lib, cuda_dev, shape):
             ref = _gemm_ref(a, w, b, r, epi, kw.get("qscale", 1.0), kw.get("qcols", 0))
             assert torch.allclose(o.cpu(), ref, atol=2e-4, rtol=1e-5), (variant, epi, (o.cpu() - ref).abs().max())
     assert torch.equal(outs["128x256/w4"], outs["128x256/w8"]) and torch.equal(outs["128x128/w4"], outs["128x256/w8"])
+    assert torch.equal(outs["256x256/w4"], outs["128x256/w8"])
     # the small-M ring kernel: without split-K bit-identical to the big tiles (same K order per element); with split-K another association
     ring = ops.gemm_split3(sa, sw, variant="ring")
     assert torch.equal(ring, outs["128x256/w8"]) and torch.equal(ops.gemm_split3(sa, sw, variant="auto"), outs["128x256/w8"])
@@ -259,7 +260,7 @@ def test_gemm_split3(built_lib, cuda_dev, shape):
             half = ops.gemm_split3(ops.split3(da[:M // 2].contiguous()), sw, db, dr[:M // 2].contiguous(), epi="bias_resid", variant=name)
             assert torch.equal(half, o[:M // 2]), name
     if N % 8 == 0:      # the epilogue's result as the next GEMM's split3 operand: bit-identical to converting the fp32 result
-        for variant in ("128x256/w8", "128x256/w4", "128x128/w4", "ring"):
+        for variant in ("128x256/w8", "128x256/w4", "128x128/w4", "256x256/w4", "ring"):
             for epi, kw in (("none", {}), ("bias", {}), ("bias_gelu", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
                 bb = None if epi == "none" else db
                 fused = ops.gemm_split3(sa, sw, bb, epi=epi, variant=variant, out_split=True, **kw)

@@ -1543,7 +1543,7 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
     if (epi == EPI_BIAS_RESID && !resid) return fail(e, THMR_ERR_INVALID, "epilogue needs resid");
     if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || ldc < N)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: K % 32 == 0, lda / ldw multiples of 8 and >= K, ldc >= N");
-    if (!(variant >= -1 && variant <= 3) && variant != 31 && variant != 32 && variant != 34 && variant != 37 && !(variant >= 100 && variant <= 102) &&
+    if (!(variant >= -1 && variant <= 4) && variant != 31 && variant != 32 && variant != 34 && variant != 37 && !(variant >= 100 && variant <= 102) &&
         variant != 202 && variant != 204)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 1, 2, 100-102, 202, 204 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, resid, ldc, C, ldc, M, N, K);
@@ -1611,7 +1611,7 @@ int thmr_op_gemm_split3_out_split3(const void* A, int64_t lda, const void* W, in
     if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || (N % 8) != 0 ||
         (ldcs % 8) != 0 || ldcs < N)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: K % 32 == 0, N % 8 == 0, lda / ldw / ldcs multiples of 8 and >= K / K / N");
-    if ((variant < -1 || variant > 2) && variant != 100) return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 1, 2 or 100 (small-M ring kernel)");
+    if ((variant < -1 || variant > 2) && variant != 4 && variant != 100) return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 1, 2, 4 or 100 (small-M ring kernel)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, nullptr, 0, nullptr, 0, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
     a.c_split = Cs; a.ldcs = ldcs;

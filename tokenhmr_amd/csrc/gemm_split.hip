@@ -477,11 +477,149 @@ __global__ __launch_bounds__(256) void gemm_split3_ring_kernel(GemmArgs a, int t
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 x 256 block tile, 4 waves of 128 x 128 (ONE wave per SIMD, 256 accumulator registers), 16-deep stages — fewer LDS bytes per MFMA:
+// a step needs 24 ds_read_b128 for 96 MFMAs (0.25 per MFMA against the 64 x 64 wave tile's 0.5) and the tile 125 B of copies per MFMA
+// (192).  The schedule ablation of the 128 x 256 kernel prices the fragment reads at 20 % and the copies at 12.5 % of its time
+// (profiles/r3v_split3_schedule_ablation.jsonl); this variant trades that against having no second wave per SIMD.
+// A stage is 512 rows x 96 B = 48 KB (two stages); 6 chunks per row = 24 banks, rows r and r + 8 of a ds_read_b128 lane group collide,
+// hence rot(r) = (r >> 3) & 1.  Per K tile (one step of 16 k): the copies of tile kt + 2 into the buffer whose fragments were read during
+// the previous tile, the reads of tile kt + 1's fragments from the other buffer, 96 MFMAs; barrier.  Same K order per element as the other
+// tiles (per 16 k: lh hl mm mh hm hh) -> bit-identical results.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_split3_wide_kernel(GemmArgs a, int tiles_m, int tiles_n, int nwg) {
+    constexpr int TM = 4, TN = 4, WN = 2, NW = 4, BM = 256, BN = 256;
+    constexpr int WSLOTS = 6, WROWB = 96;                             // 16 k: 2 k-groups x 3 pieces
+    constexpr int A_STAGE = BM * WROWB, B_STAGE = BN * WROWB;         // 24 KB each
+    constexpr int A_P = BM * WSLOTS / 64 / NW, B_P = BN * WSLOTS / 64 / NW, NP = A_P + B_P;     // 6 + 6 copies per wave and tile
+    __shared__ __attribute__((aligned(16))) char smem[2 * (A_STAGE + B_STAGE)];
+    char* As = smem;
+    char* Bs = smem + 2 * A_STAGE;
+
+    int tile_m, tile_n;
+    tile_coords(tiles_m, tiles_n, logical_block(nwg, 0), tile_m, tile_n);
+    const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+    const int nk = a.K / 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / WN) * TM * 32, wn0 = (wave % WN) * TN * 32;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+
+    const int64_t arow = a.lda * 6, wrow = a.ldw * 6;
+    const char* Abase = reinterpret_cast<const char*>(a.A) + (int64_t)bm0 * arow;
+    const char* Wbase = reinterpret_cast<const char*>(a.W) + (int64_t)bn0 * wrow;
+    uint32_t Aoff[A_P], Woff[B_P];
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+        const int c = (wave + i * NW) * 64 + lane, row = c / WSLOTS, slot = c - row * WSLOTS;
+        const int j = (slot + WSLOTS - ((row >> 3) & 1)) % WSLOTS;
+        Aoff[i] = (uint32_t)(min(bm0 + row, a.M - 1) - bm0) * (uint32_t)arow + (uint32_t)j * 16u;
+        Woff[i] = (uint32_t)(min(bn0 + row, a.N - 1) - bn0) * (uint32_t)wrow + (uint32_t)j * 16u;
+    }
+    auto dma_piece = [&](int kt, int buf, int p) {
+        const int64_t k0b = (int64_t)kt * WROWB;
+        if (p < A_P) dma16_saddr(Abase + k0b, Aoff[p], lds_addr_b(As + buf * A_STAGE + (wave + p * NW) * 1024));
+        else dma16_saddr(Wbase + k0b, Woff[p - A_P], lds_addr_b(Bs + buf * B_STAGE + (wave + (p - A_P) * NW) * 1024));
+    };
+    uint32_t fo[3];
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+        fo[pc] = (uint32_t)lrow * WROWB + (uint32_t)(((lhalf * 3 + pc) + ((lrow >> 3) & 1)) % WSLOTS) * 16u;
+    const char* Afr = As + wm0 * WROWB;
+    const char* Bfr = Bs + wn0 * WROWB;
+    bf16x8 af[2][TM][3], bf[2][TN][3];
+    constexpr int NR = 3 * (TM + TN);
+    auto read_one = [&](int buf, int set, int r) {
+        if (r < 3 * TM) {
+            const int mi = r / 3, pc = r % 3;
+            af[set][mi][pc] = *reinterpret_cast<const bf16x8*>(Afr + buf * A_STAGE + mi * 32 * WROWB + fo[pc]);
+        } else {
+            const int q = r - 3 * TM, ni = q / 3, pc = q % 3;
+            bf[set][ni][pc] = *reinterpret_cast<const bf16x8*>(Bfr + buf * B_STAGE + ni * 32 * WROWB + fo[pc]);
+        }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#pragma unroll
+    for (int p = 0; p < NP; ++p) dma_piece(0, 0, p);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) dma_piece(min(1, nk - 1), 1, p);
+    dma_wait_barrier();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) read_one(0, 0, r);
+
+    auto ktile = [&](int kt, auto bufc) {
+        constexpr int buf = decltype(bufc){};                        // buffer and fragment set of tile kt
+        const int kt2 = min(kt + 2, nk - 1);
+#pragma unroll
+        for (int p = 0; p < NPROD; ++p)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const int idx = (p * TM + mi) * TN + ni;
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[buf][mi][piece_a(p)], bf[buf][ni][piece_w(p)], acc[mi][ni], 0, 0, 0);
+                    bool any = false;
+                    if (idx < NP) { dma_piece(kt2, buf, idx); any = true; }
+                    else if (idx - NP < NR) { read_one(buf ^ 1, buf ^ 1, idx - NP); any = true; }
+                    if (any) __builtin_amdgcn_sched_barrier(0);
+                }
+        __builtin_amdgcn_sched_barrier(0);
+        dma_wait_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        ktile(kt, IntC<0>{});
+        ktile(kt + 1, IntC<1>{});
+    }
+    if (kt < nk) ktile(kt, IntC<0>{});
+
+    if (a.c_split) {
+        // one 32-row slice of the wave tile at a time through a wave-private 32 x 132 fp32 tile (the stage buffers are dead)
+        constexpr int WT = TN * 32 + 4;
+        static_assert(NW * 32 * WT * 4 <= 2 * (A_STAGE + B_STAGE), "transpose tile does not fit the stage buffers");
+        float* T = reinterpret_cast<float*>(smem) + wave * (32 * WT);
+        static_for<TM>([&](auto mic) {
+            constexpr int mi = decltype(mic){};
+            store_tile_split3<1, TN, EPI>(a, reinterpret_cast<f32x16(&)[1][TN]>(acc[mi]), T, bm0 + wm0 + mi * 32, bn0 + wn0, lane);
+        });
+        return;
+    }
+    store_tile<TM, TN, EPI>(a, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
+}
+
 template <int WM, int WN, int TM, int TN, int ABL, int RS>
 int launch_split3_abl(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, nwg = tiles_m * tiles_n;
     hipLaunchKernelGGL((gemm_split3_kernel<WM, WN, TM, TN, EPI_NONE, ABL, RS>), dim3(nwg), dim3(WM * WN * 64), 0, s, a, tiles_m, tiles_n, nwg);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_split3_wide(const GemmArgs& a, int epi, hipStream_t s) {
+    if (a.ksplit > 1) return -1;
+    const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256, nwg = tiles_m * tiles_n;
+    const dim3 grid(nwg), block(256);
+#define THMR_WIDE_CASE(E)                                                                                       \
+    case E:                                                                                                     \
+        hipLaunchKernelGGL((gemm_split3_wide_kernel<E>), grid, block, 0, s, a, tiles_m, tiles_n, nwg);          \
+        break;
+    switch (epi) {
+        THMR_WIDE_CASE(EPI_NONE)
+        THMR_WIDE_CASE(EPI_BIAS)
+        THMR_WIDE_CASE(EPI_BIAS_GELU)
+        THMR_WIDE_CASE(EPI_BIAS_RESID)
+        THMR_WIDE_CASE(EPI_BIAS_QSCALE)
+        default: return -1;
+    }
+#undef THMR_WIDE_CASE
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -566,6 +704,7 @@ static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStrea
         case 0: return launch_split3_cfg<2, 4, 2, 2>(a, epi, s);
         case 1: return launch_split3_cfg<2, 2, 2, 4>(a, epi, s);
         case 2: return launch_split3_cfg<2, 2, 2, 2>(a, epi, s);
+        case 4: return launch_split3_wide(a, epi, s);               // 256 x 256, 4 waves of 128 x 128, 16-deep stages
         // experiments on the default tile, EPI_NONE only: 3 = step-0 fragment reads every 2nd MFMA (the first version's schedule);
         // 31 / 32 / 34 / 37 = timing-only ablations (no copies / no barrier / no fragment reads / none of the three): garbage results
         case 3: return epi == EPI_NONE ? launch_split3_abl<2, 4, 2, 2, 0, 2>(a, s) : -1;

@@ -41,7 +41,7 @@ def gemm(a, w, bias=None, resid=None, epi="none", qscale=1.0, qcols=0, variant="
     return out
 
 
-SPLIT3_VARIANT = {"auto": -1, "128x256/w8": 0, "128x256/w4": 1, "128x128/w4": 2, "ring": 100, "ring/k2": 101, "ring/k4": 102, "auto/k2": 202, "auto/k4": 204,
+SPLIT3_VARIANT = {"auto": -1, "128x256/w8": 0, "128x256/w4": 1, "128x128/w4": 2, "256x256/w4": 4, "ring": 100, "ring/k2": 101, "ring/k4": 102, "auto/k2": 202, "auto/k4": 204,
                   # schedule experiments (epilogue "none" only; the abl/* ones are timing-only, their results are garbage)
                   "exp/reads-every-2nd": 3, "abl/no-copies": 31, "abl/no-barrier": 32, "abl/no-reads": 34, "abl/none": 37}
 
