@@ -344,8 +344,8 @@ def main():
     eng.finalize(assume_all_loaded=(rank != 0))
     split_mode = a.vit_gemm == "split3"
     if split_mode:
-        if cpu_dry or B < 7:
-            sys.exit("--vit-gemm split3 needs real engines and at least 7 crops per GPU (below, the mode runs the exact-fp32 kernels)")
+        if cpu_dry or B < 3:
+            sys.exit("--vit-gemm split3 needs real engines and at least 3 crops per GPU (below, the mode runs the exact-fp32 kernels)")
         eng.set_vit_gemm("split3")
 
     def crops_of(r):
@@ -562,7 +562,7 @@ def main():
                           "vs_engine_forward": round((elapsed / a.steps * 1e3) / f_ms, 4),
                           "what": "TokenHMR facade model({'img': ...}) -> dict, outputs allocated per call (untimed extra)"}
         split3 = None
-        if world == 1 and not a.no_extras and not cpu_dry and B >= 7 and not split_mode:
+        if world == 1 and not a.no_extras and not cpu_dry and B >= 3 and not split_mode:
             # SECOND measurement, not `value`: the same K steps with the ViT GEMMs in the engine's opt-in "split3" mode — fp32 operands
             # as three bf16 pieces on the bf16 matrix pipe, six products, fp32 accumulation (csrc/gemm_split.hip).  fp32-grade, not
             # bitwise fp32; its parity against the reference golden is reported beside the headline's.  The headline above is exact-fp32 MFMA.

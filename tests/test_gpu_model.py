@@ -228,8 +228,8 @@ def _check_b64_golden(out, g, tag):
 def test_vit_gemm_split3_mode(built_lib, cuda_dev):
     """thmr_set_vit_gemm: the split3 mode (ViT GEMMs on the bf16 matrix pipe, fp32 operands as three bf16 pieces) against the exact-fp32
     mode of the SAME engine and against the oracle: fp32-rounding-close features, equal token indices away from near-ties, vertices
-    within 0.1 mm; deterministic; a crop's result does not depend on the batch it rides in (within 7 ... 15, 16 ... 31 and >= 32
-    crops); below 7 crops the mode changes nothing (bit-identical to the exact-fp32 path); switching back restores the exact-fp32 results bit for bit."""
+    within 0.1 mm; deterministic; a crop's result does not depend on the batch it rides in (within 3 ... 4, 5 ... 15, 16 ... 31
+    and >= 32 crops); one and two crops: the mode changes nothing (bit-identical to the exact-fp32 path); switching back restores the exact-fp32 results bit for bit."""
     from oracle import tokenhmr_oracle as O
     from tokenhmr_amd.config import HMRConfig
     from tokenhmr_amd.model import TokenHMR
@@ -253,10 +253,22 @@ def test_vit_gemm_split3_mode(built_lib, cuda_dev):
         assert torch.equal(s3[k], again[k]), k                                  # deterministic
         assert torch.equal(s3[k], s3_24[k][:20]), k                             # batch-independent
     s3_12 = _to_cpu(model({"img": img[:12]}))
+    f32_2, f32_4 = None, None
+    model.engine.set_vit_gemm("f32")
+    f32_2, f32_4 = _to_cpu(model({"img": img[:2]})), _to_cpu(model({"img": img[:4]}))
+    model.engine.set_vit_gemm("split3")
+    s3_2, s3_3, s3_4 = _to_cpu(model({"img": img[:2]})), _to_cpu(model({"img": img[:3]})), _to_cpu(model({"img": img[:4]}))
+    s3_6 = _to_cpu(model({"img": img[:6]}))
     for k in ("pred_vertices", "cls_logits", "vit_features"):
-        assert torch.equal(s3_small[k], f32_small[k]), k                        # under 7 crops: the exact-fp32 kernels whatever the mode
-        assert not torch.equal(s3_mid[k], f32_mid[k]), k                        # 7 ... 15 crops: the mode's mid regime (proj / fc2 split K two ways)
-        assert torch.equal(s3_mid[k], s3_12[k][:9]), k                          # ... batch-independent within it
+        assert torch.equal(s3_2[k], f32_2[k]), k                                # one and two crops: the exact-fp32 kernels whatever the mode
+        assert not torch.equal(s3_4[k], f32_4[k]) and torch.equal(s3_3[k], s3_4[k][:3]), k      # 3 and 4 crops: proj / fc2 split K four ways
+        assert not torch.equal(s3_mid[k], f32_mid[k]), k                        # 5 ... 15 crops: two ways
+        assert torch.equal(s3_mid[k], s3_12[k][:9]) and torch.equal(s3_small[k], s3_6[k][:5]), k      # ... batch-independent within it
+    # (the head has its own regime boundary between 6 and 7 crops, so the outputs are bit-identical within 5 ... 6 and within 7 ... 15; the
+    # ViT features within the whole range)
+    assert torch.equal(s3_small["vit_features"], s3_12["vit_features"][:5])
+    assert (s3_4["vit_features"] - f32_4["vit_features"]).abs().max() < 2e-4 and torch.equal(s3_4["token_idx"], f32_4["token_idx"])
+    assert (s3_4["pred_vertices"] - s3_mid["pred_vertices"][:4]).abs().max() < 2e-5
     assert (s3_mid["vit_features"] - f32_mid["vit_features"]).abs().max() < 2e-4
     assert (s3_mid["pred_vertices"] - f32_mid["pred_vertices"]).abs().max() < 1e-4 and torch.equal(s3_mid["token_idx"], f32_mid["token_idx"])
     assert (s3_mid["pred_vertices"] - s3["pred_vertices"][:9]).abs().max() < 2e-5      # the two ranges agree to fp32 rounding

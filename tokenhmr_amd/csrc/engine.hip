@@ -45,7 +45,11 @@ constexpr int kMidLoM = 7 * 192, kMidHiM = 16 * 192, kMidSplit = 2;
 // CU: below the big-tile regime the exact-fp32 kernels with their smaller tiles and split-K stay in charge)
 constexpr int kSplit3MinB = 16;
 // ... and 7 ... 15 crops run them with proj / fc2 split K two ways (60-120 tiles of 128 x 256 otherwise): the mode's own mid regime
-constexpr int kSplit3MidMinB = 7, kSplit3MidSplit = 2;
+constexpr int kSplit3MidMinB = 5, kSplit3MidSplit = 2;
+// ... and 3 and 4 crops four ways (100-120 workgroups of 128 x 128 otherwise: fc2 3.3 vs 2.0 ms per call for the exact-fp32 ring kernel);
+// with them 5 / 6 crops run at 447 / 478 crops/s against 413 / 423 (profiles/r3am_split3_mid_regime_3_to_6_crops.log).  One and two
+// crops (2-3 row tiles of 128) stay with the exact-fp32 kernels.
+constexpr int kSplit3LowMinB = 3, kSplit3LowSplit = 4;
 // fc2 (K = 5120) splits K two ways up to 31 crops: 128 x 256 tiles of K = 5120 are ~400 us blocks, and halving them shortens the ragged
 // last round — op level 198 vs 229 us at 16 crops, 547 vs 666 at 40, 596 vs 741 at 48 incl. the reduce
 // (profiles/r3af_split3_n1280_tile_splitk_sweep.log); per call 702 vs 658 crops/s at 16 crops, 756 vs 707 at 48 — but 773 vs 784 at 32 and
@@ -485,13 +489,16 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
     };
     const float* lastn_w = e->hot.lastn_w;
     const float* lastn_b = e->hot.lastn_b;
-    const int s3_min = e->split3_min_b > 0 ? e->split3_min_b : kSplit3MidMinB;
+    const int s3_min = e->split3_min_b > 0 ? e->split3_min_b : kSplit3LowMinB;
     if (e->vit_gemm_mode == 1 && B >= s3_min) {
         // 7 ... 15 crops: proj / fc2 split K two ways into `part`, reduced (in a fixed order) by the residual + LayerNorm kernel, as in the
         // exact-fp32 path's mid regime; 16 crops and more: unsplit.  One factor per range: a crop's result is batch-independent within it.
-        const int s3_split = B < kSplit3MinB ? kSplit3MidSplit : 1;
-        const int s3_fc2 = B <= kSplit3Fc2MaxB ? e->split3_fc2_split : 1;
-        float* part2 = reinterpret_cast<float*>(e->split_act + (size_t)e->max_batch * TOK * (DIM + MLP) * 6);      // fc2's partial sums (any batch size)
+        const bool s3_low = B < kSplit3MidMinB;                  // 3 and 4 crops: both N = 1280 GEMMs four ways
+        const int s3_split = s3_low ? kSplit3LowSplit : B < kSplit3MinB ? kSplit3MidSplit : 1;
+        const int s3_fc2 = s3_low ? kSplit3LowSplit : B <= kSplit3Fc2MaxB ? e->split3_fc2_split : 1;
+        // fc2's partial sums: the engine-owned planes behind the operand buffers (two planes for any batch size); the four planes of
+        // 3 and 4 crops fit the scratch arena's `part` (4 x 1152 rows)
+        float* part2 = s3_low ? part : reinterpret_cast<float*>(e->split_act + (size_t)e->max_batch * TOK * (DIM + MLP) * 6);
         // The four GEMMs as split3 products on the bf16 matrix pipe (csrc/gemm_split.hip); everything else — patch embed, attention,
         // LayerNorm arithmetic, epilogues — is the fp32 path's.  A operands: the LayerNorms, the attention kernel and fc1's GELU epilogue
         // write their results directly as three bf16 pieces (hs, bs): no conversion pass, no fp32 copy of those activations.

@@ -249,7 +249,7 @@ class Engine:
 
     def set_vit_gemm(self, mode="f32"):
         """"f32" (default): exact-fp32 MFMA.  "split3": fp32 operands as three bf16 pieces on the bf16 matrix pipe (six products, fp32
-        accumulate; fp32-grade, not bitwise fp32) for calls of at least 7 crops — see thmr_set_vit_gemm in the header."""
+        accumulate; fp32-grade, not bitwise fp32) for calls of at least 3 crops — see thmr_set_vit_gemm in the header."""
         with torch.cuda.device(self.device):
             _cabi.check(self.lib.thmr_set_vit_gemm(self.h, self.VIT_GEMM[mode], _stream_ptr(self.device)), self.h)
 

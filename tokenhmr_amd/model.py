@@ -200,7 +200,7 @@ def load_tokenhmr(checkpoint_path="", model_cfg="", dataset_dir="", is_train_sta
     """Drop-in for tokenhmr/lib/models/__init__.py:3-26: (model, cfg) from the reference's files.  See read_reference_files
     for what is read and how; `device` is where the engine is built (the reference builds on the CPU and the caller moves the
     module, eval.py:52-54 — an engine cannot be moved, so pass the target here; `.to()` of the same device is a no-op).
-    `vit_gemm`: "f32" (exact-fp32 MFMA, the default) or "split3" (Engine.set_vit_gemm: the ViT GEMMs of calls of 7 crops and more on
+    `vit_gemm`: "f32" (exact-fp32 MFMA, the default) or "split3" (Engine.set_vit_gemm: the ViT GEMMs of calls of 3 crops and more on
     the bf16 matrix pipe with fp32 operands as three bf16 pieces — fp32-grade, ~1.4x the rate); None reads $THMR_VIT_GEMM, so that
     an unmodified eval.py can be switched from the shell."""
     hcfg, state, tok, smpl, cfg = read_reference_files(checkpoint_path, model_cfg, dataset_dir, is_train_state, strict)
