@@ -200,7 +200,7 @@ int thmr_op_gemm(const float* A_dev, int64_t lda, const float* W_dev, const floa
  * strides lda / ldw in fp32-equivalents (multiples of 8), K % 32 == 0; bias / resid / C fp32; epi 0, 1, 2, 4, 5 as thmr_op_gemm;
  * variant -1 = the engine's rule; 0 = 128x256 tile, 8 waves; 1 = 128x256, 4 waves; 2 = 128x128, 4 waves; 4 = 256x256, 4 waves of
  * 128x128 (all bit-identical to each other); 100 + j = the small-M ring kernel (64x64 tiles, 4-deep LDS-DMA ring) with split-K 2^j, j <= 2 — 100 is bit-identical to the big
- * tiles, the split ones associate K differently; 202 / 204 = split-K 2 / 4 on the big tiles (the engine's 7 ... 15 crops use 2);
+ * tiles, the split ones associate K differently; 202 / 204 = split-K 2 / 4 on the big tiles (the engine's 5 ... 31 crops use 2, 3 and 4 crops 4);
  * (3, 31, 32, 34, 37: schedule experiments of scripts/split3_bench.py, epilogue 0 only;
  * 31-37 are timing-only and return garbage). */
 int thmr_op_split3(const float* src_dev, int64_t ld_src, void* dst_dev, int64_t ld_dst, int64_t rows, int32_t K, void* stream);

@@ -44,7 +44,7 @@ constexpr int kMidLoM = 7 * 192, kMidHiM = 16 * 192, kMidSplit = 2;
 // thmr_set_vit_gemm(1): batches of at least this many crops run the ViT GEMMs as split3 products (128 x 256 tiles, one workgroup per
 // CU: below the big-tile regime the exact-fp32 kernels with their smaller tiles and split-K stay in charge)
 constexpr int kSplit3MinB = 16;
-// ... and 7 ... 15 crops run them with proj / fc2 split K two ways (60-120 tiles of 128 x 256 otherwise): the mode's own mid regime
+// ... and 5 ... 15 crops run them with proj / fc2 split K two ways (60-120 tiles of 128 x 256 otherwise): the mode's own mid regime
 constexpr int kSplit3MidMinB = 5, kSplit3MidSplit = 2;
 // ... and 3 and 4 crops four ways (100-120 workgroups of 128 x 128 otherwise: fc2 3.3 vs 2.0 ms per call for the exact-fp32 ring kernel);
 // with them 5 / 6 crops run at 447 / 478 crops/s against 413 / 423 (profiles/r3am_split3_mid_regime_3_to_6_crops.log).  One and two
@@ -491,8 +491,9 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
     const float* lastn_b = e->hot.lastn_b;
     const int s3_min = e->split3_min_b > 0 ? e->split3_min_b : kSplit3LowMinB;
     if (e->vit_gemm_mode == 1 && B >= s3_min) {
-        // 7 ... 15 crops: proj / fc2 split K two ways into `part`, reduced (in a fixed order) by the residual + LayerNorm kernel, as in the
-        // exact-fp32 path's mid regime; 16 crops and more: unsplit.  One factor per range: a crop's result is batch-independent within it.
+        // 3 ... 4 / 5 ... 15 crops: proj / fc2 split K four / two ways into `part`, reduced (in a fixed order) by the residual + LayerNorm kernel,
+        // as in the exact-fp32 path's regimes; 16 ... 31: only fc2 (two ways); 32 and more: unsplit.  One factor per range: a crop's result is
+        // batch-independent within it.
         const bool s3_low = B < kSplit3MidMinB;                  // 3 and 4 crops: both N = 1280 GEMMs four ways
         const int s3_split = s3_low ? kSplit3LowSplit : B < kSplit3MinB ? kSplit3MidSplit : 1;
         const int s3_fc2 = s3_low ? kSplit3LowSplit : B <= kSplit3Fc2MaxB ? e->split3_fc2_split : 1;

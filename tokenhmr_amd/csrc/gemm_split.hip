@@ -673,7 +673,7 @@ int launch_gemm_split3(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     return launch_split3_tiles(a, epi, variant, s);
 }
 
-// Split-K on the split3 big tiles (the mode's 7 ... 15 crops: the N = 1280 GEMMs have 60-120 tiles of 128 x 256): `ksplit` copies of the tile
+// Split-K on the split3 big tiles (the mode's 3 ... 31 crops: the N = 1280 GEMMs have 25-240 tiles of 128 x 256): `ksplit` copies of the tile
 // grid in ONE launch, copy sp reducing K slice sp into part[sp][M][N] (raw fp32 partial tiles, no epilogue), summed in a fixed order by the
 // residual + LayerNorm kernel that follows proj / fc2 anyway.  Tile by the same rule over tiles * ksplit (bit-identical either way).
 int launch_gemm_split3_splitk(const GemmArgs& a0, int ksplit, float* part, hipStream_t s) {

@@ -383,7 +383,7 @@ int launch_splitk_epilogue(const GemmArgs& a, int epi, const float* part, int S,
 int launch_splitk_resid_ln(const float* part, int S, int rows, int D, const float* bias, const float* resid, float* xout,
                            const float* gamma, const float* beta, float* y, float eps, hipStream_t s, bool y_is_split3) {
     if (rows <= 0 || S < 1 || D != 1280) return -1;
-    if (y_is_split3) {      // the split3 mode's regimes: 2 ways (7 ... 15 crops) or 4 ways (the small-batch experiment)
+    if (y_is_split3) {      // the split3 mode's ranges: 2 ways (5 ... 31 crops) or 4 ways (3 and 4 crops)
         if (S == 4)
             hipLaunchKernelGGL((splitk_resid_ln_kernel<5, 4, true>), dim3((rows + 3) / 4), dim3(256), 0, s, part, S, (int64_t)rows * D, bias,
                                resid, xout, gamma, beta, y, rows, eps);
