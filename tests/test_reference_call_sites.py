@@ -110,3 +110,36 @@ def test_every_output_key_the_reference_reads_is_produced():
     assert set_keys, "no output[...] assignment found in forward_step"
     assert set_keys <= keys, (set_keys - keys)
     assert nested.get("pred_smpl_params") == {"global_orient", "body_pose", "betas"}
+
+
+def test_tokenizer_dropins_keep_the_reference_constructors_and_call_sites():
+    """tokenhmr_amd.tokenizer.DecodeTokens / EncodeTokens: the reference classes' constructor parameters come first, in order, with the same
+    defaults (vanilla_pose_vqvae.py:258-262, :304-307), and the one place the reference instantiates and calls DecodeTokens
+    (heads/token_classifier.py: Proxy) passes nothing the drop-in does not take."""
+    from tokenhmr_amd import tokenizer as T
+    tok_src = os.path.join(os.path.dirname(REF), "tokenization", "models", "vanilla_pose_vqvae.py")
+    with open(tok_src) as f:
+        tree = ast.parse(f.read())
+    for cls_name in ("DecodeTokens", "EncodeTokens"):
+        cls = next(n for n in ast.walk(tree) if isinstance(n, ast.ClassDef) and n.name == cls_name)
+        init = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "__init__")
+        ref_args = [a.arg for a in init.args.args][1:]
+        ref_defaults = [ast.literal_eval(d) for d in init.args.defaults]
+        mine = inspect.signature(getattr(T, cls_name).__init__)
+        names = list(mine.parameters)[1:]
+        assert names[:len(ref_args)] == ref_args, (cls_name, names, ref_args)
+        assert [mine.parameters[a].default for a in ref_args] == ref_defaults, cls_name
+        fwd = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "forward")
+        assert len(fwd.args.args) == 2 and len(inspect.signature(getattr(T, cls_name).forward).parameters) == 2      # (self, x)
+    # the reference's own call site (token_classifier.py:85): eval('VanillaDecodeTokens')(tokenizer_checkpoint_path), handed to Proxy, which
+    # moves it with .to(x.device) and calls it with the token probabilities (:12-20)
+    tc = _parse("lib/models/heads/token_classifier.py")
+    calls = [n for n in ast.walk(tc) if isinstance(n, ast.Call) and isinstance(n.func, ast.Call) and isinstance(n.func.func, ast.Name)
+             and n.func.func.id == "eval"]
+    assert calls, "the reference no longer instantiates the tokenizer through eval(...)(ckpt_path) in token_classifier.py?"
+    ok = set(inspect.signature(T.DecodeTokens.__init__).parameters)
+    for c in calls:
+        assert len(c.args) == 1 and all(k.arg in ok for k in c.keywords), ast.dump(c)
+    proxy = next(n for n in ast.walk(tc) if isinstance(n, ast.ClassDef) and n.name == "Proxy")
+    used = {n.attr for n in ast.walk(proxy) if isinstance(n, ast.Attribute) and isinstance(n.value, ast.Attribute) and n.value.attr == "tokenizer"}
+    assert used <= {"to"} and all(hasattr(T.DecodeTokens, a) for a in used | {"__call__"}), used
