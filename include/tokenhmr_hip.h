@@ -305,7 +305,7 @@ const char* thmr_collective_last_error(void);
  *      (csrc/gemm_split.hip; thmr_op_gemm_split3 is the same kernel).  fp32-GRADE, not bitwise fp32: the measured error against an fp64
  *      product is no larger than the exact-fp32 kernel's (tests/test_gpu_ops.py::test_gemm_split3), at ~1.6x its rate.  Applies to calls of at
  *      least 3 crops (one and two crops run the exact-fp32 kernels regardless).  Four ranges, a crop's result is batch-independent within
- *      each: 3 and 4 crops split the K sums of proj and fc2 four ways, 5 ... 15 two ways, 16 ... 31 only fc2's (two ways), 32 and more neither; LayerNorm, attention, the epilogues and the head are unchanged.
+ *      each: 3 and 4 crops split the K sums of proj and fc2 four ways, 5 ... 15 two ways, 16 ... 31 only fc2's (two ways), 32 and more neither; the decoder's stacked to_kv GEMM runs the same way; LayerNorm, attention, the epilogues and the rest of the head are unchanged.
  * Setting 1 needs finalized weights; the engine then owns a split3 copy of the ViT weights (1.5x their fp32 bytes) and the operand
  * buffers (+ the partial-sum planes of its split-K ranges), rebuilt by thmr_finalize_weights while the mode is on and kept until
  * thmr_destroy (setting 0 again does not free them).  Like thmr_forward it allocates nothing per call, so a call in either mode can be

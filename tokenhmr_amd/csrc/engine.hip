@@ -119,6 +119,7 @@ struct thmr_engine {
     char* split_act = nullptr;
     struct SplitW { const char *qkv, *proj, *fc1, *fc2; };
     std::vector<SplitW> vitw_s;
+    const char* kv_s = nullptr;       // split3 copy of the decoder's stacked to_kv weights (dec_depth * 1024 rows x 1280)
     unsigned* host_err = nullptr;     // host-mapped sticky error word of the persistent decoder kernel (hipHostMalloc)
     std::string err;
     // derived / constant regions (float offsets in weight arena)
@@ -745,8 +746,17 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
     const int ldkv = e->dec_depth * 2 * INNER;
     {   // K8: to_kv of all decoder layers in ONE GEMM on the un-normalised context (pose_transformer.py:102,113)
         ProfScope ps(e, st, THMR_PROF_DEC_KV, 2.0 * M * DIM * (double)ldkv, 4.0 * ((double)M * DIM + (double)ldkv * DIM + (double)M * ldkv));
-        GemmArgs a = mk(ctx, DIM, e->warena + e->o_kv_all, DIM, nullptr, nullptr, 0, big, ldkv, M, ldkv, DIM);
-        LAUNCH_OK(launch_gemm(a, EPI_NONE, -1, st));
+        const int s3_min = e->split3_min_b > 0 ? e->split3_min_b : kSplit3LowMinB;
+        if (e->vit_gemm_mode == 1 && B >= s3_min && e->kv_s) {
+            // split3 mode: the context (fp32: it may be a caller's buffer) converted into the ViT's idle operand buffer, then the same product
+            // on the bf16 matrix pipe (1.5 -> 1.0 ms at 64 crops)
+            LAUNCH_OK(launch_split3(ctx, DIM, e->split_act, DIM, M, DIM, st));
+            GemmArgs a = mk(reinterpret_cast<const float*>(e->split_act), DIM, reinterpret_cast<const float*>(e->kv_s), DIM, nullptr, nullptr, 0, big, ldkv, M, ldkv, DIM);
+            LAUNCH_OK(launch_gemm_split3(a, EPI_NONE, -1, st));
+        } else {
+            GemmArgs a = mk(ctx, DIM, e->warena + e->o_kv_all, DIM, nullptr, nullptr, 0, big, ldkv, M, ldkv, DIM);
+            LAUNCH_OK(launch_gemm(a, EPI_NONE, -1, st));
+        }
     }
     ProfScope ps_head(e, st, THMR_PROF_HEAD, 2.0 * B * (6.0 * 4.2e6 + 116.7e6 + 167.8e6 + 705.0e6), 0);
     float *dx = e->S(so.dx), *dh = e->S(so.dh), *dv = e->S(so.dv), *dq = e->S(so.dq), *dca = e->S(so.dca), *dff = e->S(so.dff);
@@ -1148,7 +1158,8 @@ int thmr_load_smpl(thmr_engine* e, const thmr_smpl_desc* s, void* stream) {
 // split3 copies of the four ViT GEMM weights of every block (6 bytes per weight) + the activation operand buffers, engine-owned
 static int build_split_weights(thmr_engine* e, hipStream_t st) {
     const size_t per_block = (size_t)DIM * (3 * DIM) + (size_t)DIM * DIM + 2 * (size_t)DIM * MLP;      // weights of one block
-    if (!e->split_w && hipMalloc(reinterpret_cast<void**>(&e->split_w), per_block * 6 * e->vit_depth) != hipSuccess)
+    const size_t kv_rows = (size_t)e->dec_depth * 2 * INNER;                                           // + the decoder's to_kv of all layers
+    if (!e->split_w && hipMalloc(reinterpret_cast<void**>(&e->split_w), (per_block * e->vit_depth + kv_rows * DIM) * 6) != hipSuccess)
         return fail(e, THMR_ERR_NOMEM, "hipMalloc(split3 ViT weights) failed");
     const size_t M = (size_t)e->max_batch * TOK;
     // activations: [M][1280] + [M][5120] split3 operands, then the two fp32 partial-sum planes of fc2's split-K ([2][M][1280])
@@ -1169,6 +1180,8 @@ static int build_split_weights(thmr_engine* e, hipStream_t st) {
         LAUNCH_OK(conv(w.f1w, MLP, DIM, e->vitw_s[i].fc1));
         LAUNCH_OK(conv(w.f2w, DIM, MLP, e->vitw_s[i].fc2));
     }
+    e->kv_s = p;
+    LAUNCH_OK(launch_split3(e->warena + e->o_kv_all, DIM, p, DIM, (int64_t)kv_rows, DIM, st));
     return 0;
 }
 
