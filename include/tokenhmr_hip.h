@@ -221,8 +221,10 @@ int thmr_op_vit_attention(const float* qkv_dev, float* out_dev /*(B,192,1280)*/,
  * the 192 keys split over its 4 waves, partial softmaxes merged: what the engine uses up to six crops; equal to fp32 rounding;
  * 61 / 62 / 63 = the same with 16 / 32 / 48 queries per workgroup, bit-identical to each other) */
 int thmr_op_vit_attention_variant(const float* qkv_dev, float* out_dev, int32_t B, int32_t variant, void* stream);
-/* thmr_op_vit_attention with the output written as a split3 operand [B*192][1280/8][3][8] bf16 (see thmr_op_split3): bit-identical to
- * thmr_op_split3 of thmr_op_vit_attention's output; what the engine's split3 mode hands the proj GEMM. */
+/* thmr_op_vit_attention with the output written as a split3 operand [B*192][1280/8][3][8] bf16 (see thmr_op_split3): for B >= 3
+ * bit-identical to thmr_op_split3 of thmr_op_vit_attention's output; for B = 1 and 2 this operator runs the key-split kernel (another
+ * order of the key sum), so there it is bit-identical to thmr_op_split3 of thmr_op_vit_attention_variant(..., 6, ...)'s output.
+ * What the engine's split3 mode hands the proj GEMM. */
 int thmr_op_vit_attention_split3(const float* qkv_dev, void* out_split_dev, int32_t B, void* stream);
 /* rot6d_to_rotmat (geometry.py:64-84): (n,6) -> (n,3,3) */
 int thmr_op_rot6d(const float* x_dev, float* R_dev, int32_t n, void* stream);

@@ -159,12 +159,18 @@ def freeze_compact(ref, cfg):
 VERT_STRIDE_B64 = 53
 
 CASES = {
-    # name: (vit_depth, dec_depth, batch, seed)
+    # name: (vit_depth, dec_depth, batch, seed[, weight style])
     "small_d2": (2, 2, 2, 0),
     "full_d32": (32, 6, 2, 0),
     # BASELINE.json configs[2] at its own size: 64 distinct crops = 10,240 pose tokens through the reference's modules.
     # The crops are make_inputs(64, 0) == bench.py's rank-0 batch, so the bench line can report parity on its own input.
     "full_d32_b64": (32, 6, 64, 0),
+    # the same size on two more weight / crop seeds, and on a "trained-like" state (weights.make_synthetic_state(style="trained"):
+    # LayerNorm gains in [0.1, 10], x50 outlier channels in proj / fc2, non-trivial mean parameters): 4 x 10,240 = 40,960 tokens
+    "full_d32_b64_s1": (32, 6, 64, 1),
+    "full_d32_b64_s2": (32, 6, 64, 2),
+    "full_d32_b64_trained": (32, 6, 64, 3, "trained"),
+    "small_d2_trained": (2, 2, 2, 3, "trained"),
 }
 
 
@@ -174,15 +180,21 @@ def main():
     os.makedirs(outdir, exist_ok=True)
     names = sys.argv[1:] or list(CASES)
     for name in names:
-        vd, dd, B, seed = CASES[name]
+        vd, dd, B, seed = CASES[name][:4]
+        style = CASES[name][4] if len(CASES[name]) > 4 else "init"
         cfg = HMRConfig(vit_depth=vd, dec_depth=dd)
-        sd = W.make_synthetic_state(cfg, seed)
+        sd = W.make_synthetic_state(cfg, seed, style)
         tok = W.make_synthetic_tokenizer(cfg, seed)
         smpl = make_synthetic_smpl(cfg, seed)
         img = make_inputs(B, seed)
         ref = reference_forward(img, cfg, sd, tok, smpl)
-        g = freeze_compact(ref, cfg) if name.endswith("_b64") else freeze(ref, cfg)
+        g = freeze_compact(ref, cfg) if "_b64" in name else freeze(ref, cfg)
         g["meta"] = np.array([vd, dd, B, seed], dtype=np.int64)
+        g["style"] = np.array(style)
+        gap = torch.from_numpy(g["top2_gap"])
+        print(f"[{name}] logits |max| {ref['cls_logits'].abs().max():.3f}  top-2 gaps: min {gap.min():.3e}, "
+              f"< 1e-4: {int((gap < 1e-4).sum())}, < 1e-3: {int((gap < 1e-3).sum())}, < 1e-2: {int((gap < 1e-2).sum())} of {gap.numel()};  "
+              f"distinct token ids {len(np.unique(g['token_idx']))};  vit feature |max| {ref['vit_features'].abs().max():.2f}")
         g["weights_checksum"] = np.array([W.checksum(sd), W.checksum(tok)], dtype=np.float64)
         g["img_checksum"] = np.array([float(img.double().sum()), float(img[:, :, ::7, ::5].double().abs().sum())])
         # oracle vs live reference, reported at generation time

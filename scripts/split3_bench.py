@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--crops", type=int, default=64)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--no-error", action="store_true")
+    ap.add_argument("--persist", action="store_true", help="only the default tile and the persistent kernel")
     ap.add_argument("--schedule", action="store_true", help="schedule experiments and timing-only ablations instead of the variant table")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -64,9 +65,19 @@ def main():
                 row[v] = {"us": round(t * 1e6, 1), "f32_equiv_tflops": round(flop / t * 1e-12, 1)}
             print(json.dumps(row), flush=True)
             continue
-        for v in ("128x256/w8", "128x256/w4", "128x128/w4", "256x256/w4"):
+        persist_ok = M % 128 == 0 and (M // 128) * (N // 256) >= 256
+        variants = ("128x256/w8", "persist") if args.persist else ("128x256/w8", "128x256/w4", "128x128/w4", "256x256/w4", "persist")
+        for v in variants:
+            if v == "persist" and not persist_ok:
+                continue
             t = timed(lambda: ops.gemm_split3(sa, sw, db, res, epi=epi, variant=v, **kw), args.iters)
             row["split3 " + v] = {"us": round(t * 1e6, 1), "f32_equiv_tflops": round(flop / t * 1e-12, 1), "vs_f32_mfma": round(t32 / t, 3)}
+        if name == "fc1":        # what the engine runs: the GELU result written as fc2's split3 operand
+            for v in ("128x256/w8", "persist/lds", "persist/swap"):
+                if v != "128x256/w8" and not persist_ok:
+                    continue
+                t = timed(lambda: ops.gemm_split3(sa, sw, db, epi=epi, variant=v, out_split=True), args.iters)
+                row["split3-out " + v] = {"us": round(t * 1e6, 1), "f32_equiv_tflops": round(flop / t * 1e-12, 1), "vs_f32_mfma": round(t32 / t, 3)}
         if not args.no_error:
             c64 = da.double() @ dw.double().t()
             bound = da.double().abs() @ dw.double().abs().t()

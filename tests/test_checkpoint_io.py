@@ -143,6 +143,58 @@ class _TorchGadget:                      # torch.hub / torch.load-style entry po
         return (torch.hub.load, ("someone/repo", "model"))
 
 
+class _NestedArchiveGadget:
+    """torch.storage._load_from_bytes is torch.load(io.BytesIO(b), weights_only=False) — an UNRESTRICTED nested un-pickle — in torch
+    itself; a pickle that REDUCEs it with an inner archive holding an os.system gadget ran the command through round 3's loader
+    (ADVICE r3)."""
+
+    def __init__(self, marker):
+        self.marker = marker
+
+    def __reduce__(self):
+        import io
+        buf = io.BytesIO()
+        torch.save({"inner": _MarkerGadget(self.marker), "t": torch.arange(3.0)}, buf)
+        return (torch.storage._load_from_bytes, (buf.getvalue(),))
+
+
+class _MarkerGadget:
+    def __init__(self, marker):
+        self.marker = marker
+
+    def __reduce__(self):
+        return (os.system, (f"echo pwned > {self.marker}",))
+
+
+class _MemmapGadget:                     # numpy.memmap is a TYPE of an allowed module whose constructor creates / truncates files
+    def __init__(self, path):
+        self.path = path
+
+    def __reduce__(self):
+        return (np.memmap, (self.path, "uint8", "w+", 0, (16,)))
+
+
+def test_restricted_unpickler_nested_archive_and_memmap(tmp_path):
+    """Negative tests for the two bypasses ADVICE r3 demonstrated: a nested archive through `_load_from_bytes` is read by the SAME
+    restricted un-pickler (its tensors load, its gadget stays data), and numpy.memmap does not resolve (no file is created)."""
+    from tokenhmr_amd import ckpt_io
+    marker = str(tmp_path / "nested_gadget_ran")
+    victim = str(tmp_path / "memmap_victim.bin")
+    torch.save({"state_dict": {"w": torch.ones(2)}, "nested": _NestedArchiveGadget(marker), "mm": _MemmapGadget(victim)},
+               tmp_path / "nested.ckpt")
+    c = ckpt_io.load_checkpoint(str(tmp_path / "nested.ckpt"))
+    assert not os.path.exists(marker), "the nested archive's os.system gadget was executed"
+    assert not os.path.exists(victim), "numpy.memmap was resolved and created a file"
+    assert isinstance(c["nested"], dict) and torch.equal(c["nested"]["t"], torch.arange(3.0))
+    assert isinstance(c["nested"]["inner"], ckpt_io.InertNode) and c["nested"]["inner"]._inert_origin[1] == "system"
+    assert isinstance(c["mm"], ckpt_io.InertNode) and c["mm"]._inert_origin == ("numpy", "memmap")
+    # a tensor pickled OUTSIDE torch.save legitimately reduces through _load_from_bytes: still loads
+    import pickle as _p
+    blob = _p.dumps({"t": torch.arange(5.0)})
+    got = ckpt_io.RestrictedUnpickler(__import__("io").BytesIO(blob)).load()
+    assert torch.equal(got["t"], torch.arange(5.0))
+
+
 def test_restricted_unpickler_never_resolves_code(tmp_path):
     """The reference's torch.load un-pickles arbitrary globals; this loader cannot: anything that is not a tensor / array /
     plain container becomes inert data."""

@@ -20,10 +20,10 @@ VERT_STRIDE = 13
 SAMPLE_TOKENS = [0, 5, 77, 100, 191]
 
 
-def _assets(cfg, seed=0):
+def _assets(cfg, seed=0, style="init"):
     from tokenhmr_amd import weights as W
     from tokenhmr_amd.smpl_assets import make_synthetic_smpl
-    return W.make_synthetic_state(cfg, seed), W.make_synthetic_tokenizer(cfg, seed), make_synthetic_smpl(cfg, seed)
+    return W.make_synthetic_state(cfg, seed, style), W.make_synthetic_tokenizer(cfg, seed), make_synthetic_smpl(cfg, seed)
 
 
 def _inputs(B, seed=0):
@@ -150,6 +150,24 @@ def test_small_vs_golden(small):
     _check_golden(model, cfg, sd, tok, "small_d2.npz")
 
 
+def test_small_trained_like_vs_golden(built_lib, cuda_dev):
+    """depth 2 on the "trained-like" weight statistics (LayerNorm gains in [0.1, 10], x50 outlier channels, non-trivial mean
+    parameters), every stage boundary against the reference's own modules — in both ViT GEMM modes (2 crops run the exact-fp32
+    kernels in either mode; the padded 8-crop batch runs the split3 products)"""
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd.model import TokenHMR
+    cfg = HMRConfig(vit_depth=2, dec_depth=2)
+    sd, tok, smpl = _assets(cfg, 3, "trained")
+    model = TokenHMR.from_state(cfg, sd, tok, smpl, max_batch=8, device=cuda_dev)
+    model.return_taps = True
+    for mode in ("f32", "split3"):
+        model.engine.set_vit_gemm(mode)
+        _check_golden(model, cfg, sd, tok, "small_d2_trained.npz")
+        _check_golden(model, cfg, sd, tok, "small_d2_trained.npz", pad_to=8)
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_full_depth_vs_golden(built_lib, cuda_dev):
     """ViT-H depth 32 + 6-layer decoder: the release architecture, vs tensors the reference's own modules produced — once as
     the fixture's own B=2 batch (small-batch regime) and once at BASELINE.json's full size, B=64 (large-batch regime), where
@@ -176,20 +194,28 @@ def test_full_depth_vs_golden(built_lib, cuda_dev):
     torch.cuda.empty_cache()
 
 
-def test_b64_tokens_vs_reference_golden(built_lib, cuda_dev):
-    """BASELINE.json configs[2] at its own size: 64 DISTINCT seeded crops (= bench.py's rank-0 batch) through ViT-H depth 32 +
-    the full head, against tests/golden/full_d32_b64.npz, which oracle/gen_golden.py produced with the reference's own
-    modules: 64 x 160 = 10,240 pose-token indices.  Rule: indices are EQUAL wherever the reference's own top-2 logit gap
-    exceeds 1e-3 (100 of the 10,240 tokens are closer than that, 15 closer than 1e-4, the closest pair is 4.8e-6 apart —
-    below that a different but equally valid fp32 summation order can legitimately flip the argmax); the absolute number
-    of mismatches is printed and bounded by a handful (measured on MI355X: see profiles/ and the bench line's `parity`)."""
+# the 64-crop depth-32 fixtures of oracle/gen_golden.py: three weight / crop seeds of the default-init statistics and one "trained-like"
+# state (LayerNorm gains in [0.1, 10], x50 outlier channels in proj / fc2, non-trivial mean parameters) = 4 x 10,240 pose tokens
+B64_GOLDENS = ["full_d32_b64", "full_d32_b64_s1", "full_d32_b64_s2", "full_d32_b64_trained"]
+
+
+@pytest.mark.parametrize("golden", B64_GOLDENS)
+def test_b64_tokens_vs_reference_golden(built_lib, cuda_dev, golden):
+    """BASELINE.json configs[2] at its own size: 64 DISTINCT seeded crops (full_d32_b64 = bench.py's rank-0 batch) through ViT-H
+    depth 32 + the full head, against tests/golden/<golden>.npz, which oracle/gen_golden.py produced with the reference's own
+    modules: 64 x 160 = 10,240 pose-token indices per fixture, 40,960 over the four, in BOTH ViT GEMM modes.  Rule: indices are
+    EQUAL wherever the reference's own top-2 logit gap exceeds 1e-3 (44-100 of the 10,240 tokens of a fixture are closer than
+    that, 6-15 closer than 1e-4, the closest pairs are 5e-6 ... 4e-5 apart — below that a different but equally valid fp32
+    summation order can legitimately flip the argmax); the absolute number of mismatches is printed with their gaps and bounded by
+    a handful (measured on MI355X: see profiles/ and the bench line's `parity`)."""
     from tokenhmr_amd.config import RELEASE
     from tokenhmr_amd.model import TokenHMR
     from tokenhmr_amd import weights as W
-    g = np.load(os.path.join(GOLDEN_DIR, "full_d32_b64.npz"))
+    g = np.load(os.path.join(GOLDEN_DIR, golden + ".npz"))
     vd, dd, B, seed = [int(v) for v in g["meta"]]
+    style = str(g["style"]) if "style" in g.files else "init"
     assert (vd, dd, B) == (32, 6, 64)
-    sd, tok, smpl = _assets(RELEASE, seed)
+    sd, tok, smpl = _assets(RELEASE, seed, style)
     assert abs(W.checksum(sd) - g["weights_checksum"][0]) < 1e-6 * max(1.0, abs(g["weights_checksum"][0]))
     img = _inputs(B, seed)
     assert abs(float(img.double().sum()) - g["img_checksum"][0]) < 1e-6
@@ -201,7 +227,7 @@ def test_b64_tokens_vs_reference_golden(built_lib, cuda_dev):
         assert model.engine.vit_gemm() == vit_gemm
         out = _to_cpu(model({"img": img.to(cuda_dev)}))
         model.engine.status()
-        _check_b64_golden(out, g, vit_gemm)
+        _check_b64_golden(out, g, f"{golden}, ViT GEMMs {vit_gemm}")
     del model
     torch.cuda.empty_cache()
 
@@ -216,7 +242,7 @@ def _check_b64_golden(out, g, tag):
                rot=np.abs(R - g["rotmat"]).max(), betas=np.abs(out["pred_smpl_params"]["betas"].numpy() - g["betas"]).max(),
                cam=np.abs(out["pred_cam"].numpy() - g["cam"]).max(), kp2d=np.abs(out["pred_keypoints_2d"].numpy() - g["kp2d"]).max(),
                probs_max=np.abs(out["cls_logits_softmax"].max(-1).values.numpy() - g["probs_max"]).max())
-    print(f"[golden full_d32_b64, ViT GEMMs {tag}] token-index mismatches: {n_mis} of {idx.size} "
+    print(f"[golden {tag}] token-index mismatches: {n_mis} of {idx.size} "
           f"({n_safe_mis} where the reference's top-2 gap > 1e-3; gaps at the mismatches: "
           f"{sorted(float(x) for x in gap[mism])[:8]}) " + " ".join(f"{k}={v:.2e}" for k, v in rep.items()))
     assert n_safe_mis == 0, "a token index differs from the reference's where its top-2 logit gap > 1e-3"

@@ -270,6 +270,63 @@ def test_gemm_split3(built_lib, cuda_dev, shape):
         assert torch.equal(half, outs["128x256/w8"][:M // 2])
 
 
+# (M, N, K): 256 tiles exactly (every stream lane 8 tiles) / ragged lists (272 tiles: lanes 0-15 hold 9, the rest 8) with an odd number
+# of K tiles / the four ViT GEMM shapes of a 64-crop batch (1440, 480, 1920, 480 tiles = 5.625 / 1.875 / 7.5 / 1.875 per CU)
+PERSIST_SHAPES = [(2048, 4096, 320), (2176, 4096, 352), (12288, 3840, 1280), (12288, 1280, 1280), (12288, 5120, 1280), (12288, 1280, 5120)]
+
+
+@pytest.mark.parametrize("shape", PERSIST_SHAPES)
+def test_gemm_split3_persistent(built_lib, cuda_dev, shape):
+    """The persistent split3 GEMM (256 workgroups over a tile stream, a ragged last round split along K with the accumulators handed
+    from one XCD's workgroup to the next through memory) is BIT-IDENTICAL to the one-workgroup-per-tile kernel — the accumulator chain of
+    every element is the same, only who runs which part of it changes — for every epilogue, for the split3 output in both forms (LDS
+    transposition / swapped operand roles + permlane swaps), repeatedly (the hand-over flags re-arm themselves), and interleaved with
+    other shapes on the same workspace."""
+    import torch
+    from tokenhmr_amd import ops
+    if torch.cuda.get_device_properties(cuda_dev).multi_processor_count != 256:
+        pytest.skip("the persistent decomposition is 8 XCDs x 32 CUs")
+    M, N, K = shape
+    a, w, b = _rand(M, K, seed=11), _rand(N, K, seed=12, scale=1 / math.sqrt(K)), _rand(N, seed=13)
+    a[:, ::7] *= 30.0
+    da, dw, db = a.to(cuda_dev), w.to(cuda_dev), b.to(cuda_dev)
+    dr = _rand(M, N, seed=14).to(cuda_dev)
+    sa, sw = ops.split3(da), ops.split3(dw)
+    base = ops.gemm_split3(sa, sw, variant="128x256/w8")
+    ref64 = a[:256].double() @ w.double().t()                              # the kernel itself against fp64 on a slice (the rest by identity)
+    bound = a[:256].double().abs() @ w.double().abs().t()
+    assert ((base[:256].cpu().double() - ref64).abs() / bound).max().item() < 2.0 ** -21
+    for rep in range(3):
+        o = ops.gemm_split3(sa, sw, variant="persist")
+        assert torch.equal(o, base), (rep, int((o != base).sum()), (o - base).abs().max().item())
+    for epi, kw in (("bias", {}), ("bias_gelu", {}), ("bias_resid", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
+        rr = dr if epi == "bias_resid" else None
+        want = ops.gemm_split3(sa, sw, db, rr, epi=epi, variant="128x256/w8", **kw)
+        got = ops.gemm_split3(sa, sw, db, rr, epi=epi, variant="persist", **kw)
+        assert torch.equal(got, want), (epi, int((got != want).sum()))
+    for epi in ("none", "bias_gelu"):
+        bb = None if epi == "none" else db
+        want = ops.gemm_split3(sa, sw, bb, epi=epi, variant="128x256/w8", out_split=True)
+        for variant in ("persist/lds", "persist/swap"):
+            got = ops.gemm_split3(sa, sw, bb, epi=epi, variant=variant, out_split=True)
+            assert torch.equal(got, want), (variant, epi, int((got != want).sum()))
+    # another shape on the same (device, stream) workspace in between, then this one again
+    a2, w2 = _rand(2048, 64, seed=21).to(cuda_dev), _rand(4096, 64, seed=22).to(cuda_dev)
+    s2a, s2w = ops.split3(a2), ops.split3(w2)
+    assert torch.equal(ops.gemm_split3(s2a, s2w, variant="persist"), ops.gemm_split3(s2a, s2w, variant="128x256/w8"))
+    assert torch.equal(ops.gemm_split3(sa, sw, variant="persist"), base)
+
+
+def test_gemm_split3_persistent_rejects(built_lib, cuda_dev):
+    from tokenhmr_amd import ops, _cabi
+    sa, sw = ops.split3(_rand(2048, 64, seed=1).to(cuda_dev)), ops.split3(_rand(3840, 64, seed=2).to(cuda_dev))
+    with pytest.raises(_cabi.EngineError):
+        ops.gemm_split3(sa, sw, variant="persist")             # 16 x 15 = 240 tiles < 256
+    sa2 = ops.split3(_rand(2048 + 64, 64, seed=1).to(cuda_dev))
+    with pytest.raises(_cabi.EngineError):
+        ops.gemm_split3(sa2, ops.split3(_rand(4096, 64, seed=2).to(cuda_dev)), variant="persist")     # M % 128 != 0
+
+
 TINY_SHAPES = [(21, 512, 1536), (160, 512, 768), (160, 256, 2048), (126, 6, 1536), (960, 512, 1536), (55, 512, 512), (37, 31, 256)]
 
 

@@ -32,7 +32,8 @@ def _run(name):
     g = np.load(os.path.join(GOLDEN_DIR, name))
     vd, dd, B, seed = [int(v) for v in g["meta"]]
     cfg = HMRConfig(vit_depth=vd, dec_depth=dd)
-    sd, tok, smpl = W.make_synthetic_state(cfg, seed), W.make_synthetic_tokenizer(cfg, seed), make_synthetic_smpl(cfg, seed)
+    style = str(g["style"]) if "style" in g.files else "init"
+    sd, tok, smpl = W.make_synthetic_state(cfg, seed, style), W.make_synthetic_tokenizer(cfg, seed), make_synthetic_smpl(cfg, seed)
     assert abs(W.checksum(sd) - g["weights_checksum"][0]) <= 1e-9 * abs(g["weights_checksum"][0])
     assert abs(W.checksum(tok) - g["weights_checksum"][1]) <= 1e-9 * abs(g["weights_checksum"][1])
     img = _inputs(B, seed)
@@ -67,6 +68,26 @@ def _compare(g, out, tol):
 def test_oracle_matches_reference_golden_small():
     g, out, _ = _run("small_d2.npz")
     _compare(g, out, tol=1e-6)   # same torch CPU kernels as the reference run; thread-count effects only
+
+
+def test_oracle_matches_reference_golden_small_trained_like():
+    """the "trained-like" weight statistics (weights.make_synthetic_state(style="trained"): LayerNorm gains in [0.1, 10], x50 outlier
+    channels in proj / fc2, non-trivial mean parameters) through the reference's own modules"""
+    g, out, (cfg, sd, tok, smpl) = _run("small_d2_trained.npz")
+    assert str(g["style"]) == "trained"
+    assert float(sd["backbone.blocks.0.norm1.weight"].max() / sd["backbone.blocks.0.norm1.weight"].min()) > 50
+    _compare(g, out, tol=1e-5)
+
+
+def test_weight_styles_are_independent():
+    """the default-init tensors of a (cfg, seed) do not depend on which styles exist: goldens made before the style argument stay valid"""
+    cfg = HMRConfig(vit_depth=1, dec_depth=1)
+    a, b = W.make_synthetic_state(cfg, 5), W.make_synthetic_state(cfg, 5, "trained")
+    assert torch.equal(a["backbone.blocks.0.attn.qkv.weight"], b["backbone.blocks.0.attn.qkv.weight"])
+    assert not torch.equal(a["backbone.blocks.0.mlp.fc2.weight"], b["backbone.blocks.0.mlp.fc2.weight"])
+    assert not torch.equal(a["smpl_head.init_body_pose"], b["smpl_head.init_body_pose"])
+    with pytest.raises(ValueError):
+        W.make_synthetic_state(cfg, 5, "nonsense")
 
 
 def test_oracle_matches_reference_golden_full_depth():

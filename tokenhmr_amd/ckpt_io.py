@@ -15,15 +15,20 @@ pytorch_lightning are not importable.  `load_checkpoint` un-pickles them with a 
 numpy arrays and plain containers resolve to the real classes; every other global — whatever its module — becomes an inert,
 dict-like stand-in (`InertNode`) that records what the pickle fed it and never imports or executes anything.  This is the
 pattern `smpl_assets._Unpickler` uses for chumpy, extended to "any class", and it is also strictly safer than the
-reference's unrestricted un-pickling (no `os.system`-style gadget can be resolved).
+reference's unrestricted un-pickling: no `os.system`-style gadget can be resolved, a nested archive
+(`torch.storage._load_from_bytes`, which is an unrestricted `torch.load` in torch itself) is read by THIS un-pickler again,
+and of numpy only `ndarray`, `dtype`, the scalar types and the `numpy.dtypes` classes resolve (not `memmap`, whose
+constructor creates / truncates files).
 
 `tokenizer_arch` / `check_tokenizer_arch` then read `hparams.ARCH.*` from the stand-in exactly where the reference reads it
 (vanilla_pose_vqvae.py:266-278) and compare it with the architecture the HIP engine bakes into its kernels.
 """
+import io
 import pickle
 import types
 import warnings
 
+import numpy as np
 import torch
 
 # globals that are resolved for real: exactly what a tensor archive legitimately needs, by (module, name) — never by module alone
@@ -37,7 +42,7 @@ _REAL_GLOBALS = {
                      "_rebuild_meta_tensor_no_storage"},
     "torch._tensor": {"_rebuild_from_type", "_rebuild_from_type_v2", "Tensor"},
     "torch.nn.parameter": {"Parameter", "Buffer", "UninitializedParameter"},
-    "torch.storage": {"TypedStorage", "UntypedStorage", "_load_from_bytes"},
+    "torch.storage": {"TypedStorage", "UntypedStorage"},       # _load_from_bytes: see _nested_archive below
     "torch.serialization": {"_get_layout"},
 }
 _NUMPY_MODULES = {"numpy", "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric", "numpy._core.numeric",
@@ -106,6 +111,23 @@ class InertNode(dict):
         return f"<inert {'.'.join(self._inert_origin)} {dict.__repr__(self)}>"
 
 
+def _nested_archive(b):
+    """Replacement for torch.storage._load_from_bytes (= torch.load(io.BytesIO(b), weights_only=False) in torch: a nested,
+    UNRESTRICTED un-pickle).  Tensors pickled outside torch.save reduce through it; the inner archive is read with the same
+    restricted un-pickler, so nesting cannot be used to reach a real global."""
+    if not isinstance(b, (bytes, bytearray)):
+        raise pickle.UnpicklingError("_load_from_bytes: expected a bytes payload")
+    return torch.load(io.BytesIO(bytes(b)), map_location="cpu", weights_only=False, pickle_module=_pickle_module)
+
+
+def _numpy_data_type(obj):
+    """ndarray, dtype, the scalar types (float64, int32 ...) and the numpy.dtypes classes — NOT ndarray subclasses such as memmap
+    (its constructor opens / creates / truncates a file), recarray or matrix."""
+    if not isinstance(obj, type):
+        return False
+    return obj is np.ndarray or obj is np.dtype or issubclass(obj, np.generic) or issubclass(obj, np.dtype)
+
+
 _stub_cache = {}
 
 
@@ -130,18 +152,21 @@ class RestrictedUnpickler(pickle.Unpickler):
             if isinstance(obj, (type, torch.dtype)) or name.endswith("Storage"):
                 return super().find_class(module, name)
             return _stub_for(module, name)
+        if module == "torch.storage" and name == "_load_from_bytes":
+            return _nested_archive
         if name in _REAL_GLOBALS.get(module, ()):
             try:
                 return super().find_class(module, name)
             except (ImportError, AttributeError):
                 return _stub_for(module, name)
         if module in _NUMPY_MODULES:
-            # array / scalar reconstruction helpers, and TYPES (ndarray, dtype, float64, dtypes.Float32DType ...) — no other numpy function
+            # array / scalar reconstruction helpers, and the DATA types (ndarray, dtype, float64, dtypes.Float32DType ...) — no other
+            # numpy function and no other ndarray subclass
             try:
                 obj = super().find_class(module, name)
             except (ImportError, AttributeError):
                 return _stub_for(module, name)
-            if name in _NUMPY_FUNCS or isinstance(obj, type):
+            if name in _NUMPY_FUNCS or _numpy_data_type(obj):
                 return obj
             return _stub_for(module, name)
         return _stub_for(module, name)

@@ -290,6 +290,14 @@ int launch_split3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, i
 int launch_gemm_split3(const GemmArgs& a, int epi, int variant, hipStream_t s);
 // split-K on the split3 big tiles: ksplit copies of the tile grid in one launch, raw partial sums into part[ksplit][M][N]
 int launch_gemm_split3_splitk(const GemmArgs& a, int ksplit, float* part, hipStream_t s);
+// gemm_split_persist.hip: the same product on 256 persistent workgroups (a tile stream per CU, ragged last round split along K with the
+// accumulators handed over through `ws`; bit-identical to launch_gemm_split3).  mode 0 = fp32 C; 1 / 2 = split3 output (a.c_split) through the
+// LDS transposition / through swapped operand roles.  ws: gemm_split3_persist_ws_bytes() of device memory zeroed once, one launch at a time.
+size_t gemm_split3_persist_ws_bytes();
+bool gemm_split3_persist_ok(const GemmArgs& a);        // shape served by the persistent kernel (M % 128, N % 256, >= 256 tiles, no split-K)
+int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws, hipStream_t s);
+int gemm_split3_persist_error(void* ws, hipStream_t s, unsigned* err_out);   // synchronises s; *err_out != 0: a hand-over spin timed out
+void* gemm_split3_persist_op_ws(hipStream_t s);        // zeroed workspace per (device, stream) for the stateless operators
 // small-M split3 GEMM (64x64 tiles, LDS-DMA ring, optional split-K into part[ksplit][M][N] without epilogue)
 int launch_gemm_split3_ring(const GemmArgs& a, int epi, int ksplit, float* part, hipStream_t s);
 // LayerNorm (D = 1280) whose result is written as a split3 operand [rows][D/8][3][8] instead of fp32 (same arithmetic as launch_layernorm)

@@ -41,8 +41,8 @@ constexpr int kKeysplitMaxB = 2;                  // key-split attention kernel:
 // -10 % per call at 9 and 10 crops, -2.5 ... -3.7 % at 11 ... 16, -2 % at 7 and 8 with the 64x128 tile; from 17 on the unsplit launch
 // is the faster one, and 4 ways never beats 2).  That range is its own regime of the K sum.
 constexpr int kMidLoM = 7 * 192, kMidHiM = 16 * 192, kMidSplit = 2;
-// thmr_set_vit_gemm(1): batches of at least this many crops run the ViT GEMMs as split3 products (128 x 256 tiles, one workgroup per
-// CU: below the big-tile regime the exact-fp32 kernels with their smaller tiles and split-K stay in charge)
+// thmr_set_vit_gemm(1): the split3 mode serves calls of kSplit3LowMinB (3) crops and more, in ranges.  From THIS many crops on the
+// N = 1280 GEMM proj runs with its K sum unsplit (128 x 256 tiles, one workgroup per CU); below it proj / fc2 split K (next constants)
 constexpr int kSplit3MinB = 16;
 // ... and 5 ... 15 crops run them with proj / fc2 split K two ways (60-120 tiles of 128 x 256 otherwise): the mode's own mid regime
 constexpr int kSplit3MidMinB = 5, kSplit3MidSplit = 2;
@@ -108,15 +108,21 @@ struct thmr_engine {
     bool attn_keysplit = true;        // THMR_ATTN_KEYSPLIT=0: one and two crops keep the 64-query attention workgroups (A/B only)
     int mid_split_force[2] = {-1, -1};   // THMR_MID_SPLIT=<p><f> (digits 0|2|4): force the split factors of proj and fc2 above 6 crops where the partial-sum buffer allows (A/B only)
     bool smpl_loaded = false, finalized = false;
-    // thmr_set_vit_gemm(1): the four ViT GEMMs of batches of at least kSplit3MinB crops run on the bf16 matrix pipe with fp32 operands
+    // thmr_set_vit_gemm(1): the four ViT GEMMs of batches of at least kSplit3LowMinB (3) crops run on the bf16 matrix pipe with fp32 operands
     // carried as three bf16 pieces (csrc/gemm_split.hip).  Engine-owned memory: the split3 copies of the ViT weights (1.5 x their fp32
     // size) and the split3 activation operands (M x (1280 + 5120) x 6 bytes).  Off (0) = exact-fp32 MFMA everywhere, the default.
     int vit_gemm_mode = 0;
     bool split3_small = false;        // THMR_SPLIT3_SMALL=1: the split3 mode also serves up to six crops (ring kernel on split3 operands) — measured SLOWER, A/B only
     int split3_fc2_split = 2;         // THMR_SPLIT3_FC2_SPLIT=1: fc2 of the split3 mode unsplit from 16 crops on (A/B only)
-    int split3_min_b = 0;             // THMR_SPLIT3_MIN_B=<n>: A/B knob for the smallest batch the split3 mode serves (0 = kSplit3MinB)
+    int split3_min_b = 0;             // THMR_SPLIT3_MIN_B=<n>: A/B knob for the smallest batch the split3 mode serves (0 = kSplit3LowMinB)
     char* split_w = nullptr;
     char* split_act = nullptr;
+    // persistent split3 GEMM (csrc/gemm_split_persist.hip; bit-identical to the one-workgroup-per-tile kernel, so purely a matter of time):
+    // hand-over slabs + flags, allocated with the split3 weights on a 256-CU device.  s3_persist: 0 off / 1 on (THMR_SPLIT3_PERSIST);
+    // s3_fc1_mode: how fc1's split3 output leaves the persistent kernel — 2 swapped operand roles, 1 LDS transposition, 0 = fc1 stays on
+    // the per-tile kernel (THMR_SPLIT3_FC1_MODE)
+    void* s3_ws = nullptr;
+    int s3_persist = 1, s3_fc1_mode = 2;
     struct SplitW { const char *qkv, *proj, *fc1, *fc2; };
     std::vector<SplitW> vitw_s;
     const char* kv_s = nullptr;       // split3 copy of the decoder's stacked to_kv weights (dec_depth * 1024 rows x 1280)
@@ -510,6 +516,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             ProfScope ps(e, st, cls, 2.0 * M * (double)N * K, 6.0 * ((double)M * K + (double)N * K) + 4.0 * M * N * (resid ? 2.0 : 1.0));
             GemmArgs a = mk(reinterpret_cast<const float*>(A), K, reinterpret_cast<const float*>(Wt), K, bias, resid, N, C, N, M, N, K);
             a.qscale = qscale; a.qcols = DIM;
+            if (e->s3_ws && e->s3_persist && gemm_split3_persist_ok(a)) return launch_gemm_split3_persist(a, epi, 0, e->s3_ws, st);
             return launch_gemm_split3(a, epi, -1, st);
         };
         {
@@ -542,7 +549,10 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 ProfScope ps(e, st, THMR_PROF_GEMM_FC1, 2.0 * M * DIM * (double)MLP, 6.0 * ((double)M * DIM + (double)DIM * MLP + (double)M * MLP));
                 GemmArgs a = mk(reinterpret_cast<const float*>(hs), DIM, reinterpret_cast<const float*>(ws.fc1), DIM, w.f1b, nullptr, 0, nullptr, 0, M, MLP, DIM);
                 a.c_split = bs; a.ldcs = MLP;
-                LAUNCH_OK(launch_gemm_split3(a, EPI_BIAS_GELU, -1, st));
+                if (e->s3_ws && e->s3_persist && e->s3_fc1_mode && gemm_split3_persist_ok(a))
+                    LAUNCH_OK(launch_gemm_split3_persist(a, EPI_BIAS_GELU, e->s3_fc1_mode, e->s3_ws, st));
+                else
+                    LAUNCH_OK(launch_gemm_split3(a, EPI_BIAS_GELU, -1, st));
             }
             if (s3_fc2 > 1) {
                 {
@@ -752,7 +762,8 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
             // on the bf16 matrix pipe (1.5 -> 1.0 ms at 64 crops)
             LAUNCH_OK(launch_split3(ctx, DIM, e->split_act, DIM, M, DIM, st));
             GemmArgs a = mk(reinterpret_cast<const float*>(e->split_act), DIM, reinterpret_cast<const float*>(e->kv_s), DIM, nullptr, nullptr, 0, big, ldkv, M, ldkv, DIM);
-            LAUNCH_OK(launch_gemm_split3(a, EPI_NONE, -1, st));
+            if (e->s3_ws && e->s3_persist && gemm_split3_persist_ok(a)) LAUNCH_OK(launch_gemm_split3_persist(a, EPI_NONE, 0, e->s3_ws, st));
+            else LAUNCH_OK(launch_gemm_split3(a, EPI_NONE, -1, st));
         } else {
             GemmArgs a = mk(ctx, DIM, e->warena + e->o_kv_all, DIM, nullptr, nullptr, 0, big, ldkv, M, ldkv, DIM);
             LAUNCH_OK(launch_gemm(a, EPI_NONE, -1, st));
@@ -995,7 +1006,13 @@ int launch_decoder_serialised(thmr_engine* e, const DecParams& d, hipStream_t st
 // words are in an undefined state.  Recover instead of staying poisoned: drain the device, zero the barrier words and the
 // sticky error, and run this engine's head as the launch chain from now on (it needs no co-residency), so the caller can
 // simply re-submit.  Returns the error ONCE.
-int recover_decoder_timeout(thmr_engine* e) {
+int recover_decoder_timeout(thmr_engine* e, hipStream_t st = nullptr) {
+    // hipDeviceSynchronize / hipMemset are illegal while a stream of this thread is being captured into a hipGraph (they would also
+    // invalidate the capture): report, leave the device alone, and let the caller recover outside the capture
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(e, THMR_ERR_HIP, "persistent decoder kernel: grid barrier timed out in a previous forward, and this call is inside a "
+                                     "stream capture: end the capture, call thmr_engine_status() (it resets the engine), then re-capture");
     (void)hipDeviceSynchronize();
     (void)hipMemset(e->sarena + e->so.sync, 0, 512 * sizeof(float));
     if (e->host_err) *e->host_err = 0;
@@ -1005,9 +1022,9 @@ int recover_decoder_timeout(thmr_engine* e) {
                                  "the launch-chain head: re-submit the batch");
 }
 
-int check_ready(thmr_engine* e, int B) {
+int check_ready(thmr_engine* e, int B, hipStream_t st = nullptr) {
     if (!e) return fail(nullptr, THMR_ERR_INVALID, "null engine");
-    if (e->host_err && *static_cast<volatile unsigned*>(e->host_err) != 0) return recover_decoder_timeout(e);
+    if (e->host_err && *static_cast<volatile unsigned*>(e->host_err) != 0) return recover_decoder_timeout(e, st);
     if (!e->finalized) return fail(e, THMR_ERR_STATE, "weights not finalized: call thmr_finalize_weights first");
     if (B < 1 || B > e->max_batch) return fail(e, THMR_ERR_INVALID, "batch " + std::to_string(B) + " outside [1, max_batch=" + std::to_string(e->max_batch) + "]");
     return 0;
@@ -1095,6 +1112,8 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* ss = getenv("THMR_SPLIT3_SMALL"); e->split3_small = ss && ss[0] == '1'; }
     { const char* fs = getenv("THMR_SPLIT3_FC2_SPLIT"); e->split3_fc2_split = (fs && fs[0] == '1') ? 1 : kSplit3Fc2Split; }
     { const char* sm = getenv("THMR_SPLIT3_MIN_B"); e->split3_min_b = sm ? atoi(sm) : 0; }
+    { const char* sp = getenv("THMR_SPLIT3_PERSIST"); if (sp && sp[0] >= '0' && sp[0] <= '1') e->s3_persist = sp[0] - '0'; }
+    { const char* fm = getenv("THMR_SPLIT3_FC1_MODE"); if (fm && fm[0] >= '0' && fm[0] <= '2') e->s3_fc1_mode = fm[0] - '0'; }
     { const char* ms = getenv("THMR_MID_SPLIT"); if (ms && ms[0] && ms[1]) { e->mid_split_force[0] = ms[0] - '0'; e->mid_split_force[1] = ms[1] - '0'; } }
     { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
     *out = e;
@@ -1108,6 +1127,7 @@ void thmr_destroy(thmr_engine* e) {
     if (e->host_err) (void)hipHostFree(e->host_err);
     if (e->split_w) (void)hipFree(e->split_w);
     if (e->split_act) (void)hipFree(e->split_act);
+    if (e->s3_ws) (void)hipFree(e->s3_ws);
     if (e->own_w && e->warena) (void)hipFree(e->warena);
     if (e->own_s && e->sarena) (void)hipFree(e->sarena);
     delete e;
@@ -1165,6 +1185,14 @@ static int build_split_weights(thmr_engine* e, hipStream_t st) {
     // activations: [M][1280] + [M][5120] split3 operands, then the two fp32 partial-sum planes of fc2's split-K ([2][M][1280])
     if (!e->split_act && hipMalloc(reinterpret_cast<void**>(&e->split_act), M * (size_t)(DIM + MLP) * 6 + (size_t)kSplit3Fc2Split * M * DIM * 4) != hipSuccess)
         return fail(e, THMR_ERR_NOMEM, "hipMalloc(split3 activations) failed");
+    if (!e->s3_ws) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, e->cfg.device) == hipSuccess && prop.multiProcessorCount == 256) {
+            // the persistent kernel's decomposition is 8 XCDs x 32 CUs; elsewhere the per-tile kernel stays in charge (same results)
+            if (hipMalloc(&e->s3_ws, gemm_split3_persist_ws_bytes()) != hipSuccess) return fail(e, THMR_ERR_NOMEM, "hipMalloc(split3 hand-over workspace) failed");
+            HIP_OK(hipMemsetAsync(e->s3_ws, 0, gemm_split3_persist_ws_bytes(), st));
+        }
+    }
     e->vitw_s.resize(e->vit_depth);
     char* p = e->split_w;
     for (int i = 0; i < e->vit_depth; ++i) {
@@ -1302,7 +1330,10 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
         }
     }
     e->finalized = true;
-    if (e->vit_gemm_mode == 1) return build_split_weights(e, st);      // weights were (re)loaded with the split3 mode on
+    if (e->vit_gemm_mode == 1) {                                       // weights were (re)loaded with the split3 mode on
+        if (int r = build_split_weights(e, st)) return r;
+        HIP_OK(hipStreamSynchronize(st));                              // as in thmr_set_vit_gemm: visible to forwards on any stream
+    }
     return 0;
 }
 
@@ -1313,6 +1344,9 @@ int thmr_set_vit_gemm(thmr_engine* e, int32_t mode, void* stream) {
         if (!e->finalized) return fail(e, THMR_ERR_STATE, "thmr_set_vit_gemm(1) needs finalized weights (thmr_finalize_weights)");
         if (hipSetDevice(e->cfg.device) != hipSuccess) return fail(e, THMR_ERR_HIP, "hipSetDevice failed");
         if (int r = build_split_weights(e, static_cast<hipStream_t>(stream))) return r;
+        // the conversion (3.8 GB of writes) was enqueued on the caller's stream; a forward on ANOTHER stream right after this call must
+        // not read half-converted weights: a one-time switch, so simply wait for it
+        HIP_OK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     }
     e->vit_gemm_mode = mode;
     return 0;
@@ -1402,6 +1436,20 @@ int thmr_engine_status(thmr_engine* e, void* stream) {
     HIP_OK(hipMemcpyAsync(words, e->sarena + e->so.sync, sizeof(words), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     if (words[3] != 0 || (e->host_err && *static_cast<volatile unsigned*>(e->host_err) != 0)) return recover_decoder_timeout(e);
+    if (e->s3_ws) {
+        // persistent split3 GEMM: a consumer's bounded wait for a hand-over slab ran out (its workgroups were not resident together with
+        // their producers for ~0.5 s: another kernel held the device).  That forward's outputs are invalid; reset the workspace and fall
+        // back to the per-tile kernel (same results) so the caller can simply re-submit.  Reported once.
+        unsigned err = 0;
+        if (gemm_split3_persist_error(e->s3_ws, st, &err) != 0) return fail(e, THMR_ERR_HIP, "reading the split3 hand-over error word failed");
+        if (err != 0) {
+            HIP_OK(hipMemsetAsync(e->s3_ws, 0, gemm_split3_persist_ws_bytes(), st));
+            HIP_OK(hipStreamSynchronize(st));
+            e->s3_persist = 0;
+            return fail(e, THMR_ERR_HIP, "persistent split3 GEMM: a hand-over wait timed out in a previous forward; that call's outputs are invalid. "
+                                         "The engine has reset the workspace and switched to the per-tile kernel: re-submit the batch");
+        }
+    }
     return 0;
 }
 
@@ -1414,13 +1462,13 @@ int thmr_debug_decoder_timeline(thmr_engine* e, uint64_t* stamps_host, int32_t m
 }
 
 int thmr_vit_forward(thmr_engine* e, const float* img_dev, int32_t B, float* feats_dev, void* stream) {
-    if (int r = check_ready(e, B)) return r;
+    if (int r = check_ready(e, B, static_cast<hipStream_t>(stream))) return r;
     if (!img_dev || !feats_dev) return fail(e, THMR_ERR_INVALID, "null buffer");
     return vit_forward(e, img_dev, B, feats_dev, static_cast<hipStream_t>(stream));
 }
 
 int thmr_head_forward(thmr_engine* e, const float* ctx_dev, int32_t B, const thmr_outputs* out, void* stream) {
-    if (int r = check_ready(e, B)) return r;
+    if (int r = check_ready(e, B, static_cast<hipStream_t>(stream))) return r;
     if (!ctx_dev) return fail(e, THMR_ERR_INVALID, "null buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (int r = head_forward(e, ctx_dev, B, out, st)) return r;
@@ -1434,7 +1482,7 @@ int thmr_head_forward(thmr_engine* e, const float* ctx_dev, int32_t B, const thm
 }
 
 int thmr_forward(thmr_engine* e, const float* img_dev, int32_t B, const thmr_outputs* out, void* stream) {
-    if (int r = check_ready(e, B)) return r;
+    if (int r = check_ready(e, B, static_cast<hipStream_t>(stream))) return r;
     if (!img_dev || !out) return fail(e, THMR_ERR_INVALID, "null buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* ctx = e->S(e->so.h);
@@ -1565,11 +1613,19 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
     if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || ldc < N)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: K % 32 == 0, lda / ldw multiples of 8 and >= K, ldc >= N");
     if (!(variant >= -1 && variant <= 4) && variant != 31 && variant != 32 && variant != 34 && variant != 37 && !(variant >= 100 && variant <= 102) &&
-        variant != 202 && variant != 204)
-        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 1, 2, 100-102, 202, 204 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
+        variant != 202 && variant != 204 && variant != 300)
+        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 1, 2, 100-102, 202, 204, 300 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, resid, ldc, C, ldc, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (variant == 300) {
+        // 256 persistent workgroups over a tile stream (gemm_split_persist.hip): M % 128 == 0, N % 256 == 0, at least 256 tiles
+        if (!gemm_split3_persist_ok(a)) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM: M % 128 == 0, N % 256 == 0, M / 128 * N / 256 >= 256, K >= 64");
+        void* ws = gemm_split3_persist_op_ws(st);
+        if (!ws) return fail(e, THMR_ERR_NOMEM, "persistent split3 GEMM: workspace allocation failed");
+        LAUNCH_OK(launch_gemm_split3_persist(a, epi, 0, ws, st));
+        return 0;
+    }
     if (variant == 202 || variant == 204) {
         // split-K 2 / 4 on the big tiles; partial sums in a grow-only workspace per (device, stream), then the fixed-order reduce + epilogue
         const int ksplit = variant - 200;
@@ -1632,10 +1688,19 @@ int thmr_op_gemm_split3_out_split3(const void* A, int64_t lda, const void* W, in
     if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || (N % 8) != 0 ||
         (ldcs % 8) != 0 || ldcs < N)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: K % 32 == 0, N % 8 == 0, lda / ldw / ldcs multiples of 8 and >= K / K / N");
-    if ((variant < -1 || variant > 2) && variant != 4 && variant != 100) return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 1, 2, 4 or 100 (small-M ring kernel)");
+    if ((variant < -1 || variant > 2) && variant != 4 && variant != 100 && variant != 301 && variant != 302)
+        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 1, 2, 4, 100 (small-M ring kernel), 301 / 302 (persistent workgroups: LDS / swapped-role epilogue)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, nullptr, 0, nullptr, 0, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
     a.c_split = Cs; a.ldcs = ldcs;
+    if (variant >= 301) {
+        if (epi != EPI_NONE && epi != EPI_BIAS_GELU) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM with split3 output: epilogue must be 0 or 2");
+        if (!gemm_split3_persist_ok(a)) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM: M % 128 == 0, N % 256 == 0, M / 128 * N / 256 >= 256, K >= 64");
+        void* ws = gemm_split3_persist_op_ws(static_cast<hipStream_t>(stream));
+        if (!ws) return fail(e, THMR_ERR_NOMEM, "persistent split3 GEMM: workspace allocation failed");
+        LAUNCH_OK(launch_gemm_split3_persist(a, epi, variant - 300, ws, static_cast<hipStream_t>(stream)));
+        return 0;
+    }
     if (variant == 100) LAUNCH_OK(launch_gemm_split3_ring(a, epi, 1, nullptr, static_cast<hipStream_t>(stream)));
     else LAUNCH_OK(launch_gemm_split3(a, epi, variant, static_cast<hipStream_t>(stream)));
     return 0;

@@ -164,7 +164,8 @@ class ShardedRunner:
 
     def __init__(self, forward_fn, gather: bool = True, device=None):
         """device: where this rank's records live (the engine's device).  Default: the current CUDA device under the nccl
-        backend, else the device of the batch handed to __call__."""
+        backend; under gloo the device of the first records this rank packs.  Pass it explicitly under gloo with GPU engines when a
+        rank's FIRST shard can be empty and the batch is a host tensor — otherwise that one call returns host tensors on this rank."""
         self.forward_fn = forward_fn
         self.gather = gather
         self.rank = dist.get_rank() if dist.is_initialized() else 0
@@ -181,6 +182,8 @@ class ShardedRunner:
         s, e = self.local_slice(total)
         if e > s:
             rec = pack_records(self.forward_fn(img_global[s:e]))
+            if self.device is None:
+                self.device = rec.device            # remembered: a later EMPTY shard of this rank puts its zero rows on the same device
         else:
             # fewer crops than ranks (e.g. 3 detections in a frame on 8 GPUs): this rank has nothing to run — the engine
             # rejects B < 1 — but it must still enter the collective, with a zero-row record block

@@ -122,8 +122,8 @@ class Engine:
     # ------------------------------------------------------------------ forward
     def _alloc_outputs(self, B, taps=False, want_probs=True):
         """Fresh output tensors for one call (never reused across calls: a caller may keep the previous call's dict), carved out
-        of ONE allocation for the nine small tensors (ten separate torch.empty calls cost ~0.1 ms per call, 3 % of a one-crop forward)
-        plus one each for the MB-per-crop tensors.  Every tensor starts on a 256-byte boundary; token_idx is an int32 view."""
+        of ONE allocation for the eight small tensors (ten separate torch.empty calls cost ~0.1 ms per call, 3 % of a one-crop forward)
+        plus one each for the vertices and the MB-per-crop tensors.  Every tensor starts on a 256-byte boundary; token_idx is an int32 view."""
         f32 = torch.float32
         spec = [("pred_cam", (B, 3)), ("rotmat", (B, 24, 3, 3)), ("betas", (B, 10)), ("pred_cam_t", (B, 3)), ("focal_length", (B, 2)),
                 ("pred_keypoints_3d", (B, 44, 3)), ("pred_vertices", (B, 6890, 3)), ("pred_keypoints_2d", (B, 44, 2)),
@@ -132,7 +132,9 @@ class Engine:
             spec.append(("cls_logits_softmax", (B, 160, 2048)))
         if taps:
             spec += [("vit_features", (B, 192, 1280)), ("token_out", (B, 1024)), ("cls_logits", (B, 160, 2048)), ("pose6d", (B, 144))]
-        big = {"cls_logits_softmax", "vit_features", "cls_logits"}     # MB per crop: own allocations, so a kept small tensor does not pin them
+        # 80 KB ... MB per crop: own allocations, so a kept (or torch.save-d) small tensor neither pins nor serialises them.  The small
+        # tensors share ONE storage: they are views — `.clone()` what is to outlive the dict cheaply or to be pickled on its own
+        big = {"cls_logits_softmax", "vit_features", "cls_logits", "pred_vertices"}
         offs, total = {}, 0
         for name, shape in spec:
             if name in big:

@@ -81,9 +81,9 @@ class TokenHMR:
         """tokenhmr.py:135-188: batch['img'] (B,3,256,256) fp32 -> output dict.  Batches larger
         than max_batch are processed in max_batch chunks."""
         img = batch["img"]
-        if img.device.type != self.engine.device.type:
+        if img.device != self.engine.device:      # type AND index: a cuda:1 batch must not reach kernels launched on cuda:0
             raise RuntimeError(f"batch['img'] is on {img.device}, the engine on {self.engine.device}: move the batch first "
-                               "(recursive_to(batch, device), eval.py:145) — there is no CPU path")
+                               "(recursive_to(batch, device), eval.py:145) — there is no CPU path and no peer-access path")
         if img.dtype != torch.float32:
             img = img.float()
         B = img.shape[0]

@@ -42,6 +42,9 @@ def gemm(a, w, bias=None, resid=None, epi="none", qscale=1.0, qcols=0, variant="
 
 
 SPLIT3_VARIANT = {"auto": -1, "128x256/w8": 0, "128x256/w4": 1, "128x128/w4": 2, "256x256/w4": 4, "ring": 100, "ring/k2": 101, "ring/k4": 102, "auto/k2": 202, "auto/k4": 204,
+                  # 256 persistent workgroups over a tile stream (csrc/gemm_split_persist.hip; M % 128 == 0, N % 256 == 0, >= 256 tiles):
+                  # fp32 output / split3 output through the LDS transposition / split3 output through swapped operand roles
+                  "persist": 300, "persist/lds": 301, "persist/swap": 302,
                   # schedule experiments (epilogue "none" only; the abl/* ones are timing-only, their results are garbage)
                   "exp/reads-every-2nd": 3, "abl/no-copies": 31, "abl/no-barrier": 32, "abl/no-reads": 34, "abl/none": 37}
 

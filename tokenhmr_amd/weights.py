@@ -167,12 +167,49 @@ def _fill(shape, kind, fan_in, g):
     raise ValueError(kind)
 
 
-def make_synthetic_state(cfg: HMRConfig = RELEASE, seed: int = 0):
-    """Seeded TokenHMR state_dict (reference key names)."""
+def make_synthetic_state(cfg: HMRConfig = RELEASE, seed: int = 0, style: str = "init"):
+    """Seeded TokenHMR state_dict (reference key names).
+
+    style "init": the default-init statistics described in the module docstring.
+    style "trained": the same draw, then reshaped towards what a TRAINED ViT-H looks like (the released weights are trained,
+    README.md:92-97, and cannot be fetched here): per-channel LayerNorm gains log-uniform in [0.1, 10] with biases of a few
+    tenths, ~1 % outlier output channels scaled x50 in every `attn.proj` / `mlp.fc2` weight (the "massive activation" channels
+    of the residual stream), and non-trivial mean parameters (a random pose of ~0.3 rad per joint, betas, a shifted camera).
+    The "init" tensors of a (cfg, seed) are bit-for-bit the same whatever styles exist (own generator for the reshaping)."""
     g = torch.Generator(device="cpu").manual_seed(1000 + seed)
     sd = OrderedDict()
     for name, shape, kind, fan_in in spec(cfg):
         sd[name] = _fill(shape, kind, fan_in, g)
+    if style == "init":
+        return sd
+    if style != "trained":
+        raise ValueError(f"unknown weight style '{style}'")
+    g2 = torch.Generator(device="cpu").manual_seed(7000 + seed)
+    for name, shape, kind, fan_in in spec(cfg):
+        if name.endswith(("mixer_trans.ff.1.weight", "mixer_trans.ff.1.bias")):
+            continue                                  # LayerNorm(10240) in front of the classifier: left at its init statistics
+        if kind == "ln_w":
+            lo, hi = math.log(0.1), math.log(10.0)
+            sd[name] = torch.exp(lo + (hi - lo) * torch.rand(shape, generator=g2, dtype=torch.float32))
+        elif kind == "ln_b":
+            sd[name] = 0.3 * torch.randn(shape, generator=g2, dtype=torch.float32)
+        elif kind == "w" and name.startswith("backbone.blocks.") and name.endswith(("attn.proj.weight", "mlp.fc2.weight")):
+            n_out = shape[0]
+            pick = torch.randperm(n_out, generator=g2)[: max(1, n_out // 100)]
+            w = sd[name].clone()
+            w[pick] *= 50.0
+            sd[name] = w
+    # mean parameters: 24 random rotations of ~0.3 rad in the reference's 6D form (the first two ROWS of R: geometry.py:73-84
+    # reads elements 0-2 as a1, 3-5 as a2 and stacks b1, b2, b3 as rows), betas, camera
+    aa = 0.3 * torch.randn(24, 3, generator=g2, dtype=torch.float64)
+    th = aa.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    k = aa / th
+    K = torch.zeros(24, 3, 3, dtype=torch.float64)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -k[:, 2], k[:, 1], k[:, 2], -k[:, 0], -k[:, 1], k[:, 0]
+    R = torch.eye(3, dtype=torch.float64) + torch.sin(th)[..., None] * K + (1 - torch.cos(th))[..., None] * (K @ K)
+    sd["smpl_head.init_body_pose"] = R[:, :2, :].reshape(1, 144).float()
+    sd["smpl_head.init_betas"] = 0.5 * torch.randn(1, 10, generator=g2, dtype=torch.float32)
+    sd["smpl_head.init_cam"] = torch.tensor([[0.85, 0.06, -0.04]], dtype=torch.float32)
     return sd
 
 
