@@ -239,12 +239,13 @@ def test_fused_head_equals_chain_head_across_batch_sizes(built_lib, cuda_dev, mo
     fused.load_state(sd, tok)
     fused.load_smpl(smpl)
     fused.finalize()
+    # the forcing knobs exist only in the experiments build of the library (experiments=True); `fused` is the shipped one
     monkeypatch.setenv("THMR_LEGACY_HEAD", "1")          # read once, at thmr_create
-    chain = Engine(cfg, max_batch=128, device=cuda_dev, weight_arena=fused.weight_arena)
+    chain = Engine(cfg, max_batch=128, device=cuda_dev, weight_arena=fused.weight_arena, experiments=True)
     chain.finalize(assume_all_loaded=True)
     monkeypatch.delenv("THMR_LEGACY_HEAD")
     monkeypatch.setenv("THMR_MIXER_CLUSTER", "0")        # the mixer stack as its own kernel, one workgroup per crop, at every batch size
-    plain = Engine(cfg, max_batch=128, device=cuda_dev, weight_arena=fused.weight_arena)
+    plain = Engine(cfg, max_batch=128, device=cuda_dev, weight_arena=fused.weight_arena, experiments=True)
     plain.finalize(assume_all_loaded=True)
     monkeypatch.delenv("THMR_MIXER_CLUSTER")
     ctx = torch.randn(128, 192, 1280, generator=torch.Generator().manual_seed(12)).to(cuda_dev)
@@ -290,16 +291,18 @@ def test_decoder_timeout_is_reported_once_and_the_engine_recovers(built_lib, cud
     from tokenhmr_amd.engine import Engine
     cfg = HMRConfig(vit_depth=1, dec_depth=2)
     sd, tok, smpl = W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0), make_synthetic_smpl(cfg, 0)
+    # THMR_LEGACY_HEAD / THMR_DEC_FORCE_TIMEOUT are hooks of the experiments build (experiments=True); the recovery code they exercise
+    # (check_ready / thmr_engine_status -> recover_decoder_timeout) is the shipped library's, compiled from the same source
     monkeypatch.setenv("THMR_LEGACY_HEAD", "1")
-    chain = Engine(cfg, max_batch=4, device=cuda_dev)
+    chain = Engine(cfg, max_batch=4, device=cuda_dev, experiments=True)
     chain.load_state(sd, tok)
     chain.load_smpl(smpl)
     chain.finalize()
     monkeypatch.delenv("THMR_LEGACY_HEAD")
     monkeypatch.setenv("THMR_DEC_FORCE_TIMEOUT", "1")          # read at finalize
-    a = Engine(cfg, max_batch=4, device=cuda_dev, weight_arena=chain.weight_arena)
+    a = Engine(cfg, max_batch=4, device=cuda_dev, weight_arena=chain.weight_arena, experiments=True)
     a.finalize(assume_all_loaded=True)
-    b = Engine(cfg, max_batch=4, device=cuda_dev, weight_arena=chain.weight_arena)
+    b = Engine(cfg, max_batch=4, device=cuda_dev, weight_arena=chain.weight_arena, experiments=True)
     b.finalize(assume_all_loaded=True)
     monkeypatch.delenv("THMR_DEC_FORCE_TIMEOUT")
     img = torch.randn(4, 3, 256, 256, generator=torch.Generator().manual_seed(3)).to(cuda_dev)

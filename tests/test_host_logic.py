@@ -103,10 +103,14 @@ def test_create_without_gpu_fails_loudly(built_lib):
 
 
 def test_missing_library_message(monkeypatch):
-    monkeypatch.setattr(_cabi, "_lib", None)
+    monkeypatch.setattr(_cabi, "_libs", {})
     monkeypatch.setattr(_cabi, "LIB_PATH", "/nonexistent/libtokenhmr_hip.so")
+    monkeypatch.setattr(_cabi, "LIB_PATH_EXP", "/nonexistent/libtokenhmr_hip_exp.so")
+    monkeypatch.delenv("THMR_LIB", raising=False)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _cabi.load()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _cabi.load(exp=True)
 
 
 def test_validate_state_strict():
@@ -295,6 +299,29 @@ def test_gemm_k_loops_carry_no_valu_instruction(built_lib, tmp_path):
         assert len(m0_writers) == len(dma), (sym, len(m0_writers), len(dma))
 
 
+def test_shipped_library_reads_no_environment_and_carries_no_experiment(built_lib):
+    """the A/B knobs (22 getenv("THMR_*") in round 3), the debug hooks and the kernels that lost their A/B live in the
+    EXPERIMENTS build only (-DTHMR_EXPERIMENTS -> lib/libtokenhmr_hip_exp.so).  The shipped library imports no getenv, holds no knob
+    name, none of those kernels' symbols, and no source file calls getenv outside the one guarded helper in common.h."""
+    import glob
+    import re
+    shipped = open(_cabi.LIB_PATH, "rb").read()
+    exp = open(_cabi.LIB_PATH_EXP, "rb").read()
+    assert b"getenv" not in shipped and b"getenv" in exp
+    knobs = [b"THMR_LEGACY_HEAD", b"THMR_DEC_FORCE_TIMEOUT", b"THMR_DEC_BARRIER", b"THMR_SPLIT3_SMALL", b"THMR_ALONE_PENALTY", b"THMR_SPLIT3_TILE",
+             b"THMR_ATTN_VARIANT", b"THMR_MID_SPLIT", b"THMR_SPLIT3_PERSIST"]
+    for k in knobs:
+        assert k not in shipped and k in exp, k
+    for sym in (b"gemm_split3_wide_kernel", b"gemm_split3_ring_kernel"):
+        assert sym not in shipped and sym in exp, sym
+    assert b"gemm_split3_persist_kernel" in shipped and b"gemm_split3_kernel" in shipped
+    csrc = os.path.join(os.path.dirname(os.path.dirname(_cabi.LIB_PATH)), "csrc")
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        n = len(re.findall(r"\bgetenv\s*\(", open(f).read()))
+        assert n == (1 if f.endswith("common.h") else 0), (f, n)
+    assert b"experiments" in _cabi.load(exp=True).thmr_build_info() and b"experiments" not in _cabi.load(exp=False).thmr_build_info()
+
+
 def test_attention_lds_dma_copies_keep_their_m0(built_lib, tmp_path):
     """The attention kernel issues its K / V copies through the same inline-assembly saddr LDS-DMA as the GEMM (attention.hip
     dma16_saddr): M0 is written inside the asm and cannot be declared, so — on every toolchain bump — check at the ISA level that each
@@ -335,14 +362,17 @@ def test_attention_lds_dma_copies_keep_their_m0(built_lib, tmp_path):
             # waits with vmcnt(30) for the K' copies, i.e. it RELIES on exactly 15 output stores + 15 Q' loads being the only younger
             # operations of the wave.  Fewer (a toolchain that merges stores, or spill traffic moved elsewhere) would make the wait too
             # weak: check the instruction stream between the last copy and that wait, and that the kernel has no scratch traffic.
-            # The SPLIT instantiation (output as a split3 operand: three 8-byte stores per tile) waits with vmcnt(60) for 45 stores + 15 loads.
+            # The SPLIT instantiation (output as a split3 operand: after the permlane16 swaps 7 tile pairs x three 16-byte stores + one
+            # unpaired tile x three 8-byte stores) waits with vmcnt(39) for 24 stores + 15 loads.
             split = "Lb1E" in text[st]
-            n_wait, store_op, n_stores = (60, "global_store_dwordx2", 45) if split else (30, "global_store_dwordx4", 15)
+            n_wait, store_ops = (39, {"global_store_dwordx4": 21, "global_store_dwordx2": 3}) if split else (30, {"global_store_dwordx4": 15})
             w30 = [i for i, (op, a) in enumerate(ins) if op == "s_waitcnt" and a.replace(" ", "") == f"vmcnt({n_wait})"]
             assert len(w30) == 1, [a for op, a in ins if op == "s_waitcnt" and "vmcnt" in a]
             last_dma = max(i for i in dma if i < w30[0])
             between = [op for op, _ in ins[last_dma + 1:w30[0]]]
-            assert between.count(store_op) == n_stores and between.count("global_load_dwordx4") == 15, between
-            assert not any(op.startswith(("global_", "buffer_", "scratch_", "flat_")) and op not in (store_op, "global_load_dwordx4")
+            assert all(between.count(op) == n for op, n in store_ops.items()) and between.count("global_load_dwordx4") == 15, between
+            assert not any(op.startswith(("global_", "buffer_", "scratch_", "flat_")) and op not in (*store_ops, "global_load_dwordx4")
                            for op in between), between
+            if split:
+                assert sum(1 for op, _ in ins if op.startswith("v_permlane16_swap")) >= 28
             assert not any(op.startswith("scratch_") for op, _ in ins), "register spills in the persistent attention kernel"

@@ -9,6 +9,10 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtokenhmr_hip.so")
+# the EXPERIMENTS build of the same sources (-DTHMR_EXPERIMENTS: THMR_* environment knobs, debug hooks, kernels that lost their A/B —
+# csrc/common.h).  Never the product path: tests and scripts ask for it with load(exp=True) / Engine(..., experiments=True), or a whole
+# process with THMR_LIB=exp.
+LIB_PATH_EXP = os.path.join(_HERE, "lib", "libtokenhmr_hip_exp.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "tokenhmr_hip.h")
 
 ABI_VERSION = 3
@@ -58,16 +62,20 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(thmr_[a-z0-9_]+)\s*\(", text)))
 
 
-_lib = None
+_libs = {}
 
 
-def load():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(exp=None):
+    """The shipped library, or (exp=True, or exp=None with THMR_LIB=exp in the environment) the experiments build."""
+    if exp is None:
+        exp = os.environ.get("THMR_LIB", "") == "exp"
+    exp = bool(exp)
+    if exp in _libs:
+        return _libs[exp]
+    path = LIB_PATH_EXP if exp else LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
+            f"{path} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
     # ONE HIP runtime per process.  libtokenhmr_hip.so needs "libamdhip64.so.7" (resolved to /opt/rocm when nothing of that soname
     # is loaded yet); PyTorch's libraries need "libamdhip64.so" and find the copy bundled under torch/lib, which the loader does NOT
@@ -79,7 +87,7 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     if missing:
         raise RuntimeError(f"libtokenhmr_hip.so lacks symbols declared in tokenhmr_hip.h: {missing}")
@@ -143,7 +151,7 @@ def load():
             fn.restype = C.c_int
     if lib.thmr_abi_version() != ABI_VERSION:
         raise RuntimeError("libtokenhmr_hip.so ABI version mismatch")
-    _lib = lib
+    _libs[exp] = lib
     return lib
 
 
@@ -151,8 +159,8 @@ class EngineError(RuntimeError):
     pass
 
 
-def check(rc, engine=None):
+def check(rc, engine=None, lib=None):
     if rc != 0:
-        lib = load()
+        lib = lib if lib is not None else load()
         msg = lib.thmr_last_error(engine)
         raise EngineError(f"tokenhmr_hip error {rc}: {msg.decode() if msg else '?'}")

@@ -85,6 +85,39 @@ __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// SPLIT output of a wave's O tiles.  The MFMA leaves lane (l15, g) with 4 consecutive d of query l15 per (qt, dt) tile: columns
+// h 80 + 16 dt + 4 g ... + 3 — the 8-byte LOWER half of a split3 chunk group for even g, the upper half for odd g.  Written as such that is
+// three 8-byte stores per tile (45 per item; measured 137 vs 102 us per launch at 64 crops, profiles/r3ah_split3_kernel_stats.csv).  Two
+// tiles X, Y at a time, v_permlane16_swap exchanges X's odd 16-lane rows with Y's even rows: afterwards an even-g lane holds all 8 columns
+// of tile X's group (its own half + its neighbour's) and the odd-g lane next to it all 8 of tile Y's — three 16-byte stores of 48
+// contiguous bytes each, 21 + 3 stores per item instead of 45.  The values are the same fp32 numbers, so the pieces are too.
+struct SplitPair { int qa, da, qb, db; };
+template <int QT>
+__device__ __forceinline__ void store_o_split3(char* out, int64_t tok0, int col0, int l15, int g, f32x4 (&o)[QT][5], const float (&inv)[QT]) {
+    constexpr int NPAIR = QT == 3 ? 7 : 2 * QT;
+    constexpr SplitPair P3[7] = {{0, 0, 0, 1}, {0, 2, 0, 3}, {1, 0, 1, 1}, {1, 2, 1, 3}, {2, 0, 2, 1}, {2, 2, 2, 3}, {0, 4, 1, 4}};
+    const bool odd = (g & 1) != 0;
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+        const SplitPair pr = QT == 3 ? P3[p] : SplitPair{p / 2, 2 * (p % 2), p / 2, 2 * (p % 2) + 1};
+        f32x4 x = o[pr.qa][pr.da] * inv[pr.qa], y = o[pr.qb][pr.db] * inv[pr.qb];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+            const u32x2_t sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[j]), __float_as_uint(y[j]), false, false);
+            x[j] = __uint_as_float(sw.x);
+            y[j] = __uint_as_float(sw.y);
+        }
+        const int q = odd ? pr.qb : pr.qa, dt = odd ? pr.db : pr.da;
+        store_split3_oct(out + (tok0 + q * 16 + l15) * (DIM * 6), col0 + dt * 16 + (g & 2) * 4, x, y);
+    }
+    // the tile without a partner (QT = 3: (2, 4); otherwise every (qt, 4)): the 8-byte halves
+#pragma unroll
+    for (int qt = (QT == 3 ? 2 : 0); qt < QT; ++qt)
+        store_split3_quad(out + (tok0 + qt * 16 + l15) * (DIM * 6), col0 + 4 * 16 + g * 4, o[qt][4] * inv[qt]);
+}
+constexpr int kSplitStores3 = 7 * 3 + 3;       // VMEM stores per item of store_o_split3<3> (the persistent kernel counts them: vmcnt)
+
 // Diagnostics (scripts/micro/attn_timeline.hip only; the product instantiations use DBG = 0 and compile to the same code as before):
 //   DBG & 1: wave 0 of every workgroup stamps s_memrealtime (100 MHz) at the phase boundaries and records HW_ID / XCC_ID
 //   DBG & 4: the round-1 block order (logical index = blockIdx.x, heads of a crop spread over the eight XCDs)
@@ -276,16 +309,15 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 6 : 2) void vit_attention_kerne
     // ---- normalise + store: D layout of 16x16: col = lane&15 -> query (the lane that holds this query's 1/sum),
     //      row = 4*(lane>>4) + reg -> d  (one float4 per tile) ----
     float* obase = out + (int64_t)b * NTOK * DIM + h * HD;
+    if constexpr (SPLIT) {
+        store_o_split3<QT>(reinterpret_cast<char*>(out), (int64_t)b * NTOK + q0, h * HD, l15, g, o, inv);
+    } else {
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int dt = 0; dt < 5; ++dt) {
-            if constexpr (SPLIT)
-                store_split3_quad(reinterpret_cast<char*>(out) + ((int64_t)b * NTOK + q0 + qt * 16 + l15) * (DIM * 6), h * HD + dt * 16 + g * 4,
-                                  o[qt][dt] * inv[qt]);
-            else
+            for (int dt = 0; dt < 5; ++dt)
                 *reinterpret_cast<f32x4*>(obase + (int64_t)(q0 + qt * 16 + l15) * DIM + dt * 16 + g * 4) = o[qt][dt] * inv[qt];
-        }
+    }
     if constexpr ((DBG & 1) != 0) {
         if (tid == 0) {
             unsigned long long* t = dbg.tl + (size_t)blockIdx.x * 16;
@@ -498,16 +530,15 @@ __global__ __launch_bounds__(256, 2) void vit_attention_persistent_kernel(const 
         {
             const int bh = xcd * per_xcd + it;
             float* obase = out + (int64_t)(bh / NH) * NTOK * DIM + (bh % NH) * HD;
+            if constexpr (SPLIT) {       // 24 stores per item instead of 15 (see the wait below)
+                store_o_split3<QT>(reinterpret_cast<char*>(out), (int64_t)(bh / NH) * NTOK + q0, (bh % NH) * HD, l15, g, o, inv);
+            } else {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
+                for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-                for (int dt = 0; dt < 5; ++dt) {
-                    if constexpr (SPLIT)      // three 8-byte stores per tile instead of one 16-byte store: 45 stores per item (see the wait below)
-                        store_split3_quad(reinterpret_cast<char*>(out) + ((int64_t)(bh / NH) * NTOK + q0 + qt * 16 + l15) * (DIM * 6),
-                                          (bh % NH) * HD + dt * 16 + g * 4, o[qt][dt] * inv[qt]);
-                    else
+                    for (int dt = 0; dt < 5; ++dt)
                         *reinterpret_cast<f32x4*>(obase + (int64_t)(q0 + qt * 16 + l15) * DIM + dt * 16 + g * 4) = o[qt][dt] * inv[qt];
-                }
+            }
         }
         if constexpr ((DBG & 1) != 0) {
             if (tid == 0 && it == within) {          // timeline of the first item only
@@ -531,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void vit_attention_persistent_kernel(const 
             for (int j = 0; j < 5; ++j)
                 qf[qt][j] = *reinterpret_cast<const f32x4*>(nbase + (int64_t)(q0 + qt * 16 + l15) * QKV_LD + j * 16 + g * 4);
         asm volatile("" ::: "memory");
-        wait_vm_barrier<SPLIT ? 60 : 30>();   // this wave's K'[0:96] and K'[96:192] copies landed: only the 15 (split3: 45) stores and the 15 Q' loads are younger
+        wait_vm_barrier<SPLIT ? kSplitStores3 + 15 : 30>();   // this wave's K'[0:96] and K'[96:192] copies landed: only the 15 (split3: 24) stores and the 15 Q' loads are younger
         it += wpx;
         base = nbase;
     }
@@ -648,23 +679,29 @@ __global__ __launch_bounds__(256) void vit_attention_keysplit_kernel(const float
     }
     __syncthreads();
     if constexpr (SPLIT) {
-        // the same merge, four consecutive d per thread, written as the 8-byte halves of the three split3 chunks (out = split3 operand)
-        for (int idx = tid; idx < 16 * QT * (HD / 4); idx += 256) {
-            const int q = idx / (HD / 4), d = (idx - q * (HD / 4)) * 4;
+        // the same merge, eight consecutive d per thread, written as the three whole 16-byte chunks of one k-group (out = split3 operand)
+        for (int idx = tid; idx < 16 * QT * (HD / 8); idx += 256) {
+            const int q = idx / (HD / 8), d = (idx - q * (HD / 8)) * 8;
             const float M = fmaxf(fmaxf(sm[0][q], sm[1][q]), fmaxf(sm[2][q], sm[3][q]));
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             float L = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const float a = __builtin_amdgcn_exp2f((sm[w][q] - M) * LOG2E);
-                const f32x4 pv = *reinterpret_cast<const f32x4*>(&so[w][q][d]);
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(&so[w][q][d]), p1 = *reinterpret_cast<const f32x4*>(&so[w][q][d + 4]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = fmaf(pv[e], a, acc[e]);
+                for (int e = 0; e < 4; ++e) {
+                    acc0[e] = fmaf(p0[e], a, acc0[e]);
+                    acc1[e] = fmaf(p1[e], a, acc1[e]);
+                }
                 L = fmaf(sl[w][q], a, L);
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = acc[e] / L;
-            store_split3_quad(reinterpret_cast<char*>(out) + ((int64_t)b * NTOK + q0 + q) * (DIM * 6), h * HD + d, acc);
+            for (int e = 0; e < 4; ++e) {
+                acc0[e] = acc0[e] / L;
+                acc1[e] = acc1[e] / L;
+            }
+            store_split3_oct(reinterpret_cast<char*>(out) + ((int64_t)b * NTOK + q0 + q) * (DIM * 6), h * HD + d, acc0, acc1);
         }
         return;
     }
@@ -689,7 +726,7 @@ __global__ __launch_bounds__(256) void vit_attention_keysplit_kernel(const float
 int launch_vit_attention_keysplit_qt(const float* qkv, float* out, int B, int want_qt, hipStream_t s) {
     if (B <= 0) return -1;
     // 16 / 32 / 48 queries per workgroup are bit-identical: one crop takes the shortest chain, more crops the fewer K / V re-reads
-    static const int forced_qt = [] { const char* e = getenv("THMR_ATTN_KEYSPLIT_QT"); return e ? atoi(e) : 0; }();   // A/B knob
+    static const int forced_qt = [] { const char* e = thmr_knob("THMR_ATTN_KEYSPLIT_QT"); return e ? atoi(e) : 0; }();   // A/B knob
     const int qt = want_qt ? want_qt : forced_qt ? forced_qt : (B == 1 ? 1 : B <= 2 ? 2 : 3);      // measured: profiles/r3j_attention_keysplit_ab.log
     if (qt == 1) hipLaunchKernelGGL(vit_attention_keysplit_kernel<1>, dim3(B * NH * 12), dim3(256), 0, s, qkv, out);
     else if (qt == 2) hipLaunchKernelGGL(vit_attention_keysplit_kernel<2>, dim3(B * NH * 6), dim3(256), 0, s, qkv, out);
@@ -729,7 +766,7 @@ int launch_vit_attention_split3(const float* qkv, void* out_split, int B, hipStr
 int launch_vit_attention_variant(const float* qkv, float* out, int B, int want, hipStream_t s) {
     if (B <= 0) return -1;
     // while 48*B workgroups of 64 queries still fit the 512 resident slots (2 per CU) they finish sooner than 16*B of 192
-    static const int forced = [] { const char* e = getenv("THMR_ATTN_VARIANT"); return e ? atoi(e) : 0; }();   // A/B knob (scripts/)
+    static const int forced = [] { const char* e = thmr_knob("THMR_ATTN_VARIANT"); return e ? atoi(e) : 0; }();   // A/B knob (scripts/)
     // The variants are bit-identical, so the choice is purely a matter of time (profiles/r2ab_attn_variant_sweep.log, us per launch):
     //   1 = three 64-query workgroups per (crop, head): wins while its 48 B workgroups fill the 512 resident slots evenly — up to 10
     //       crops (one round: 23-25 us vs 30-32) and again for 17-24 crops (two rounds: 44-54 us, where 16 B workgroups of 192
@@ -745,13 +782,17 @@ int launch_vit_attention_variant(const float* qkv, float* out, int B, int want, 
     const AttnDbg nodbg{nullptr, 0, 0};
     if (variant == 6) return launch_vit_attention_keysplit(qkv, out, B, s);
     if (variant == 5) {
-        static const int dephase_us = [] { const char* e = getenv("THMR_ATTN_DEPHASE_US"); return e ? atoi(e) : kAttnDephaseUs; }();   // A/B knob
+        static const int dephase_us = [] { const char* e = thmr_knob("THMR_ATTN_DEPHASE_US"); return e ? atoi(e) : kAttnDephaseUs; }();   // A/B knob
         const AttnDbg dph{nullptr, dephase_us * 100, 0};
         hipLaunchKernelGGL((vit_attention_persistent_kernel<0>), dim3(min(B * NH, 512)), dim3(256), 0, s, qkv, out, B * NH, dph);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     if (variant == 1) hipLaunchKernelGGL((vit_attention_kernel<1, 4>), dim3(B * NH * 3), dim3(256), 0, s, qkv, out, nodbg);
+#ifdef THMR_EXPERIMENTS
     else if (variant == 12) hipLaunchKernelGGL((vit_attention_kernel<1, 12>), dim3(B * NH), dim3(768), 0, s, qkv, out, nodbg);   // A/B only: measured no faster (profiles/r2c_attention_variants.log)
+#else
+    else if (variant == 12) return -1;            // 12 waves of 16 queries: experiments build only
+#endif
     else hipLaunchKernelGGL((vit_attention_kernel<3, 4>), dim3(B * NH), dim3(256), 0, s, qkv, out, nodbg);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -7,6 +7,19 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- A/B knobs and measured-slower variants: the EXPERIMENTS build only ----
+// The shipped library (libtokenhmr_hip.so) reads no environment variable and carries no kernel that lost its A/B: every THMR_* knob
+// below resolves to its default at compile time, and the variants they select are compiled out.  -DTHMR_EXPERIMENTS
+// (lib/libtokenhmr_hip_exp.so, built beside it by __graft_entry__.build(); tokenhmr_amd._cabi.load(exp=True) or THMR_LIB=exp) keeps
+// the knobs, the debug hooks (forced decoder timeout, barrier variants, timelines) and those kernels for the tests and scripts that
+// measure them.  The documented user-facing switch, THMR_VIT_GEMM, is read by the Python facade (tokenhmr_amd/model.py), not here.
+#include <cstdlib>
+#ifdef THMR_EXPERIMENTS
+inline const char* thmr_knob(const char* name) { return getenv(name); }
+#else
+inline const char* thmr_knob(const char*) { return nullptr; }
+#endif
+
 #define THMR_WAVE 64
 
 // ---- epilogue ids of the tiled / skinny GEMMs (also exposed through thmr_op_gemm) ----
@@ -203,6 +216,21 @@ __device__ __forceinline__ void store_split3_quad(char* row, int c, f32x4 v) {
     *reinterpret_cast<u32x2*>(o) = u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
     *reinterpret_cast<u32x2*>(o + 16) = u32x2{m[0] | (m[1] << 16), m[2] | (m[3] << 16)};
     *reinterpret_cast<u32x2*>(o + 32) = u32x2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+}
+
+// 8 consecutive columns c ... c + 7 (c % 8 == 0) of one row: the three whole 16-byte chunks of k-group c / 8 (48 contiguous bytes)
+__device__ __forceinline__ void store_split3_oct(char* row, int c, f32x4 lo, f32x4 hi) {
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        split3_of(lo[e], h[e], m[e], l[e]);
+        split3_of(hi[e], h[4 + e], m[4 + e], l[4 + e]);
+    }
+    u32x4_t* o = reinterpret_cast<u32x4_t*>(row + (c >> 3) * 48);
+    o[0] = u32x4_t{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+    o[1] = u32x4_t{m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16)};
+    o[2] = u32x4_t{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

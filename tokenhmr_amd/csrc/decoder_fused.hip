@@ -67,6 +67,7 @@ __device__ __forceinline__ bool grid_barrier(GridSync& gs, int tid, volatile int
         __hip_atomic_store(&gs.w[256 + blockIdx.x], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_ok = 1;
     }
+#ifdef THMR_EXPERIMENTS
     if (gs.a2a) {
         // Round 3 experiment (THMR_DEC_BARRIER=1), NOT the default: all-to-all.  The two-hop form below costs flag store -> workgroup 0's
         // poll -> release store -> everybody's poll = two device-scope round trips (~0.85 us each, scripts/micro/xcd_handoff.hip);
@@ -90,6 +91,7 @@ __device__ __forceinline__ bool grid_barrier(GridSync& gs, int tid, volatile int
         __syncthreads();
         return *s_ok != 0;
     }
+#endif
     if (blockIdx.x == 0) {
         __syncthreads();                                            // s_ok initialised
         if (tid < G) {
@@ -508,10 +510,12 @@ __global__ __launch_bounds__(NWAVE * 64) void decoder_persistent_kernel(DecParam
     __syncthreads();
     GridSync gs{p.sync, s_base, 0, p.host_err, p.barrier_a2a};
     bool ok = true;
+#ifdef THMR_EXPERIMENTS
     if (p.debug_fail && blockIdx.x == 0 && tid == 0) {      // tests only: exercise the host's recovery path without a real timeout
         __hip_atomic_store(&gs.w[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gs.host_err) __hip_atomic_store(gs.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+#endif
     const int B = p.B;
     // optional stage timeline (THMR_DEC_TIMELINE=1): workgroup 0 stamps the 100 MHz wall clock after every step and barrier
     unsigned long long* stamp = (p.timeline && blockIdx.x == 0 && tid == 0) ? reinterpret_cast<unsigned long long*>(p.sync + 16) : nullptr;
@@ -601,7 +605,7 @@ int launch_decoder_fused(const DecParams& p, hipStream_t s) {
     // the steps deal their items round-robin)
     const int nsub = (p.B + 15) / 16;
     int grid = NBLK * (nsub < 4 ? nsub : 4);
-    static const int min_grid = [] { const char* e = getenv("THMR_DEC_MIN_GRID"); return e ? atoi(e) : kDecMinGrid; }();   // A/B knob
+    static const int min_grid = [] { const char* e = thmr_knob("THMR_DEC_MIN_GRID"); return e ? atoi(e) : kDecMinGrid; }();   // A/B knob
     if (grid < min_grid) grid = min_grid;
     if (p.mixer_cluster != 0 && p.mixer_cluster != 10 && p.mixer_cluster != 5 && p.mixer_cluster != 2) return -1;
     if (grid < p.mixer_cluster * p.B) grid = p.mixer_cluster * p.B;     // the distributed mixer tail: mixer_cluster workgroups per crop
@@ -611,12 +615,14 @@ int launch_decoder_fused(const DecParams& p, hipStream_t s) {
     // THMR_DEC_COOP=1 (A/B knob): cooperative launch — the runtime then refuses a grid that cannot be co-resident instead of
     // letting the bounded barrier find out.  The default is a plain launch of a grid sized from the occupancy query
     // (decoder_max_coresident_blocks, engine.hip finalize), which is the same guarantee for everything this process controls.
-    static const bool coop = [] { const char* e = getenv("THMR_DEC_COOP"); return e && e[0] == '1'; }();
+#ifdef THMR_EXPERIMENTS
+    static const bool coop = [] { const char* e = thmr_knob("THMR_DEC_COOP"); return e && e[0] == '1'; }();
     if (coop) {
         DecParams pc = p;
         void* args[] = {&pc};
         return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&decoder_persistent_kernel), dim3(grid), dim3(NWAVE * 64), args, 0, s) == hipSuccess ? 0 : -2;
     }
+#endif
     hipLaunchKernelGGL(decoder_persistent_kernel, dim3(grid), dim3(NWAVE * 64), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

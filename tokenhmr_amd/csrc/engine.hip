@@ -575,6 +575,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         }
         return 0;
     }
+#ifdef THMR_EXPERIMENTS
     if (e->vit_gemm_mode == 1 && small && e->split3_small) {
         // EXPERIMENT (THMR_SPLIT3_SMALL=1, off by default): a small-batch regime (up to six crops) of the split3 mode — the ring kernel
         // on split3 operands (64 x 64 tiles, 4-deep LDS-DMA ring; proj / fc2 split K four ways into `part`, reduced by the residual +
@@ -634,6 +635,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         }
         return 0;
     }
+#endif  // THMR_EXPERIMENTS
     {
         ProfScope ps(e, st, THMR_PROF_LN, 0, 8.0 * M * DIM);
         LAUNCH_OK(launch_layernorm(x, e->vitw[0].n1w, e->vitw[0].n1b, h, M, DIM, VIT_EPS, 0, st));
@@ -1039,7 +1041,12 @@ int thmr_abi_version(void) { return THMR_ABI_VERSION; }
 #ifndef THMR_SRC_HASH
 #define THMR_SRC_HASH "unhashed"      // __graft_entry__.build() passes the content hash of csrc/ + include/ + flags
 #endif
-const char* thmr_build_info(void) { return "tokenhmr_hip gfx950 fp32-mfma src:" THMR_SRC_HASH " " __DATE__ " " __TIME__; }
+#ifdef THMR_EXPERIMENTS
+#define THMR_BUILD_KIND " experiments"      // environment knobs, debug hooks and the kernels that lost their A/B (csrc/common.h)
+#else
+#define THMR_BUILD_KIND ""
+#endif
+const char* thmr_build_info(void) { return "tokenhmr_hip gfx950 fp32-mfma src:" THMR_SRC_HASH THMR_BUILD_KIND " " __DATE__ " " __TIME__; }
 
 const char* thmr_last_error(const thmr_engine* e) { return e ? e->err.c_str() : g_last_error.c_str(); }
 
@@ -1104,17 +1111,17 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     // sticky error word of the persistent decoder kernel, host-mapped so that the next call sees a timeout without a D2H copy
     if (hipHostMalloc(reinterpret_cast<void**>(&e->host_err), 64, hipHostMallocMapped) != hipSuccess) return bail(THMR_ERR_NOMEM, "hipHostMalloc(error word) failed");
     *e->host_err = 0;
-    { const char* lg = getenv("THMR_LEGACY_HEAD"); e->legacy_head = lg && lg[0] == '1'; }
-    { const char* mc = getenv("THMR_MIXER_CLUSTER"); e->mixer_cluster = !(mc && mc[0] == '0'); }
-    { const char* tg = getenv("THMR_TINY_GEMM"); e->tiny_gemm = !(tg && tg[0] == '0'); }
-    { const char* qr = getenv("THMR_QKV_RING16"); e->qkv_ring16 = !(qr && qr[0] == '0'); }
-    { const char* ak = getenv("THMR_ATTN_KEYSPLIT"); e->attn_keysplit = !(ak && ak[0] == '0'); }
-    { const char* ss = getenv("THMR_SPLIT3_SMALL"); e->split3_small = ss && ss[0] == '1'; }
-    { const char* fs = getenv("THMR_SPLIT3_FC2_SPLIT"); e->split3_fc2_split = (fs && fs[0] == '1') ? 1 : kSplit3Fc2Split; }
-    { const char* sm = getenv("THMR_SPLIT3_MIN_B"); e->split3_min_b = sm ? atoi(sm) : 0; }
-    { const char* sp = getenv("THMR_SPLIT3_PERSIST"); if (sp && sp[0] >= '0' && sp[0] <= '1') e->s3_persist = sp[0] - '0'; }
-    { const char* fm = getenv("THMR_SPLIT3_FC1_MODE"); if (fm && fm[0] >= '0' && fm[0] <= '2') e->s3_fc1_mode = fm[0] - '0'; }
-    { const char* ms = getenv("THMR_MID_SPLIT"); if (ms && ms[0] && ms[1]) { e->mid_split_force[0] = ms[0] - '0'; e->mid_split_force[1] = ms[1] - '0'; } }
+    { const char* lg = thmr_knob("THMR_LEGACY_HEAD"); e->legacy_head = lg && lg[0] == '1'; }
+    { const char* mc = thmr_knob("THMR_MIXER_CLUSTER"); e->mixer_cluster = !(mc && mc[0] == '0'); }
+    { const char* tg = thmr_knob("THMR_TINY_GEMM"); e->tiny_gemm = !(tg && tg[0] == '0'); }
+    { const char* qr = thmr_knob("THMR_QKV_RING16"); e->qkv_ring16 = !(qr && qr[0] == '0'); }
+    { const char* ak = thmr_knob("THMR_ATTN_KEYSPLIT"); e->attn_keysplit = !(ak && ak[0] == '0'); }
+    { const char* ss = thmr_knob("THMR_SPLIT3_SMALL"); e->split3_small = ss && ss[0] == '1'; }
+    { const char* fs = thmr_knob("THMR_SPLIT3_FC2_SPLIT"); e->split3_fc2_split = (fs && fs[0] == '1') ? 1 : kSplit3Fc2Split; }
+    { const char* sm = thmr_knob("THMR_SPLIT3_MIN_B"); e->split3_min_b = sm ? atoi(sm) : 0; }
+    { const char* sp = thmr_knob("THMR_SPLIT3_PERSIST"); if (sp && sp[0] >= '0' && sp[0] <= '1') e->s3_persist = sp[0] - '0'; }
+    { const char* fm = thmr_knob("THMR_SPLIT3_FC1_MODE"); if (fm && fm[0] >= '0' && fm[0] <= '2') e->s3_fc1_mode = fm[0] - '0'; }
+    { const char* ms = thmr_knob("THMR_MID_SPLIT"); if (ms && ms[0] && ms[1]) { e->mid_split_force[0] = ms[0] - '0'; e->mid_split_force[1] = ms[1] - '0'; } }
     { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
     *out = e;
     return 0;
@@ -1289,11 +1296,11 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
         d.ro = e->S(e->so.ro); d.mt = e->S(e->so.mt);
         d.sync = reinterpret_cast<unsigned*>(e->S(e->so.sync));
         d.depth = e->dec_depth; d.B = 0;
-        { const char* tl = getenv("THMR_DEC_TIMELINE"); d.timeline = tl && tl[0] == '1'; }
-        { const char* ft = getenv("THMR_DEC_FORCE_TIMEOUT"); d.debug_fail = ft && ft[0] == '1'; }
+        { const char* tl = thmr_knob("THMR_DEC_TIMELINE"); d.timeline = tl && tl[0] == '1'; }
+        { const char* ft = thmr_knob("THMR_DEC_FORCE_TIMEOUT"); d.debug_fail = ft && ft[0] == '1'; }
         // all-to-all barrier: measured SLOWER (head 0.711 vs 0.664 ms at one crop, 2.87-2.90 vs 2.81-2.82 at 64: 128-256 workgroups x
         // 128-256 device-scope polls contend; profiles/r3k_decoder_barrier_all_to_all_ab.log) — kept behind the knob only
-        { const char* bm = getenv("THMR_DEC_BARRIER"); d.barrier_a2a = bm && bm[0] == '1'; }
+        { const char* bm = thmr_knob("THMR_DEC_BARRIER"); d.barrier_a2a = bm && bm[0] == '1'; }
         {
             // never more workgroups than can be resident at once (occupancy query x CUs): the grid barrier depends on it
             const int nb = decoder_max_coresident_blocks(e->cfg.device);
@@ -1647,6 +1654,7 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
         LAUNCH_OK(launch_splitk_epilogue(a, epi, slot.first, ksplit, st));
         return 0;
     }
+#ifdef THMR_EXPERIMENTS
     if (variant >= 100) {
         // small-M ring kernel, split-K 2^(variant - 100); partial sums in a grow-only workspace per (device, stream), then the fixed-order
         // reduce + epilogue (the engine fuses that into its residual + LayerNorm kernel)
@@ -1674,6 +1682,10 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
         if (ksplit > 1) LAUNCH_OK(launch_splitk_epilogue(a, epi, ws, ksplit, st));
         return 0;
     }
+#else
+    if (variant >= 100 || variant == 1 || variant >= 3)
+        return fail(e, THMR_ERR_INVALID, "split3 GEMM: this variant exists only in the experiments build (libtokenhmr_hip_exp.so)");
+#endif
     LAUNCH_OK(launch_gemm_split3(a, epi, variant, st));
     return 0;
 }
@@ -1694,6 +1706,9 @@ int thmr_op_gemm_split3_out_split3(const void* A, int64_t lda, const void* W, in
     a.qscale = qscale; a.qcols = qcols;
     a.c_split = Cs; a.ldcs = ldcs;
     if (variant >= 301) {
+#ifndef THMR_EXPERIMENTS
+        if (variant == 301) return fail(e, THMR_ERR_INVALID, "split3 GEMM: the LDS-epilogue persistent variant exists only in the experiments build");
+#endif
         if (epi != EPI_NONE && epi != EPI_BIAS_GELU) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM with split3 output: epilogue must be 0 or 2");
         if (!gemm_split3_persist_ok(a)) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM: M % 128 == 0, N % 256 == 0, M / 128 * N / 256 >= 256, K >= 64");
         void* ws = gemm_split3_persist_op_ws(static_cast<hipStream_t>(stream));
@@ -1701,8 +1716,16 @@ int thmr_op_gemm_split3_out_split3(const void* A, int64_t lda, const void* W, in
         LAUNCH_OK(launch_gemm_split3_persist(a, epi, variant - 300, ws, static_cast<hipStream_t>(stream)));
         return 0;
     }
-    if (variant == 100) LAUNCH_OK(launch_gemm_split3_ring(a, epi, 1, nullptr, static_cast<hipStream_t>(stream)));
-    else LAUNCH_OK(launch_gemm_split3(a, epi, variant, static_cast<hipStream_t>(stream)));
+#ifdef THMR_EXPERIMENTS
+    if (variant == 100) {
+        LAUNCH_OK(launch_gemm_split3_ring(a, epi, 1, nullptr, static_cast<hipStream_t>(stream)));
+        return 0;
+    }
+#else
+    if (variant == 100 || variant == 1 || variant == 4)
+        return fail(e, THMR_ERR_INVALID, "split3 GEMM: this variant exists only in the experiments build (libtokenhmr_hip_exp.so)");
+#endif
+    LAUNCH_OK(launch_gemm_split3(a, epi, variant, static_cast<hipStream_t>(stream)));
     return 0;
 }
 

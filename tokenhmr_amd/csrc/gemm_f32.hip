@@ -679,7 +679,7 @@ int launch_ring16_st(const GemmArgs& a, int epi, hipStream_t s) {
 // (240 workgroups) and +4 % at two (480 workgroups want two per CU), profiles/r3m_ring16_depth_ab.log — ST = 4 it is
 // (THMR_RING16_DEPTH=8 for A/B; same arithmetic, bit-identical).
 int launch_ring16(const GemmArgs& a, int epi, hipStream_t s) {
-    static const int depth = [] { const char* e = getenv("THMR_RING16_DEPTH"); return e ? atoi(e) : 4; }();
+    static const int depth = [] { const char* e = thmr_knob("THMR_RING16_DEPTH"); return e ? atoi(e) : 4; }();
     return depth == 8 ? launch_ring16_st<8>(a, epi, s) : launch_ring16_st<4>(a, epi, s);
 }
 
@@ -839,7 +839,7 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         // nothing hides the 2-buffer pipeline's memory round trip per K tile).  It is right for the split-K launcher below, but as a
         // general rule it is wrong: 1.1 gains 1.6 % per call at 3 crops and LOSES 3 % at 5-6 and 9 % at 20 crops (fc2's 240 tiles of
         // 128x160 with their 160-tile K loops are the best choice there) — profiles/r3o_alone_penalty_ab.log.
-        static const double alone = [] { const char* e = getenv("THMR_ALONE_PENALTY"); return e ? atof(e) : 1.0; }();
+        static const double alone = [] { const char* e = thmr_knob("THMR_ALONE_PENALTY"); return e ? atof(e) : 1.0; }();
         auto cost = [&](int BM, int BN, double eff) {
             const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
             return (double)((tiles + 255) / 256) * BM * BN / eff * (tiles <= 256 ? alone : 1.0);
@@ -859,7 +859,7 @@ int launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         // ring version of the same tile is used (same K order, bit-identical; measured 46 -> ~30 us on the head's B = 1 convs).
         // NOT beyond 256 tiles: with two blocks per CU the 2-buffer kernel is the faster one (fc2 at 8 crops, 480 tiles: 176 us
         // against 229 us on the ring kernel — a threshold of 512 was tried in round 2 and cost B = 8 11 %, profiles/r2ad_batch_sweep.jsonl)
-        static const long ring_max_tiles = [] { const char* e = getenv("THMR_RING_MAX_TILES"); return e ? atol(e) : 256L; }();   // A/B knob
+        static const long ring_max_tiles = [] { const char* e = thmr_knob("THMR_RING_MAX_TILES"); return e ? atol(e) : 256L; }();   // A/B knob
         if (variant == 9 && tiles64 <= ring_max_tiles && epi != EPI_BIAS_POS) return launch_ring<4>(a, epi, 1, nullptr, s);
     }
 #ifdef THMR_GEMM_ABLATION
@@ -904,7 +904,7 @@ int launch_gemm_splitk(const GemmArgs& a0, int variant, int ksplit, float* part,
     a.ksplit = ksplit;
     a.C = part; a.ldc = a.N;
     a.bias = nullptr; a.resid = nullptr; a.ldr = 0; a.cs_out = nullptr;
-    static const int forced_tile = [] { const char* e = getenv("THMR_MID_TILE"); return e ? atoi(e) : -1; }();     // A/B knob
+    static const int forced_tile = [] { const char* e = thmr_knob("THMR_MID_TILE"); return e ? atoi(e) : -1; }();     // A/B knob
     if (variant < 0 && forced_tile > 0) variant = forced_tile;
     if (variant < 0) {
         // as launch_gemm's model, plus: a grid of at most 256 blocks runs one block per CU, where nothing hides the 2-buffer

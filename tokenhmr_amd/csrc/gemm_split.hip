@@ -90,7 +90,12 @@ __global__ __launch_bounds__(256) void ln_split3_kernel(const float* __restrict_
         }
     const float var = wave_sum(sq) * (1.0f / D);
     const float rstd = 1.0f / sqrtf(var + eps);
-    char* yr = y + (int64_t)row * D * 6;
+    // The row's split3 image (6 D bytes) is assembled in a wave-private LDS buffer and then written as WHOLE lines: 1024 contiguous
+    // bytes per store instruction.  Written straight from the registers a lane owns the 8-byte half of every third 16-byte chunk, and
+    // such partial-line stores run at 3.8 instead of 6.2 TB/s (scripts/micro/store_patterns.hip, profiles/r4c_store_patterns.jsonl:
+    // 24.8 vs 15.2 us for the 94 MB of a 64-crop operand).
+    __shared__ __attribute__((aligned(16))) char rowbuf[4][D * 6];
+    char* rb = rowbuf[threadIdx.x >> 6];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
@@ -107,10 +112,18 @@ __global__ __launch_bounds__(256) void ln_split3_kernel(const float* __restrict_
             l[e] = bf16_rne(r2);
         }
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        char* o8 = yr + (c >> 3) * 48 + (lane & 1) * 8;
+        char* o8 = rb + (c >> 3) * 48 + (lane & 1) * 8;
         *reinterpret_cast<u32x2*>(o8) = u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
         *reinterpret_cast<u32x2*>(o8 + 16) = u32x2{m[0] | (m[1] << 16), m[2] | (m[3] << 16)};
         *reinterpret_cast<u32x2*>(o8 + 32) = u32x2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+    }
+    // wave-private buffer: the wave's own LDS writes are visible to its reads in program order (no barrier)
+    char* yr = y + (int64_t)row * D * 6;
+    constexpr int NCH = D * 6 / 16;                      // 16-byte chunks of the row (480)
+#pragma unroll
+    for (int i = 0; i < (NCH + 63) / 64; ++i) {
+        const int ch = i * 64 + lane;
+        if (ch < NCH) *reinterpret_cast<u32x4*>(yr + ch * 16) = *reinterpret_cast<const u32x4*>(rb + ch * 16);
     }
 }
 
@@ -281,6 +294,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split3_kernel(GemmArgs a, i
     store_tile<TM, TN, EPI>(a, acc, bm0 + wm0, bn0 + wn0, lrow, lhalf);
 }
 
+#ifdef THMR_EXPERIMENTS      // kernels that lost their A/B (numbers in the comments): experiments build only
 // ---------------------------------------------------------------------------------------------------------------------
 // Small-M split3 GEMM (few crops: the engine's split3 mode up to six crops) — the ring kernel of gemm_f32.hip on split3 operands:
 // 64 x 64 tiles (2 x 2 waves of 32 x 32), ST-deep LDS ring of 24 KB stages fed by global_load_lds whose completion is tracked with
@@ -551,6 +565,8 @@ int launch_split3_wide(const GemmArgs& a, int epi, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+#endif  // THMR_EXPERIMENTS
+
 template <int WM, int WN, int TM, int TN>
 int launch_split3_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -616,7 +632,7 @@ int launch_gemm_split3_splitk(const GemmArgs& a0, int ksplit, float* part, hipSt
 }
 
 static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStream_t s) {
-    static const int forced = [] { const char* e = getenv("THMR_SPLIT3_TILE"); return e ? atoi(e) : -1; }();     // A/B knob (0 / 2)
+    static const int forced = [] { const char* e = thmr_knob("THMR_SPLIT3_TILE"); return e ? atoi(e) : -1; }();     // A/B knob (0 / 2)
     if (variant < 0 && forced >= 0) variant = forced;
     if (variant < 0) {
         // the tiles are bit-identical (same K order per element), so the choice is purely a matter of time:
@@ -630,9 +646,10 @@ static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStrea
     }
     switch (variant) {
         case 0: return launch_split3_cfg<2, 4, 2, 2>(a, epi, s);
-        case 1: return launch_split3_cfg<2, 2, 2, 4>(a, epi, s);
         case 2: return launch_split3_cfg<2, 2, 2, 2>(a, epi, s);
-        case 4: return launch_split3_wide(a, epi, s);               // 256 x 256, 4 waves of 128 x 128, 16-deep stages
+#ifdef THMR_EXPERIMENTS
+        case 1: return launch_split3_cfg<2, 2, 2, 4>(a, epi, s);    // 4 waves of 64 x 128: 3 % slower (r3v)
+        case 4: return launch_split3_wide(a, epi, s);               // 256 x 256, 4 waves of 128 x 128, 16-deep stages: the same rate (r3ak)
         // experiments on the default tile, EPI_NONE only: 3 = step-0 fragment reads every 2nd MFMA (the first version's schedule);
         // 31 / 32 / 34 / 37 = timing-only ablations (no copies / no barrier / no fragment reads / none of the three): garbage results
         case 3: return epi == EPI_NONE ? launch_split3_abl<2, 4, 2, 2, 0, 2>(a, s) : -1;
@@ -640,10 +657,12 @@ static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStrea
         case 32: return epi == EPI_NONE ? launch_split3_abl<2, 4, 2, 2, 2, 0>(a, s) : -1;
         case 34: return epi == EPI_NONE ? launch_split3_abl<2, 4, 2, 2, 4, 0>(a, s) : -1;
         case 37: return epi == EPI_NONE ? launch_split3_abl<2, 4, 2, 2, 7, 0>(a, s) : -1;
+#endif
         default: return -1;
     }
 }
 
+#ifdef THMR_EXPERIMENTS
 // small-M split3 GEMM: 64x64 tiles on a 4-deep LDS-DMA ring; ksplit > 1 writes raw partial sums to part[ksplit][M][N] and applies NO
 // epilogue (launch_splitk_resid_ln / launch_splitk_epilogue then do)
 int launch_gemm_split3_ring(const GemmArgs& a, int epi, int ksplit, float* part, hipStream_t s) {
@@ -673,3 +692,4 @@ int launch_gemm_split3_ring(const GemmArgs& a, int epi, int ksplit, float* part,
 #undef THMR_SRING_CASE
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+#endif  // THMR_EXPERIMENTS

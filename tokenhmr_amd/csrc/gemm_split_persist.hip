@@ -406,10 +406,12 @@ int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws_me
     THMR_PERSIST_CASE(EPI_BIAS_RESID, 0)
     THMR_PERSIST_CASE(EPI_BIAS_QSCALE, 0)
     THMR_PERSIST_CASE(EPI_BIAS_GELU, 0)
-    THMR_PERSIST_CASE(EPI_BIAS_GELU, 1)
     THMR_PERSIST_CASE(EPI_BIAS_GELU, 2)
-    THMR_PERSIST_CASE(EPI_NONE, 1)
     THMR_PERSIST_CASE(EPI_NONE, 2)
+#ifdef THMR_EXPERIMENTS      // split3 output through the LDS transposition: 796 vs 784 us on the fc1 shape (profiles/r4a_split3_gemm_persistent_b64.jsonl)
+    THMR_PERSIST_CASE(EPI_BIAS_GELU, 1)
+    THMR_PERSIST_CASE(EPI_NONE, 1)
+#endif
 #undef THMR_PERSIST_CASE
     return -1;
 }

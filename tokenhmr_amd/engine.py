@@ -21,10 +21,12 @@ class Engine:
     """One engine per GPU.  The weight arena is a torch uint8 tensor so that
     torch.distributed.broadcast (RCCL) can replicate it across ranks."""
 
-    def __init__(self, cfg: HMRConfig = RELEASE, max_batch: int = 64, device="cuda:0", weight_arena=None):
+    def __init__(self, cfg: HMRConfig = RELEASE, max_batch: int = 64, device="cuda:0", weight_arena=None, experiments=None):
         """weight_arena: share another engine's (already loaded) packed weights — a second engine on the same GPU then only
         adds its own scratch arena (finalize it with assume_all_loaded=True)."""
-        self.lib = _cabi.load()
+        # experiments: None = the shipped library (or THMR_LIB=exp for a whole process); True = the -DTHMR_EXPERIMENTS build, which reads the
+        # THMR_* A/B knobs and carries the debug hooks — tests and scripts only
+        self.lib = _cabi.load(exp=experiments)
         self.cfg = cfg
         self.max_batch = int(max_batch)
         self.device = torch.device(device)
@@ -35,7 +37,7 @@ class Engine:
         self._ccfg = _cabi.Config(abi_version=_cabi.ABI_VERSION, vit_depth=cfg.vit_depth, dec_depth=cfg.dec_depth,
                                   max_batch=self.max_batch, device=idx)
         wb, sb = C.c_size_t(0), C.c_size_t(0)
-        _cabi.check(self.lib.thmr_arena_bytes(C.byref(self._ccfg), C.byref(wb), C.byref(sb)))
+        self._check(self.lib.thmr_arena_bytes(C.byref(self._ccfg), C.byref(wb), C.byref(sb)))
         self.weight_bytes, self.scratch_bytes = wb.value, sb.value
         with torch.cuda.device(self.device):
             if weight_arena is not None:
@@ -46,10 +48,13 @@ class Engine:
                 self.weight_arena = torch.empty(self.weight_bytes, dtype=torch.uint8, device=self.device)
             self.scratch_arena = torch.empty(self.scratch_bytes, dtype=torch.uint8, device=self.device)
             h = C.c_void_p(0)
-            _cabi.check(self.lib.thmr_create(C.byref(self._ccfg), _ptr(self.weight_arena), _ptr(self.scratch_arena),
+            self._check(self.lib.thmr_create(C.byref(self._ccfg), _ptr(self.weight_arena), _ptr(self.scratch_arena),
                                              C.byref(h)))
         self.h = h
         self._keep = []
+
+    def _check(self, rc, handle=None):
+        _cabi.check(rc, handle, self.lib)
 
     def close(self):
         if getattr(self, "h", None):
@@ -94,7 +99,7 @@ class Engine:
                                           on_device=1 if t.is_cuda else 0))
         arr = (_cabi.TensorDesc * len(descs))(*descs)
         with torch.cuda.device(self.device):
-            _cabi.check(self.lib.thmr_load_weights(self.h, arr, len(descs), _stream_ptr(self.device)), self.h)
+            self._check(self.lib.thmr_load_weights(self.h, arr, len(descs), _stream_ptr(self.device)), self.h)
             torch.cuda.current_stream(self.device).synchronize()   # host staging tensors may now be freed
 
     def load_smpl(self, smpl):
@@ -112,12 +117,12 @@ class Engine:
         d = _cabi.SmplDesc(**{k: ts[k].data_ptr() for k in keys + ikeys}, on_device=0,
                            update_hips=1 if smpl.get("update_hips", False) else 0)
         with torch.cuda.device(self.device):
-            _cabi.check(self.lib.thmr_load_smpl(self.h, C.byref(d), _stream_ptr(self.device)), self.h)
+            self._check(self.lib.thmr_load_smpl(self.h, C.byref(d), _stream_ptr(self.device)), self.h)
             torch.cuda.current_stream(self.device).synchronize()
 
     def finalize(self, assume_all_loaded=False):
         with torch.cuda.device(self.device):
-            _cabi.check(self.lib.thmr_finalize_weights(self.h, 1 if assume_all_loaded else 0, _stream_ptr(self.device)), self.h)
+            self._check(self.lib.thmr_finalize_weights(self.h, 1 if assume_all_loaded else 0, _stream_ptr(self.device)), self.h)
 
     # ------------------------------------------------------------------ forward
     def _alloc_outputs(self, B, taps=False, want_probs=True):
@@ -173,13 +178,13 @@ class Engine:
         o = outputs if outputs is not None else self._alloc_outputs(B, taps, want_probs)
         st = self._outputs_struct(o)
         with torch.cuda.device(self.device):
-            _cabi.check(self.lib.thmr_forward(self.h, _ptr(img), B, C.byref(st), _stream_ptr(self.device)), self.h)
+            self._check(self.lib.thmr_forward(self.h, _ptr(img), B, C.byref(st), _stream_ptr(self.device)), self.h)
         return o
 
     def status(self):
         """Synchronises the current stream and raises if a kernel of this engine reported an asynchronous error."""
         with torch.cuda.device(self.device):
-            _cabi.check(self.lib.thmr_engine_status(self.h, _stream_ptr(self.device)), self.h)
+            self._check(self.lib.thmr_engine_status(self.h, _stream_ptr(self.device)), self.h)
 
     def vit_forward(self, img, out=None):
         img = self._check_img(img)
@@ -187,7 +192,7 @@ class Engine:
         if out is None:
             out = torch.empty(B, 192, 1280, device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
-            _cabi.check(self.lib.thmr_vit_forward(self.h, _ptr(img), B, _ptr(out), _stream_ptr(self.device)), self.h)
+            self._check(self.lib.thmr_vit_forward(self.h, _ptr(img), B, _ptr(out), _stream_ptr(self.device)), self.h)
         return out
 
     def head_forward(self, ctx, taps=False, want_probs=True):
@@ -197,7 +202,7 @@ class Engine:
         o.pop("vit_features", None)
         st = self._outputs_struct(o)
         with torch.cuda.device(self.device):
-            _cabi.check(self.lib.thmr_head_forward(self.h, _ptr(ctx), B, C.byref(st), _stream_ptr(self.device)), self.h)
+            self._check(self.lib.thmr_head_forward(self.h, _ptr(ctx), B, C.byref(st), _stream_ptr(self.device)), self.h)
         return o
 
     def lbs_forward(self, rotmat, betas, cam=None):
@@ -210,7 +215,7 @@ class Engine:
         kp2d = torch.empty(B, 44, 2, device=dev, dtype=f32) if cam is not None else None
         cam = cam.contiguous() if cam is not None else None
         with torch.cuda.device(self.device):
-            _cabi.check(self.lib.thmr_lbs_forward(self.h, _ptr(rotmat), _ptr(betas), _ptr(cam), B, _ptr(verts), _ptr(joints),
+            self._check(self.lib.thmr_lbs_forward(self.h, _ptr(rotmat), _ptr(betas), _ptr(cam), B, _ptr(verts), _ptr(joints),
                                                   _ptr(cam_t), _ptr(kp2d), _stream_ptr(self.device)), self.h)
         return verts, joints, cam_t, kp2d
 
@@ -223,7 +228,7 @@ class Engine:
         idx = torch.empty(B, 160, device=self.device, dtype=torch.int32)
         lat = torch.empty(B, 160, 256, device=self.device, dtype=torch.float32) if want_latent else None
         with torch.cuda.device(self.device):
-            _cabi.check(self.lib.thmr_encode_tokens(self.h, _ptr(pose6d), B, _ptr(idx), _ptr(lat), _stream_ptr(self.device)), self.h)
+            self._check(self.lib.thmr_encode_tokens(self.h, _ptr(pose6d), B, _ptr(idx), _ptr(lat), _stream_ptr(self.device)), self.h)
         return (idx, lat) if want_latent else idx
 
     def vq_decode(self, probs):
@@ -234,7 +239,7 @@ class Engine:
             raise ValueError(f"probs must be (B,160,2048), got {tuple(probs.shape)}")
         pose = torch.empty(B, 21, 6, device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
-            _cabi.check(self.lib.thmr_vq_decode(self.h, _ptr(probs), B, _ptr(pose), _stream_ptr(self.device)), self.h)
+            self._check(self.lib.thmr_vq_decode(self.h, _ptr(probs), B, _ptr(pose), _stream_ptr(self.device)), self.h)
         return pose
 
     def vq_argmin(self, x, want_dist=False):
@@ -243,7 +248,7 @@ class Engine:
         idx = torch.empty(rows, device=self.device, dtype=torch.int32)
         dist = torch.empty(rows, 2048, device=self.device, dtype=torch.float32) if want_dist else None
         with torch.cuda.device(self.device):
-            _cabi.check(self.lib.thmr_vq_argmin(self.h, _ptr(x), rows, _ptr(idx), _ptr(dist), _stream_ptr(self.device)), self.h)
+            self._check(self.lib.thmr_vq_argmin(self.h, _ptr(x), rows, _ptr(idx), _ptr(dist), _stream_ptr(self.device)), self.h)
         return (idx, dist) if want_dist else idx
 
     # ------------------------------------------------------------------ how the ViT GEMMs are multiplied
@@ -253,7 +258,7 @@ class Engine:
         """"f32" (default): exact-fp32 MFMA.  "split3": fp32 operands as three bf16 pieces on the bf16 matrix pipe (six products, fp32
         accumulate; fp32-grade, not bitwise fp32) for calls of at least 3 crops — see thmr_set_vit_gemm in the header."""
         with torch.cuda.device(self.device):
-            _cabi.check(self.lib.thmr_set_vit_gemm(self.h, self.VIT_GEMM[mode], _stream_ptr(self.device)), self.h)
+            self._check(self.lib.thmr_set_vit_gemm(self.h, self.VIT_GEMM[mode], _stream_ptr(self.device)), self.h)
 
     def vit_gemm(self):
         return {v: k for k, v in self.VIT_GEMM.items()}[self.lib.thmr_get_vit_gemm(self.h)]
@@ -264,11 +269,11 @@ class Engine:
         see the header)."""
         mode = {"gemm": 2, "fc1": 3}.get(on, 1 if on else 0)
         with torch.cuda.device(self.device):
-            _cabi.check(self.lib.thmr_prof_enable(self.h, mode), self.h)
+            self._check(self.lib.thmr_prof_enable(self.h, mode), self.h)
 
     def prof_collect(self, reset=True):
         arr = (_cabi.ProfEntry * len(_cabi.PROF_NAMES))()
         with torch.cuda.device(self.device):
-            _cabi.check(self.lib.thmr_prof_collect(self.h, arr, 1 if reset else 0), self.h)
+            self._check(self.lib.thmr_prof_collect(self.h, arr, 1 if reset else 0), self.h)
         return {n: dict(ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes, launches=arr[i].launches)
                 for i, n in enumerate(_cabi.PROF_NAMES)}

@@ -63,19 +63,71 @@ def regress_joints_gpu(J, verts):
     return out
 
 
+class _BatchMetrics(dict):
+    """What `Evaluator.__call__` returns: the reference's {'mode_mpjpe': (B,) array, ...} — filled from the device on first access
+    (eval.py:149 ignores the return value, so a batch normally never pays a device synchronisation for it)."""
+
+    def __init__(self, ev, lo, hi, keys):
+        dict.__init__(self, {k: None for k in keys})
+        self._ev, self._lo, self._hi = ev, lo, hi
+
+    def __getitem__(self, k):
+        if k not in self:
+            raise KeyError(k)
+        return getattr(self._ev, k)[self._lo:self._hi]
+
+    def values(self):
+        return [self[k] for k in self]
+
+    def items(self):
+        return [(k, self[k]) for k in self]
+
+
 class Evaluator:
+    """The per-sample metric arrays (`mode_mpjpe`, `mode_re`, `mode_pve`; `metrics` names them) live on the host as in the reference, but
+    they are FILLED lazily: `__call__` only enqueues the kernels and keeps the three (B,) device results; the copy to the host happens when
+    somebody looks — `log()`, `get_metrics_dict()`, reading a metric array, a returned batch dict — or after `max_pending` batches.  The
+    reference's loop (eval.py:144-149) therefore runs without a device synchronisation per batch (its own evaluator copies (B,) arrays
+    to the host every batch, pose_utils.py:139-143,246)."""
+
     def __init__(self, dataset_length, keypoint_list, pelvis_ind, metrics=("mode_mpjpe", "mode_re", "model_pve"),
-                 J_regressor_24_SMPL=None, dataset=""):
+                 J_regressor_24_SMPL=None, dataset="", max_pending=64):
         self.dataset_length = dataset_length
         self.keypoint_list = list(keypoint_list)
         self.pelvis_ind = pelvis_ind
         self.metrics = list(metrics)
         self.J_regressor_24_SMPL = J_regressor_24_SMPL
         self.dataset = dataset
-        for m in self.metrics:
-            setattr(self, m, np.zeros((dataset_length,)))
+        self._arrays = {m: np.zeros((dataset_length,)) for m in self.metrics}
+        self._pending = []                       # (first sample, stacked (3, B) device tensor)
+        self._max_pending = max(1, int(max_pending))
         self.counter = 0
         self.imgnames = []
+
+    def __getattr__(self, name):
+        # the metric arrays as attributes (`evaluator.mode_mpjpe`, `hasattr(evaluator, 'mode_pve')`), up to date when read
+        arrays = self.__dict__.get("_arrays")
+        if arrays is not None and name in arrays:
+            self._flush()
+            return arrays[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        arrays = self.__dict__.get("_arrays")
+        if arrays is not None and name in arrays:          # merge_evaluator (dist.py) replaces the arrays wholesale
+            self._flush()
+            arrays[name] = value
+        else:
+            object.__setattr__(self, name, value)
+
+    def _flush(self):
+        pending, self._pending = self._pending, []
+        for lo, dev3 in pending:
+            host = dev3.cpu().numpy()
+            n = host.shape[1]
+            for row, m in enumerate(("mode_mpjpe", "mode_re", "mode_pve")):
+                if m in self._arrays:
+                    self._arrays[m][lo:lo + n] = host[row]
 
     def log(self):
         if self.counter == 0:
@@ -95,7 +147,7 @@ class Evaluator:
 
     def __call__(self, output, batch):
         self.imgnames += list(batch.get("imgname", []))
-        want_pve = hasattr(self, "mode_pve")
+        want_pve = "mode_pve" in self._arrays
         if "EMDB" in self.dataset:                                  # pose_utils.py:209-222
             gt_v, pred_v = batch["vertices"], output["pred_vertices"]
             gt_j = regress_joints_gpu(self.J_regressor_24_SMPL, gt_v)
@@ -107,16 +159,9 @@ class Evaluator:
                                         self.pelvis_ind, 0, output["pred_vertices"] if want_pve else None,
                                         batch["vertices"] if want_pve else None)
         B = mp.shape[0]
-        host = torch.stack([mp, re, pve if pve is not None else torch.zeros_like(mp)], 0).cpu().numpy()
-        res = {}
-        if hasattr(self, "mode_mpjpe"):
-            self.mode_mpjpe[self.counter:self.counter + B] = host[0]
-            res["mode_mpjpe"] = host[0]
-        if hasattr(self, "mode_re"):
-            self.mode_re[self.counter:self.counter + B] = host[1]
-            res["mode_re"] = host[1]
-        if want_pve:
-            self.mode_pve[self.counter:self.counter + B] = host[2]
-            res["mode_pve"] = host[2]
+        self._pending.append((self.counter, torch.stack([mp, re, pve if pve is not None else torch.zeros_like(mp)], 0)))
+        res = _BatchMetrics(self, self.counter, self.counter + B, [m for m in ("mode_mpjpe", "mode_re", "mode_pve") if m in self._arrays])
         self.counter += B
+        if len(self._pending) >= self._max_pending:
+            self._flush()
         return res

@@ -15,6 +15,31 @@ VARIANT.update({f"{t}/k{k}": 100 * k + c for t, c in (("auto", 0), ("128x128", 7
 # (timing-only ablation kernels 31-53 exist only in builds with -DTHMR_GEMM_ABLATION, see gemm_f32.hip)
 
 
+_EXP = None      # None: the shipped library (or THMR_LIB=exp); True: the experiments build (variants that lost their A/B, knobs)
+
+
+class experiments_build:
+    """`with ops.experiments_build(): ...` — the wrappers below call the -DTHMR_EXPERIMENTS library inside the block (tests / scripts)."""
+
+    def __enter__(self):
+        global _EXP
+        self._old, _EXP = _EXP, True
+        return self
+
+    def __exit__(self, *a):
+        global _EXP
+        _EXP = self._old
+        return False
+
+
+def _L():
+    return _cabi.load(exp=_EXP)
+
+
+def _check(rc):
+    _cabi.check(rc, None, _L())
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -36,7 +61,7 @@ def gemm(a, w, bias=None, resid=None, epi="none", qscale=1.0, qcols=0, variant="
     N = w.shape[0]
     out = torch.empty(M, N, device=a.device, dtype=torch.float32)
     with torch.cuda.device(a.device):
-        _cabi.check(_cabi.load().thmr_op_gemm(_p(a), K, _p(w), _p(bias), _p(resid), _p(out), N, M, N, K, EPI[epi],
+        _check(_L().thmr_op_gemm(_p(a), K, _p(w), _p(bias), _p(resid), _p(out), N, M, N, K, EPI[epi],
                                              float(qscale), int(qcols), VARIANT[variant], _s(a)))
     return out
 
@@ -49,6 +74,16 @@ SPLIT3_VARIANT = {"auto": -1, "128x256/w8": 0, "128x256/w4": 1, "128x128/w4": 2,
                   "exp/reads-every-2nd": 3, "abl/no-copies": 31, "abl/no-barrier": 32, "abl/no-reads": 34, "abl/none": 37}
 
 
+# variants that exist only in the experiments build (measured slower or timing-only; csrc/gemm_split.hip, gemm_split_persist.hip): asking
+# for one of them routes THAT call to libtokenhmr_hip_exp.so
+SPLIT3_EXP_ONLY = {"128x256/w4", "256x256/w4", "ring", "ring/k2", "ring/k4", "persist/lds", "exp/reads-every-2nd", "abl/no-copies",
+                   "abl/no-barrier", "abl/no-reads", "abl/none"}
+
+
+def _L_for(exp_only):
+    return _cabi.load(exp=True) if exp_only else _L()
+
+
 def split3(x):
     """fp32 (R,K) -> the "split3" operand of gemm_split3: every element as three bf16 pieces h + m + l, laid out [R][K/8][3][8]
     (returned as an int16 tensor of shape (R, K/8, 3, 8); see csrc/gemm_split.hip).  K % 8 == 0."""
@@ -56,7 +91,7 @@ def split3(x):
     R, K = x.shape
     out = torch.empty(R, K // 8, 3, 8, device=x.device, dtype=torch.int16)
     with torch.cuda.device(x.device):
-        _cabi.check(_cabi.load().thmr_op_split3(_p(x), K, _p(out), K, R, K, _s(x)))
+        _check(_L().thmr_op_split3(_p(x), K, _p(out), K, R, K, _s(x)))
     return out
 
 
@@ -72,16 +107,17 @@ def gemm_split3(a_s, w_s, bias=None, resid=None, epi="none", qscale=1.0, qcols=0
     N = w_s.shape[0]
     if w_s.shape[1] * 8 != K:
         raise ValueError("K mismatch")
+    lib = _L_for(variant in SPLIT3_EXP_ONLY)
     if out_split:
         out = torch.empty(M, N // 8, 3, 8, device=a_s.device, dtype=torch.int16)
         with torch.cuda.device(a_s.device):
-            _cabi.check(_cabi.load().thmr_op_gemm_split3_out_split3(_p(a_s), K, _p(w_s), K, _p(bias), _p(out), N, M, N, K, EPI[epi],
-                                                                   float(qscale), int(qcols), SPLIT3_VARIANT[variant], _s(a_s)))
+            _cabi.check(lib.thmr_op_gemm_split3_out_split3(_p(a_s), K, _p(w_s), K, _p(bias), _p(out), N, M, N, K, EPI[epi],
+                                                                   float(qscale), int(qcols), SPLIT3_VARIANT[variant], _s(a_s)), None, lib)
         return out
     out = torch.empty(M, N, device=a_s.device, dtype=torch.float32)
     with torch.cuda.device(a_s.device):
-        _cabi.check(_cabi.load().thmr_op_gemm_split3(_p(a_s), K, _p(w_s), K, _p(bias), _p(resid), _p(out), N, M, N, K, EPI[epi],
-                                                    float(qscale), int(qcols), SPLIT3_VARIANT[variant], _s(a_s)))
+        _cabi.check(lib.thmr_op_gemm_split3(_p(a_s), K, _p(w_s), K, _p(bias), _p(resid), _p(out), N, M, N, K, EPI[epi],
+                                                    float(qscale), int(qcols), SPLIT3_VARIANT[variant], _s(a_s)), None, lib)
     return out
 
 
@@ -90,7 +126,7 @@ def layernorm(x, gamma, beta, eps, relu=False):
     rows, D = x.shape
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
-        _cabi.check(_cabi.load().thmr_op_layernorm(_p(x), _p(gamma), _p(beta), _p(y), rows, D, float(eps), int(relu), _s(x)))
+        _check(_L().thmr_op_layernorm(_p(x), _p(gamma), _p(beta), _p(y), rows, D, float(eps), int(relu), _s(x)))
     return y
 
 
@@ -104,9 +140,10 @@ def vit_attention(qkv, variant="auto"):
     out = torch.empty(B, 192, 1280, device=qkv.device, dtype=torch.float32)
     with torch.cuda.device(qkv.device):
         if variant == "auto":
-            _cabi.check(_cabi.load().thmr_op_vit_attention(_p(qkv), _p(out), B, _s(qkv)))
+            _check(_L().thmr_op_vit_attention(_p(qkv), _p(out), B, _s(qkv)))
         else:
-            _cabi.check(_cabi.load().thmr_op_vit_attention_variant(_p(qkv), _p(out), B, ATTN_VARIANT[variant], _s(qkv)))
+            lib = _L_for(variant == "q16x12")           # 12 waves of 16 queries: measured no faster, experiments build only
+            _cabi.check(lib.thmr_op_vit_attention_variant(_p(qkv), _p(out), B, ATTN_VARIANT[variant], _s(qkv)), None, lib)
     return out
 
 
@@ -116,7 +153,7 @@ def vit_attention_split3(qkv):
     B = qkv.shape[0]
     out = torch.empty(B * 192, 160, 3, 8, device=qkv.device, dtype=torch.int16)
     with torch.cuda.device(qkv.device):
-        _cabi.check(_cabi.load().thmr_op_vit_attention_split3(_p(qkv), _p(out), B, _s(qkv)))
+        _check(_L().thmr_op_vit_attention_split3(_p(qkv), _p(out), B, _s(qkv)))
     return out
 
 
@@ -126,7 +163,7 @@ def rot6d_to_rotmat(x):
     n = x2.shape[0]
     R = torch.empty(n, 3, 3, device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
-        _cabi.check(_cabi.load().thmr_op_rot6d(_p(x2), _p(R), n, _s(x)))
+        _check(_L().thmr_op_rot6d(_p(x2), _p(R), n, _s(x)))
     return R
 
 
@@ -137,5 +174,5 @@ def aa_to_rotmat(theta):
     n = x.shape[0]
     R = torch.empty(n, 3, 3, device=theta.device, dtype=torch.float32)
     with torch.cuda.device(theta.device):
-        _cabi.check(_cabi.load().thmr_op_aa_to_rotmat(_p(x), _p(R), n, _s(theta)))
+        _check(_L().thmr_op_aa_to_rotmat(_p(x), _p(R), n, _s(theta)))
     return R
