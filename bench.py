@@ -243,6 +243,147 @@ def lbs_at_b512(dev, smpl):
             "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "bytes": by}
 
 
+def pipeline_bench(eng, dev, B, steps, warmup, fwd_ms=None):
+    """The rows AROUND the path and the pipeline they exist for, measured end to end:
+
+        decoded uint8 1080p frames on the HOST (pinned)  --H2D-->  thmr_cropper_run (blur + warp + normalise, csrc/crop.hip)
+            -->  thmr_forward  -->  thmr_eval_pose (pelvis alignment, MPJPE, Procrustes, PVE: csrc/eval.hip) against resident GT
+
+    = what tokenhmr/eval.py:124,144-149 does per batch with a 4-worker cv2 DataLoader, recursive_to, model(batch), evaluator(out, batch).
+    Two streams: the copies and crops of batch i + 1 run on a side stream while batch i is in forward / eval on the launch stream
+    (double-buffered frames and crops), and nothing synchronises with the host inside the loop (the evaluator accumulates on the device).
+    8 frames x B / 8 people per batch; boxes of 250-900 px (the larger ones take the anti-alias blur of vitdet_dataset.py:62-68)."""
+    import numpy as np
+    import torch
+    from tokenhmr_amd.preprocess import Cropper, gen_trans_from_patch_cv, expand_to_aspect_ratio
+    from tokenhmr_amd.evaluator import eval_pose_gpu
+    F = 8 if B % 8 == 0 else (4 if B % 4 == 0 else 1)
+    P, H, W = B // F, 1080, 1920
+    rng = np.random.default_rng(11)
+    host_frames = [torch.from_numpy(rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8)).pin_memory() for _ in range(2)]
+    host_gtj = [torch.randn(B, 44, 4).pin_memory() for _ in range(2)]
+    host_gtv = [torch.randn(B, 6890, 3).mul_(0.3).pin_memory() for _ in range(2)]
+    plans, region_bytes = [], 0
+    for f in range(F):
+        hgt = rng.uniform(250, 900, P)
+        cx, cy = rng.uniform(300, W - 300, P), rng.uniform(300, H - 300, P)
+        boxes = np.stack([cx - hgt * 0.2, cy - hgt / 2, cx + hgt * 0.2, cy + hgt / 2], 1).astype(np.float32)
+        center, scale = (boxes[:, 2:4] + boxes[:, 0:2]) / 2.0, (boxes[:, 2:4] - boxes[:, 0:2]) / 200.0
+        tr, sg = [], []
+        for i in range(P):
+            bs = expand_to_aspect_ratio(scale[i] * 200, target_aspect_ratio=[192, 256]).max()
+            fct = (float(bs) / 256) / 2.0
+            sg.append((fct - 1) / 2 if fct > 1.1 else 0.0)
+            tr.append(gen_trans_from_patch_cv(center[i][0], center[i][1], bs, bs, 256, 256, 1.0, 0))
+            region_bytes += int(min(float(bs), H) * min(float(bs), W)) * 3
+        plans.append((np.stack(tr), sg))
+    crop_stream = torch.cuda.Stream(dev)
+    main = torch.cuda.current_stream(dev)
+    cropper = Cropper(dev)
+    dfr = [torch.empty(F, H, W, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+    dgj = [torch.empty(B, 44, 4, device=dev) for _ in range(2)]
+    dgv = [torch.empty(B, 6890, 3, device=dev) for _ in range(2)]
+    img = [torch.empty(B, 3, 256, 256, device=dev) for _ in range(2)]
+    outs = eng._alloc_outputs(B, taps=False, want_probs=True)
+    kp_list, pelvis = list(range(25, 38)) + [43], 39                 # 3DPW: datasets_eval.yaml:12, experiment/default.yaml:15
+    acc = torch.zeros(3, device=dev)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+    h2d_ev = []
+
+    def stage_in(i, timed=False):
+        """side stream: H2D of batch i's frames + GT, then its crops into img[i % 2]"""
+        k = i % 2
+        with torch.cuda.stream(crop_stream):
+            if i >= 2:
+                crop_stream.wait_event(consumed[k])                  # batch i - 2 is done with these buffers
+            e0 = e1 = None
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(crop_stream)
+            dfr[k].copy_(host_frames[k], non_blocking=True)
+            dgj[k].copy_(host_gtj[k], non_blocking=True)
+            dgv[k].copy_(host_gtv[k], non_blocking=True)
+            if timed:
+                e1.record(crop_stream)
+                h2d_ev.append((e0, e1))
+            for f in range(F):
+                cropper.warp(dfr[k][f], plans[f][0], plans[f][1], truncate=4.0, out=img[k][f * P:(f + 1) * P])
+            ready[k].record(crop_stream)
+
+    def run(n, timed=False):
+        stage_in(0, timed)
+        for i in range(n):
+            k = i % 2
+            if i + 1 < n:
+                stage_in(i + 1, timed)
+            main.wait_event(ready[k])
+            o = eng.forward(img[k], outputs=outs)
+            mp, re, pve = eval_pose_gpu(o["pred_keypoints_3d"], dgj[k], kp_list, pelvis, 0, o["pred_vertices"], dgv[k])
+            acc.add_(torch.stack([mp.sum(), re.sum(), pve.sum()]))
+            consumed[k].record(main)
+
+    run(max(2, warmup))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps, timed=True)
+    torch.cuda.synchronize()
+    pipe_ms = (time.perf_counter() - t0) / steps * 1e3
+    h2d_ms = sorted(e0.elapsed_time(e1) for e0, e1 in h2d_ev)
+    # forward only, same engine, crops resident (the bench's own timed region when it is handed over)
+    if fwd_ms is None:
+        for _ in range(2):
+            eng.forward(img[0], outputs=outs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.forward(img[0], outputs=outs)
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - t0) / steps * 1e3
+
+    def alone(fn, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def crops():
+        for f in range(F):
+            cropper.warp(dfr[0][f], plans[f][0], plans[f][1], truncate=4.0, out=img[0][f * P:(f + 1) * P])
+    o = eng.forward(img[0], outputs=outs)
+    crop_ms = alone(crops)
+    eval_ms = alone(lambda: eval_pose_gpu(o["pred_keypoints_3d"], dgj[0], kp_list, pelvis, 0, o["pred_vertices"], dgv[0]))
+    crop_bytes = B * 3 * 256 * 256 * 4 + region_bytes               # crops written + the frame regions under the boxes read once
+    eval_bytes = 2 * B * 6890 * 3 * 4 + 2 * B * 44 * 4 * 4
+    h2d_bytes = host_frames[0].numel() + host_gtj[0].numel() * 4 + host_gtv[0].numel() * 4
+    res = {"what": ("uint8 1080p frames on the host -> H2D + thmr_cropper_run on a side stream -> thmr_forward -> thmr_eval_pose, double-buffered, "
+                    "no host synchronisation inside the loop (untimed extra; eval.py:124,144-149)"),
+           "frames_per_batch": F, "people_per_frame": P, "steps": steps,
+           "crops_per_s": round(B / (pipe_ms * 1e-3), 2), "ms_per_batch": round(pipe_ms, 3),
+           "forward_only_ms_per_batch": round(fwd_ms, 3), "vs_forward_only": round(fwd_ms / pipe_ms, 4),
+           "h2d": {"ms_per_batch_median": round(h2d_ms[len(h2d_ms) // 2], 3), "bytes": int(h2d_bytes),
+                   "GB_per_s": round(h2d_bytes / (h2d_ms[len(h2d_ms) // 2] * 1e-3) / 1e9, 1), "overlapped": "side stream, under the previous batch"},
+           "crop_kernels": {"ms_per_batch_alone": round(crop_ms, 3), "bytes": int(crop_bytes), "GB_per_s": round(crop_bytes / (crop_ms * 1e-3) / 1e9, 1),
+                            "frac_of_hbm_peak": round(crop_bytes / (crop_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launches": F},
+           "eval_kernels": {"ms_per_batch_alone": round(eval_ms, 4), "bytes": int(eval_bytes), "GB_per_s": round(eval_bytes / (eval_ms * 1e-3) / 1e9, 1),
+                            "frac_of_hbm_peak": round(eval_bytes / (eval_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+           "metrics_accumulated_on_device": [round(float(v), 3) for v in (acc / max(1, (max(2, warmup) + steps) * B)).tolist()]}
+    try:
+        pose = torch.randn(B, 21, 6, device=dev)
+        enc_ms = alone(lambda: eng.encode_tokens(pose))
+        res["encode_tokens"] = {"ms_per_batch_alone": round(enc_ms, 3), "poses_per_s": round(B / (enc_ms * 1e-3), 1),
+                                "what": "thmr_encode_tokens: PoseSPEncoderV1 + argmin-L2 quantiser (vanilla_pose_vqvae.py:334-342), B poses"}
+    except Exception as ex:      # encoder half not loaded
+        res["encode_tokens"] = {"skipped": f"{type(ex).__name__}: {ex}"[:120]}
+    cropper.close()
+    return res
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.self_launch):
@@ -327,6 +468,7 @@ def main():
         # rank 0 "reads the checkpoint" (synthetic: no network for real weights) ...
         if not cpu_dry:
             sd, tok = W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0)
+            tok = dict(tok, **W.make_synthetic_encoder(cfg, 0))       # the tokenizer's encoder half (N4): lets the pipeline extra time thmr_encode_tokens
         smpl = make_synthetic_smpl(cfg, 0)
         eng.load_state(sd, tok)
         eng.load_smpl(smpl)
@@ -561,6 +703,12 @@ def main():
                 facade = {"ms_per_call": round(f_ms, 3), "crops_per_s": round(B / (f_ms * 1e-3), 2), "calls": n_f,
                           "vs_engine_forward": round((elapsed / a.steps * 1e3) / f_ms, 4),
                           "what": "TokenHMR facade model({'img': ...}) -> dict, outputs allocated per call (untimed extra)"}
+        pipeline = None
+        if world == 1 and not a.no_extras and not cpu_dry and a.workload == "full":
+            try:
+                pipeline = {("split3" if split_mode else "f32"): pipeline_bench(eng, dev, B, max(5, min(a.steps, 20)), 2, elapsed / a.steps * 1e3)}
+            except Exception as ex:      # an extra must never cost the headline line
+                pipeline = {"error": f"{type(ex).__name__}: {ex}"}
         split3 = None
         if world == 1 and not a.no_extras and not cpu_dry and B >= 3 and not split_mode:
             # SECOND measurement, not `value`: the same K steps with the ViT GEMMs in the engine's opt-in "split3" mode — fp32 operands
@@ -577,6 +725,11 @@ def main():
                 sync()
                 s_ms = (time.perf_counter() - t_s) / a.steps * 1e3
                 s_par = parity_vs_golden(last["out"], B, cfg, a.workload) if "out" in last else None
+                if isinstance(pipeline, dict) and "error" not in pipeline and a.workload == "full":
+                    try:
+                        pipeline["split3"] = pipeline_bench(eng, dev, B, max(5, min(a.steps, 20)), 2, s_ms)
+                    except Exception as ex:
+                        pipeline["split3"] = {"error": f"{type(ex).__name__}: {ex}"}
                 eng.prof_enable(True)
                 step()
                 sync()
@@ -628,6 +781,8 @@ def main():
             line["facade"] = facade
         if split3:
             line["split3_mode"] = split3
+        if pipeline:
+            line["pipeline"] = pipeline
         if step_ms:
             # per-step HIP-event durations on the launch stream (median of >= 20 timed iterations);
             # `value` / `ms_per_step` stay the barrier-bracketed wall-clock numbers the driver cross-checks

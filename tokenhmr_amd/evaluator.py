@@ -17,6 +17,9 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+_KP_CACHE = {}
+
+
 def eval_pose_gpu(pred_joints, gt_joints, keypoint_list, pelvis_ind, pelvis_mode=0, pred_vertices=None, gt_vertices=None):
     """Returns (mpjpe_mm, re_mm, pve_mm or None) as CUDA float32 tensors of shape (B,)."""
     dev = pred_joints.device
@@ -33,7 +36,9 @@ def eval_pose_gpu(pred_joints, gt_joints, keypoint_list, pelvis_ind, pelvis_mode
         raise IndexError(f"keypoint_list indices must lie in [0, {nj}) for {nj}-joint inputs, got min {min(kpl, default=None)} max {max(kpl, default=None)}")
     if not 0 <= int(pelvis_ind) < nj:
         raise IndexError(f"pelvis_ind {pelvis_ind} outside [0, {nj})")
-    kp = torch.as_tensor(kpl, dtype=torch.int32, device=dev)
+    kp = _KP_CACHE.get((tuple(kpl), dev))               # the index list lives on the device once: no H2D copy per batch
+    if kp is None:
+        kp = _KP_CACHE[(tuple(kpl), dev)] = torch.as_tensor(kpl, dtype=torch.int32, device=dev)
     mp = torch.empty(B, device=dev, dtype=torch.float32)
     re = torch.empty(B, device=dev, dtype=torch.float32)
     pelv = torch.empty(B, 6, device=dev, dtype=torch.float32)
