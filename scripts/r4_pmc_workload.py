@@ -1,0 +1,56 @@
+"""Workload for the round-4 rocprofv3 --pmc passes (separate passes, --kernel-trace only): the kernels of a 64-crop ViT block in the split3
+mode as the engine runs them now — persistent split3 GEMMs on the qkv / fc1 (split3 output, swapped roles) / fc2 shapes, LayerNorm and
+attention with split3 output — the exact-fp32 fc1 GEMM (for `roofline.traffic` of the headline), and ONE round of the per-tile split3 kernel
+on 128 and on 256 tiles (half the CUs idle vs none: GRBM_GUI_ACTIVE / duration = the shader clock in both cases).  6 launches each."""
+import math, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tokenhmr_amd import ops
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+M = 64 * 192
+
+
+def mk(N, K):
+    a = torch.randn(M, K, generator=g); a[:, ::97] *= 40.0
+    return a.to(dev), (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev), torch.randn(N, generator=g).to(dev)
+
+
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+if which in ("all", "gemm"):
+    a, w, b = mk(3840, 1280)
+    sa, sw = ops.split3(a), ops.split3(w)
+    for _ in range(6):
+        ops.gemm_split3(sa, sw, b, epi="bias_qscale", qscale=80 ** -0.5, qcols=1280, variant="persist")
+    a, w, b = mk(5120, 1280)
+    sa, sw = ops.split3(a), ops.split3(w)
+    for _ in range(6):
+        ops.gemm_split3(sa, sw, b, epi="bias_gelu", variant="persist/swap", out_split=True)
+    for _ in range(6):
+        ops.gemm(a, w, b, epi="bias_gelu")                     # the headline's fc1: exact-fp32 MFMA
+    a, w, b = mk(1280, 5120)
+    r = torch.randn(M, 1280, generator=g).to(dev)
+    sa, sw = ops.split3(a), ops.split3(w)
+    for _ in range(6):
+        ops.gemm_split3(sa, sw, b, r, epi="bias_resid", variant="persist")
+    torch.cuda.synchronize()
+if which in ("all", "rows"):
+    x = torch.randn(M, 1280, generator=g).to(dev)
+    gam, bet = torch.randn(1280, generator=g).to(dev), torch.randn(1280, generator=g).to(dev)
+    from tokenhmr_amd import _cabi
+    import ctypes as C
+    y = torch.empty(M, 160, 3, 8, dtype=torch.int16, device=dev)
+    qkv = torch.randn(64, 192, 3840, generator=g).to(dev)
+    for _ in range(6):
+        ops.layernorm(x, gam, bet, 1e-6)
+        ops.vit_attention(qkv)
+        ops.vit_attention_split3(qkv)
+    torch.cuda.synchronize()
+if which in ("all", "half"):
+    for tiles_m in (8, 16):
+        ah = torch.randn(tiles_m * 128, 1280, generator=g).to(dev)
+        wh = (torch.randn(4096, 1280, generator=g) / 36).to(dev)
+        sah, swh = ops.split3(ah), ops.split3(wh)
+        for _ in range(6):
+            ops.gemm_split3(sah, swh, variant="128x256/w8")
+    torch.cuda.synchronize()
