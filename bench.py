@@ -649,10 +649,18 @@ def main():
             # HBM traffic of that kernel from PMC counters (separate rocprofv3 --pmc passes, committed under profiles/;
             # FETCH_SIZE doubled per the gfx950 correction) — cannot be collected live inside this process, so it is a
             # RECORDED number and labelled as such
-            for pmc_file in ("r2x_pmc_gemm.json", "r2_pmc_gemm.json", "r1_pmc_gemm.json"):
+            for pmc_file in ("r4p_pmc_split3_persistent.json", "r2x_pmc_gemm.json", "r2_pmc_gemm.json", "r1_pmc_gemm.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
-                        pmc = json.load(f).get(dom.replace("gemm_", ""))
+                        pj = json.load(f)
+                    if pmc_file.startswith("r4p"):
+                        # round 4: one --pmc session over the round's kernels (scripts/gpu_r4p.sh); its `gemm_f32_kernel` entry is the fc1
+                        # shape of the exact-fp32 kernel (the only shape that workload runs through it)
+                        pmc = pj.get("gemm_f32_kernel") if dom == "gemm_fc1" else None
+                        if pmc:
+                            pmc = dict(pmc, algorithmic_bytes=4.0 * (12288 * 1280 + 5120 * 1280 + 12288 * 5120))
+                    else:
+                        pmc = pj.get(dom.replace("gemm_", ""))
                 except (OSError, ValueError):
                     continue
                 if pmc and a.batch == 64 and not split_mode:

@@ -189,48 +189,69 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& a, float acc, flo
 }
 
 // ---- "split3": an fp32 value as three bf16 pieces h + m + l (gemm_split.hip) ----
-// round-to-nearest-even bf16 of x (NaN stays NaN), as the 16-bit pattern.  Integer arithmetic on purpose: v_cvt_pk_bf16_f32 (two
-// conversions per instruction, 9 instead of ~36 VALU per pair of values for the three pieces) was tried — the producers are bound by their
-// stores, not by this (82.5 vs 81.7 ms per 64-crop call, profiles/r3z_hw_bf16_cvt_ab.log), and it is not bit-identical to the numpy
-// restatement the tests compare with on every input class
-__device__ __forceinline__ uint32_t bf16_rne(float x) {
+// Round-to-nearest-even bf16 of x (any NaN -> 0x7fc0), integer arithmetic on purpose: v_cvt_pk_bf16_f32 is not bit-identical to the numpy
+// restatement the tests compare with on every input class (NaN payloads, and fp32 denormals depend on the wave's denormal mode).
+// Round 4: the pieces are kept in the HIGH half of a register — (u + 0x7fff + lsb) & 0xffff0000 IS the fp32 value of the rounded piece,
+// so the exact residual needs no shift back, one NaN test serves the three pieces, and two values pack with ONE v_perm_b32: ~15 VALU
+// per value instead of ~24.  In the persistent fc1 kernel the epilogue's VALU is what is left exposed per tile (PMC: 64.6 M vector
+// instructions per fc1 launch against 26.5 M for qkv, profiles/r4p_pmc_split3_persistent.json), at the ~1.5 GHz the part grants it.
+__device__ __forceinline__ uint32_t bf16_rne(float x) {        // the 16-bit pattern (low half); kept for single values
     const uint32_t u = __float_as_uint(x);
     if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
-__device__ __forceinline__ void split3_of(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
-    h = bf16_rne(x);
-    const float r1 = x - __uint_as_float(h << 16);            // exact: the residual of a rounding fits the format
-    m = bf16_rne(r1);
-    const float r2 = r1 - __uint_as_float(m << 16);           // exact
-    l = bf16_rne(r2);
+// the three pieces of x, each in the HIGH half of its word (low half zero); bit-identical to bf16_rne applied to x, x - h, x - h - m
+__device__ __forceinline__ void split3_hi(float x, uint32_t& H, uint32_t& M, uint32_t& L) {
+    const uint32_t u = __float_as_uint(x);
+    const bool nan = (u & 0x7fffffffu) > 0x7f800000u;
+    H = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(H);                  // exact: the residual of a rounding fits the format
+    const uint32_t u1 = __float_as_uint(r1);
+    M = (u1 + 0x7fffu + ((u1 >> 16) & 1u)) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(M);                 // exact
+    const uint32_t u2 = __float_as_uint(r2);
+    L = (u2 + 0x7fffu + ((u2 >> 16) & 1u)) & 0xffff0000u;
+    if (nan) H = M = L = 0x7fc00000u;                         // what bf16_rne gives for x and for the (NaN) residuals
+}
+__device__ __forceinline__ void split3_of(float x, uint32_t& h, uint32_t& m, uint32_t& l) {      // 16-bit patterns in the low half
+    uint32_t H, M, L;
+    split3_hi(x, H, M, L);
+    h = H >> 16; m = M >> 16; l = L >> 16;
+}
+// two values -> three words of the operand format: piece(x0) in the low half, piece(x1) in the high half (v_perm_b32: bytes 2, 3 of each)
+__device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& H, uint32_t& M, uint32_t& L) {
+    uint32_t h0, m0, l0, h1, m1, l1;
+    split3_hi(x0, h0, m0, l0);
+    split3_hi(x1, h1, m1, l1);
+    H = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+    M = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    L = __builtin_amdgcn_perm(l1, l0, 0x07060302u);
 }
 // 4 consecutive columns c ... c + 3 (c % 4 == 0) of one row of a split3 operand [rows][D/8][3][8]: the 8-byte half (c & 4) of the three
 // chunks of k-group c / 8.  `row` points at the row's first byte.
 __device__ __forceinline__ void store_split3_quad(char* row, int c, f32x4 v) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    uint32_t h[4], m[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) split3_of(v[e], h[e], m[e], l[e]);
+    uint32_t H[2], M[2], L[2];
+    split3_pair(v[0], v[1], H[0], M[0], L[0]);
+    split3_pair(v[2], v[3], H[1], M[1], L[1]);
     char* o = row + (c >> 3) * 48 + (c & 4) * 2;
-    *reinterpret_cast<u32x2*>(o) = u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-    *reinterpret_cast<u32x2*>(o + 16) = u32x2{m[0] | (m[1] << 16), m[2] | (m[3] << 16)};
-    *reinterpret_cast<u32x2*>(o + 32) = u32x2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+    *reinterpret_cast<u32x2*>(o) = u32x2{H[0], H[1]};
+    *reinterpret_cast<u32x2*>(o + 16) = u32x2{M[0], M[1]};
+    *reinterpret_cast<u32x2*>(o + 32) = u32x2{L[0], L[1]};
 }
 
 // 8 consecutive columns c ... c + 7 (c % 8 == 0) of one row: the three whole 16-byte chunks of k-group c / 8 (48 contiguous bytes)
 __device__ __forceinline__ void store_split3_oct(char* row, int c, f32x4 lo, f32x4 hi) {
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    uint32_t h[8], m[8], l[8];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        split3_of(lo[e], h[e], m[e], l[e]);
-        split3_of(hi[e], h[4 + e], m[4 + e], l[4 + e]);
-    }
+    uint32_t H[4], M[4], L[4];
+    split3_pair(lo[0], lo[1], H[0], M[0], L[0]);
+    split3_pair(lo[2], lo[3], H[1], M[1], L[1]);
+    split3_pair(hi[0], hi[1], H[2], M[2], L[2]);
+    split3_pair(hi[2], hi[3], H[3], M[3], L[3]);
     u32x4_t* o = reinterpret_cast<u32x4_t*>(row + (c >> 3) * 48);
-    o[0] = u32x4_t{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-    o[1] = u32x4_t{m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16)};
-    o[2] = u32x4_t{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    o[0] = u32x4_t{H[0], H[1], H[2], H[3]};
+    o[1] = u32x4_t{M[0], M[1], M[2], M[3]};
+    o[2] = u32x4_t{L[0], L[1], L[2], L[3]};
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

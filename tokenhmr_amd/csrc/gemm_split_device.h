@@ -62,14 +62,14 @@ __device__ __forceinline__ void store_tile_split3(const GemmArgs& a, f32x16 (&ac
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = gemm_epilogue<EPI>(a, v[u], bias[u], min(m, a.M - 1), min(n + u, a.N - 1));
         }
-        uint32_t h[8], mm[8], l[8];
+        uint32_t H[4], M[4], L[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) split3_of(v[u], h[u], mm[u], l[u]);
+        for (int u = 0; u < 4; ++u) split3_pair(v[2 * u], v[2 * u + 1], H[u], M[u], L[u]);
         if (m < a.M && n < a.N) {
             u32x4* o = reinterpret_cast<u32x4*>(obase + (int64_t)m * a.ldcs * 6);
-            o[0] = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-            o[1] = u32x4{mm[0] | (mm[1] << 16), mm[2] | (mm[3] << 16), mm[4] | (mm[5] << 16), mm[6] | (mm[7] << 16)};
-            o[2] = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+            o[0] = u32x4{H[0], H[1], H[2], H[3]};
+            o[1] = u32x4{M[0], M[1], M[2], M[3]};
+            o[2] = u32x4{L[0], L[1], L[2], L[3]};
         }
     }
 }

@@ -94,13 +94,13 @@ __device__ __forceinline__ void store_tile_split3_swapped(const GemmArgs& a, f32
 #pragma unroll
                     for (int u = 0; u < 8; ++u) v[u] = gemm_epilogue<EPI>(a, v[u], bias[u], m, n + u);
                 }
-                uint32_t h[8], mm[8], l[8];
+                uint32_t H[4], M[4], L[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) split3_of(v[u], h[u], mm[u], l[u]);
+                for (int u = 0; u < 4; ++u) split3_pair(v[2 * u], v[2 * u + 1], H[u], M[u], L[u]);
                 u32x4* o = reinterpret_cast<u32x4*>(orow + (int64_t)(n >> 3) * 48);
-                o[0] = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-                o[1] = u32x4{mm[0] | (mm[1] << 16), mm[2] | (mm[3] << 16), mm[4] | (mm[5] << 16), mm[6] | (mm[7] << 16)};
-                o[2] = u32x4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+                o[0] = u32x4{H[0], H[1], H[2], H[3]};
+                o[1] = u32x4{M[0], M[1], M[2], M[3]};
+                o[2] = u32x4{L[0], L[1], L[2], L[3]};
             }
         }
     }
