@@ -78,6 +78,19 @@ def main():
                     continue
                 t = timed(lambda: ops.gemm_split3(sa, sw, db, epi=epi, variant=v, out_split=True), args.iters)
                 row["split3-out " + v] = {"us": round(t * 1e6, 1), "f32_equiv_tflops": round(flop / t * 1e-12, 1), "vs_f32_mfma": round(t32 / t, 3)}
+            for v in ("128x256/w8", "persist/swap"):      # ... in the row-blocked form (round 4: whole-line stores from the swapped-role epilogue)
+                if v != "128x256/w8" and not persist_ok:
+                    continue
+                t = timed(lambda: ops.gemm_split3(sa, sw, db, epi=epi, variant=v, out_split=True, out_blocked=True), args.iters)
+                row["split3-out row-blocked " + v] = {"us": round(t * 1e6, 1), "f32_equiv_tflops": round(flop / t * 1e-12, 1), "vs_f32_mfma": round(t32 / t, 3)}
+        if name == "fc2":        # ... and read by fc2 as a row-blocked A
+            sab = ops.split3_block(sa)
+            for v in ("128x256/w8", "persist"):
+                if v == "persist" and not persist_ok:
+                    continue
+                t = timed(lambda: ops.gemm_split3(sab, sw, db, res, epi=epi, variant=v, a_blocked_rows=M), args.iters)
+                row["split3 row-blocked A " + v] = {"us": round(t * 1e6, 1), "f32_equiv_tflops": round(flop / t * 1e-12, 1), "vs_f32_mfma": round(t32 / t, 3)}
+            del sab
         if not args.no_error:
             c64 = da.double() @ dw.double().t()
             bound = da.double().abs() @ dw.double().abs().t()

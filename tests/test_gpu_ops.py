@@ -317,6 +317,49 @@ def test_gemm_split3_persistent(built_lib, cuda_dev, shape):
     assert torch.equal(ops.gemm_split3(sa, sw, variant="persist"), base)
 
 
+@pytest.mark.parametrize("shape", [(384, 512, 256), (200, 512, 96), (777, 1280, 1280), (2048, 4096, 320), (12288, 1280, 5120)])
+def test_gemm_split3_row_blocked_operand(built_lib, cuda_dev, shape):
+    """The row-blocked split3 operand ([R/32][K/8][3][32][8]: what the engine's fc1 hands fc2) — written by both split3-output epilogues
+    (LDS transposition of the per-tile kernel, swapped roles of the persistent one) and read as A by the per-tile kernel (both tiles,
+    split-K) and the persistent kernel: the same bits as the row-major form, ragged M included."""
+    import torch
+    from tokenhmr_amd import ops
+    M, N, K = shape
+    a, w, b = _rand(M, K, seed=31), _rand(N, K, seed=32, scale=1 / math.sqrt(K)), _rand(N, seed=33)
+    a[:, ::5] *= 20.0
+    da, dw, db = a.to(cuda_dev), w.to(cuda_dev), b.to(cuda_dev)
+    dr = _rand(M, N, seed=34).to(cuda_dev)
+    sa, sw = ops.split3(da), ops.split3(dw)
+    sab = ops.split3_block(sa)
+    assert torch.equal(ops.split3_unblock(sab, M), sa)
+    persist = M % 128 == 0 and N % 256 == 0 and (M // 128) * (N // 256) >= 256 and torch.cuda.get_device_properties(cuda_dev).multi_processor_count == 256
+    # A in the blocked form
+    for epi in ("none", "bias_resid"):
+        bb, rr = (None, None) if epi == "none" else (db, dr)
+        want = ops.gemm_split3(sa, sw, bb, rr, epi=epi, variant="128x256/w8")
+        for v in ("128x256/w8", "128x128/w4") + (("persist",) if persist else ()):
+            got = ops.gemm_split3(sab, sw, bb, rr, epi=epi, variant=v, a_blocked_rows=M)
+            assert torch.equal(got, want), (v, epi, int((got != want).sum()))
+    if K % 64 == 0:
+        want = ops.gemm_split3(sa, sw, db, dr, epi="bias_resid", variant="auto/k2")
+        assert torch.equal(ops.gemm_split3(sab, sw, db, dr, epi="bias_resid", variant="auto/k2", a_blocked_rows=M), want)
+    # the result in the blocked form
+    if N % 8 == 0:
+        for epi in ("none", "bias_gelu"):
+            bb = None if epi == "none" else db
+            want = ops.gemm_split3(sa, sw, bb, epi=epi, variant="128x256/w8", out_split=True)
+            for v in ("128x256/w8", "128x128/w4") + (("persist/swap",) if persist else ()):
+                got = ops.gemm_split3(sa, sw, bb, epi=epi, variant=v, out_split=True, out_blocked=True)
+                assert torch.equal(ops.split3_unblock(got, M), want), (v, epi)
+    # and chained as the engine does: blocked out of one product, blocked A of the next
+    if N % 32 == 0 and N <= 4096:
+        w2 = _rand(256, N, seed=35, scale=1 / math.sqrt(N)).to(cuda_dev)
+        s2 = ops.split3(w2)
+        hid_b = ops.gemm_split3(sa, sw, db, epi="bias_gelu", variant="128x256/w8", out_split=True, out_blocked=True)
+        hid = ops.gemm_split3(sa, sw, db, epi="bias_gelu", variant="128x256/w8", out_split=True)
+        assert torch.equal(ops.gemm_split3(hid_b, s2, variant="128x256/w8", a_blocked_rows=M), ops.gemm_split3(hid, s2, variant="128x256/w8"))
+
+
 def test_gemm_split3_persistent_rejects(built_lib, cuda_dev):
     from tokenhmr_amd import ops, _cabi
     sa, sw = ops.split3(_rand(2048, 64, seed=1).to(cuda_dev)), ops.split3(_rand(3840, 64, seed=2).to(cuda_dev))

@@ -62,7 +62,22 @@ struct GemmArgs {
     // (row stride 6 * ldcs bytes; N % 8 == 0) INSTEAD of fp32 C — the next GEMM's A operand without a conversion pass
     void* c_split;
     int64_t ldcs;
+    // split3 GEMM only: the ROW-BLOCKED form of a split3 operand, [rows / 32][K / 8][3][32][8] bf16 — the three 16-byte chunks of a k-group
+    // as 32-row panels of 512 contiguous bytes: chunk (r, kg, piece) at (r / 32) K 192 + (kg 3 + piece) 512 + (r % 32) 16 bytes.
+    //   a_blk:  A is in this form (lda = its K in fp32-equivalents; rows padded to a multiple of 32).  A K tile of a 32-row block is 6 KB
+    //           contiguous in memory AND in the LDS image, so the LDS-DMA copies are linear on both sides and the fragment reads
+    //           conflict-free without a swizzle.
+    //   cs_blk: c_split is written in this form.  The swapped-role epilogue of the persistent kernel holds one output ROW per lane: in the
+    //           row-major form its 16-byte stores hit 64 different lines per instruction (1536 line visits per wave tile against 128 for an
+    //           fp32 tile: 7.5 of the 9.9 us fc1's epilogue costs per tile, profiles/r4e_split3_gemm_b64.jsonl); here 32 lanes write 512
+    //           contiguous bytes.  Used for the one operand that only GEMM kernels touch: fc1's GELU output = fc2's A (vit.py:84-87).
+    int a_blk, cs_blk;
 };
+
+// byte offset of chunk (row m, k-group n8, piece pc) of a split3 operand with row length ld (fp32-equivalents), row-major or row-blocked
+__device__ __forceinline__ int64_t split3_chunk_off(int64_t ld, int m, int n8, int pc, bool blk) {
+    return blk ? (int64_t)(m >> 5) * ld * 192 + (int64_t)(n8 * 3 + pc) * 512 + (m & 31) * 16 : (int64_t)m * ld * 6 + (int64_t)n8 * 48 + pc * 16;
+}
 
 // Branch-free fp32 erf, < 1.5 ulp over the whole line (tests/test_gpu_ops.py::test_gelu_epilogue_ulp): two minimax
 // pieces evaluated for every lane and selected, so the GEMM epilogue has no divergent paths.  |x| <= 0.921875 uses an odd

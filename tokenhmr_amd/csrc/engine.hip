@@ -512,10 +512,20 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         // write their results directly as three bf16 pieces (hs, bs): no conversion pass, no fp32 copy of those activations.
         char* hs = e->split_act;                                    // [M][1280] split3: LayerNorm / attention output
         char* bs = e->split_act + (size_t)M * DIM * 6;              // [M][5120] split3: GELU output
-        auto gemm_s = [&](int cls, const char* A, int K, const char* Wt, const float* bias, const float* resid, float* C, int N, int epi) -> int {
+        // fc1's output = fc2's A in the ROW-BLOCKED form (common.h GemmArgs::a_blk) when both run the persistent kernel — the swapped-role
+        // epilogue then writes 512 contiguous bytes per 32 lanes instead of 64 different lines per instruction (fc1 25.1 -> 23.7 ms per 64-crop
+        // step, profiles/r4f_engine_b64_row_blocked.log).  The per-tile kernels (fewer than 32 crops, odd batches) measured SLOWER with the
+        // blocked form on both sides (profiles/r4f_split3_gemm_b64_row_blocked.jsonl) and keep the row-major one.  Same values either way.
+        int bs_blk = 0;
+        {
+            GemmArgs t1 = mk(nullptr, DIM, nullptr, DIM, nullptr, nullptr, 0, nullptr, 0, M, MLP, DIM), t2 = mk(nullptr, MLP, nullptr, MLP, nullptr, nullptr, 0, nullptr, 0, M, DIM, MLP);
+            bs_blk = (e->s3_ws && e->s3_persist && e->s3_fc1_mode == 2 && s3_fc2 <= 1 && gemm_split3_persist_ok(t1) && gemm_split3_persist_ok(t2)) ? 1 : 0;
+        }
+        auto gemm_s = [&](int cls, const char* A, int K, const char* Wt, const float* bias, const float* resid, float* C, int N, int epi, int a_blk = 0) -> int {
             ProfScope ps(e, st, cls, 2.0 * M * (double)N * K, 6.0 * ((double)M * K + (double)N * K) + 4.0 * M * N * (resid ? 2.0 : 1.0));
             GemmArgs a = mk(reinterpret_cast<const float*>(A), K, reinterpret_cast<const float*>(Wt), K, bias, resid, N, C, N, M, N, K);
             a.qscale = qscale; a.qcols = DIM;
+            a.a_blk = a_blk;
             if (e->s3_ws && e->s3_persist && gemm_split3_persist_ok(a)) return launch_gemm_split3_persist(a, epi, 0, e->s3_ws, st);
             return launch_gemm_split3(a, epi, -1, st);
         };
@@ -549,6 +559,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 ProfScope ps(e, st, THMR_PROF_GEMM_FC1, 2.0 * M * DIM * (double)MLP, 6.0 * ((double)M * DIM + (double)DIM * MLP + (double)M * MLP));
                 GemmArgs a = mk(reinterpret_cast<const float*>(hs), DIM, reinterpret_cast<const float*>(ws.fc1), DIM, w.f1b, nullptr, 0, nullptr, 0, M, MLP, DIM);
                 a.c_split = bs; a.ldcs = MLP;
+                a.cs_blk = bs_blk;
                 if (e->s3_ws && e->s3_persist && e->s3_fc1_mode && gemm_split3_persist_ok(a))
                     LAUNCH_OK(launch_gemm_split3_persist(a, EPI_BIAS_GELU, e->s3_fc1_mode, e->s3_ws, st));
                 else
@@ -558,6 +569,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 {
                     ProfScope ps(e, st, THMR_PROF_GEMM_FC2, 2.0 * M * DIM * (double)MLP, 6.0 * ((double)M * MLP + (double)DIM * MLP) + 4.0 * s3_fc2 * M * DIM);
                     GemmArgs a = mk(reinterpret_cast<const float*>(bs), MLP, reinterpret_cast<const float*>(ws.fc2), MLP, nullptr, nullptr, 0, x, DIM, M, DIM, MLP);
+                    a.a_blk = bs_blk;
                     LAUNCH_OK(launch_gemm_split3_splitk(a, s3_fc2, part2, st));
                 }
                 ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (s3_fc2 + 3.0) * M * DIM);
@@ -567,7 +579,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                     LAUNCH_OK(launch_splitk_resid_ln(part2, s3_fc2, M, DIM, w.f2b, x, x, e->vitw[i + 1].n1w, e->vitw[i + 1].n1b,
                                                      reinterpret_cast<float*>(hs), VIT_EPS, st, true));
             } else {
-                LAUNCH_OK(gemm_s(THMR_PROF_GEMM_FC2, bs, MLP, ws.fc2, w.f2b, x, x, DIM, EPI_BIAS_RESID));
+                LAUNCH_OK(gemm_s(THMR_PROF_GEMM_FC2, bs, MLP, ws.fc2, w.f2b, x, x, DIM, EPI_BIAS_RESID, bs_blk));
                 ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
                 if (last) LAUNCH_OK(launch_layernorm(x, lastn_w, lastn_b, feats_out ? feats_out : h, M, DIM, VIT_EPS, 0, st));
                 else LAUNCH_OK(launch_layernorm_split3(x, e->vitw[i + 1].n1w, e->vitw[i + 1].n1b, hs, M, DIM, VIT_EPS, st));
@@ -1619,11 +1631,21 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
     if (epi == EPI_BIAS_RESID && !resid) return fail(e, THMR_ERR_INVALID, "epilogue needs resid");
     if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || ldc < N)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: K % 32 == 0, lda / ldw multiples of 8 and >= K, ldc >= N");
+    // + 1000: A is a ROW-BLOCKED split3 operand ([M / 32][K / 8][3][32][8], rows padded to 32; GemmArgs::a_blk) — tiles 0 / 2, split-K 202 / 204
+    // and the persistent kernel 300, epilogues 0 and 4 (what fc2 runs)
+    int a_blk = 0;
+    if (variant >= 1000) {
+        a_blk = 1;
+        variant -= 1000;
+        if ((variant != 0 && variant != 2 && variant != 202 && variant != 204 && variant != 300) || (epi != EPI_NONE && epi != EPI_BIAS_RESID))
+            return fail(e, THMR_ERR_INVALID, "split3 GEMM with a row-blocked A: variants 1000, 1002, 1202, 1204, 1300 and epilogues 0 / 4 only");
+    }
     if (!(variant >= -1 && variant <= 4) && variant != 31 && variant != 32 && variant != 34 && variant != 37 && !(variant >= 100 && variant <= 102) &&
         variant != 202 && variant != 204 && variant != 300)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 1, 2, 100-102, 202, 204, 300 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, resid, ldc, C, ldc, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
+    a.a_blk = a_blk;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (variant == 300) {
         // 256 persistent workgroups over a tile stream (gemm_split_persist.hip): M % 128 == 0, N % 256 == 0, at least 256 tiles
@@ -1700,11 +1722,18 @@ int thmr_op_gemm_split3_out_split3(const void* A, int64_t lda, const void* W, in
     if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || (N % 8) != 0 ||
         (ldcs % 8) != 0 || ldcs < N)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: K % 32 == 0, N % 8 == 0, lda / ldw / ldcs multiples of 8 and >= K / K / N");
+    // + 1000: the result in the ROW-BLOCKED form ([M / 32][N / 8][3][32][8], Cs holds ceil(M / 32) * 32 rows; GemmArgs::cs_blk)
+    int cs_blk = 0;
+    if (variant >= 1000) {
+        cs_blk = 1;
+        variant -= 1000;
+    }
     if ((variant < -1 || variant > 2) && variant != 4 && variant != 100 && variant != 301 && variant != 302)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 1, 2, 4, 100 (small-M ring kernel), 301 / 302 (persistent workgroups: LDS / swapped-role epilogue)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, nullptr, 0, nullptr, 0, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
     a.c_split = Cs; a.ldcs = ldcs;
+    a.cs_blk = cs_blk;
     if (variant >= 301) {
 #ifndef THMR_EXPERIMENTS
         if (variant == 301) return fail(e, THMR_ERR_INVALID, "split3 GEMM: the LDS-epilogue persistent variant exists only in the experiments build");

@@ -129,7 +129,9 @@ __global__ __launch_bounds__(256) void ln_split3_kernel(const float* __restrict_
 
 // ABL (timing-only experiments, results are garbage): bit0 no copies in the loop, bit1 no per-tile barrier, bit2 no fragment reads.
 // RS: step 0 issues one fragment read every RS-th MFMA (0 = as early as possible: one per MFMA).
-template <int WM, int WN, int TM, int TN, int EPI, int ABL = 0, int RS = 0>
+// ABLK: A is a ROW-BLOCKED split3 operand (GemmArgs::a_blk): its stage image in LDS is the memory image, [block of 32 rows][12 chunks of the K
+// tile][32 rows][16 B] — linear copies, fragment reads of 512 contiguous bytes per 32 lanes (no swizzle needed).
+template <int WM, int WN, int TM, int TN, int EPI, int ABL = 0, int RS = 0, bool ABLK = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_split3_kernel(GemmArgs a, int tiles_m, int tiles_n, int nwg) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -167,14 +169,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split3_kernel(GemmArgs a, i
     // ---- copies: wave instruction q = wave + i NW of an operand fills LDS chunks 64 q ... 64 q + 63 of its stage; lane -> chunk c,
     // row c / 12, physical slot c % 12, which holds logical chunk (slot - rot(row)) mod 12.  Rows past the edge are clamped.
     const int64_t arow = a.lda * 6, wrow = a.ldw * 6;                  // bytes per matrix row
-    const char* Abase = reinterpret_cast<const char*>(a.A) + (int64_t)bm0 * arow + (int64_t)ksp * nk * ROWB;
+    constexpr int A_KSTEP = ABLK ? SLOTS * 512 : ROWB;               // bytes a K tile advances the A source by (per 32-row block / per row)
+    const char* Abase = reinterpret_cast<const char*>(a.A) + (int64_t)bm0 * arow + (int64_t)ksp * nk * A_KSTEP;
     const char* Wbase = reinterpret_cast<const char*>(a.W) + (int64_t)bn0 * wrow + (int64_t)ksp * nk * ROWB;
     uint32_t Aoff[A_P], Woff[B_P];
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
-        const int c = (wave + i * NW) * 64 + lane, row = c / SLOTS, slot = c - row * SLOTS;
-        const int j = (slot + SLOTS - ((row >> 2) & 3)) % SLOTS;
-        Aoff[i] = (uint32_t)(min(bm0 + row, a.M - 1) - bm0) * (uint32_t)arow + (uint32_t)j * 16u;
+        const int c = (wave + i * NW) * 64 + lane;
+        if constexpr (ABLK) {      // LDS chunk c = (block c / 384, chunk-of-the-K-tile (c % 384) / 32, row-in-block c % 32): the memory order
+            const int row = (c / 384) * 32 + (c & 31), rg = min(bm0 + row, a.M - 1) - bm0;
+            Aoff[i] = (uint32_t)(rg >> 5) * (uint32_t)(a.lda * 192) + (uint32_t)((c % 384) >> 5) * 512u + (uint32_t)(rg & 31) * 16u;
+        } else {
+            const int row = c / SLOTS, slot = c - row * SLOTS;
+            const int j = (slot + SLOTS - ((row >> 2) & 3)) % SLOTS;
+            Aoff[i] = (uint32_t)(min(bm0 + row, a.M - 1) - bm0) * (uint32_t)arow + (uint32_t)j * 16u;
+        }
     }
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
@@ -183,9 +192,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split3_kernel(GemmArgs a, i
         Woff[i] = (uint32_t)(min(bn0 + row, a.N - 1) - bn0) * (uint32_t)wrow + (uint32_t)j * 16u;
     }
     auto dma_piece = [&](int kt, int buf, int p) {                     // p, buf: compile-time after unrolling
-        const int64_t k0b = (int64_t)kt * ROWB;                        // wave-uniform, added on the SALU
-        if (p < A_P) dma16_saddr(Abase + k0b, Aoff[p], lds_addr_b(As + buf * A_STAGE + (wave + p * NW) * 1024));
-        else dma16_saddr(Wbase + k0b, Woff[p - A_P], lds_addr_b(Bs + buf * B_STAGE + (wave + (p - A_P) * NW) * 1024));
+        // wave-uniform, added on the SALU
+        if (p < A_P) dma16_saddr(Abase + (int64_t)kt * A_KSTEP, Aoff[p], lds_addr_b(As + buf * A_STAGE + (wave + p * NW) * 1024));
+        else dma16_saddr(Wbase + (int64_t)kt * ROWB, Woff[p - A_P], lds_addr_b(Bs + buf * B_STAGE + (wave + (p - A_P) * NW) * 1024));
     };
 
     // ---- fragments: step s of a K tile multiplies k-groups 2 s (lanes 0-31) and 2 s + 1 (lanes 32-63); chunk j = 3 kgroup + piece
@@ -196,8 +205,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split3_kernel(GemmArgs a, i
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc)
             fo[s][pc] = (uint32_t)lrow * ROWB + (uint32_t)((((2 * s + lhalf) * 3 + pc) + ((lrow >> 2) & 3)) % SLOTS) * 16u;
-    const char* Afr = As + wm0 * ROWB;
+    const char* Afr = As + wm0 * ROWB;                                 // (row-blocked A: wm0 / 32 blocks of 12 x 512 bytes = the same offset)
     const char* Bfr = Bs + wn0 * ROWB;
+    uint32_t foa[2][3];                                                // A fragments of a row-blocked stage: chunk (k-group, piece) x 512 + row x 16
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) foa[s][pc] = ABLK ? (uint32_t)(((2 * s + lhalf) * 3 + pc) * 512 + lrow * 16) : fo[s][pc];
 
     bf16x8 af[2][TM][3], bf[2][TN][3];
     constexpr int NR = 3 * (TM + TN);                                  // fragment reads per step
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split3_kernel(GemmArgs a, i
     auto read_one = [&](int buf, int s, int set, int r) {
         if (r < 3 * TM) {
             const int mi = r / 3, pc = r % 3;
-            af[set][mi][pc] = *reinterpret_cast<const bf16x8*>(Afr + buf * A_STAGE + mi * 32 * ROWB + fo[s][pc]);
+            af[set][mi][pc] = *reinterpret_cast<const bf16x8*>(Afr + buf * A_STAGE + mi * 32 * ROWB + foa[s][pc]);
         } else {
             const int q = r - 3 * TM, ni = q / 3, pc = q % 3;
             bf[set][ni][pc] = *reinterpret_cast<const bf16x8*>(Bfr + buf * B_STAGE + ni * 32 * ROWB + fo[s][pc]);
@@ -546,7 +560,7 @@ int launch_split3_abl(const GemmArgs& a, hipStream_t s) {
 }
 
 int launch_split3_wide(const GemmArgs& a, int epi, hipStream_t s) {
-    if (a.ksplit > 1) return -1;
+    if (a.ksplit > 1 || a.a_blk) return -1;
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256, nwg = tiles_m * tiles_n;
     const dim3 grid(nwg), block(256);
 #define THMR_WIDE_CASE(E)                                                                                       \
@@ -572,6 +586,12 @@ int launch_split3_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, nwg = tiles_m * tiles_n * (a.ksplit > 1 ? a.ksplit : 1);
     const dim3 grid(nwg), block(WM * WN * 64);
+    if (a.a_blk) {      // row-blocked A (fc2's operand): the two epilogues fc2 runs with — raw split-K partials and bias + residual
+        if (epi == EPI_NONE) hipLaunchKernelGGL((gemm_split3_kernel<WM, WN, TM, TN, EPI_NONE, 0, 0, true>), grid, block, 0, s, a, tiles_m, tiles_n, nwg);
+        else if (epi == EPI_BIAS_RESID) hipLaunchKernelGGL((gemm_split3_kernel<WM, WN, TM, TN, EPI_BIAS_RESID, 0, 0, true>), grid, block, 0, s, a, tiles_m, tiles_n, nwg);
+        else return -1;
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
 #define THMR_SPLIT_CASE(E)                                                                                                  \
     case E:                                                                                                                 \
         hipLaunchKernelGGL((gemm_split3_kernel<WM, WN, TM, TN, E>), grid, block, 0, s, a, tiles_m, tiles_n, nwg);    \
@@ -668,7 +688,7 @@ static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStrea
 int launch_gemm_split3_ring(const GemmArgs& a, int epi, int ksplit, float* part, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || ksplit < 1 || (a.K % (SBK * ksplit)) != 0 || (a.lda % 8) != 0 || (a.ldw % 8) != 0) return -1;
     if (a.lda * 6 * 64 >= (int64_t(1) << 32) || a.ldw * 6 * 64 >= (int64_t(1) << 32) || (ksplit > 1 && part == nullptr)) return -1;
-    if (a.cs_out != nullptr || a.ksplit > 1) return -1;
+    if (a.cs_out != nullptr || a.ksplit > 1 || a.a_blk) return -1;
     if (a.c_split != nullptr && ((a.N % 8) != 0 || (a.ldcs % 8) != 0 || a.ldcs < a.N || epi == EPI_BIAS_RESID || ksplit > 1)) return -1;
     const int tiles_m = (a.M + 63) / 64, tiles_n = (a.N + 63) / 64;
     const int groups = tiles_n * ksplit;

@@ -44,7 +44,6 @@ __device__ __forceinline__ void store_tile_split3(const GemmArgs& a, f32x16 (&ac
     float bias[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) bias[u] = (EPI != EPI_NONE && n + u < a.N) ? a.bias[n + u] : 0.f;
-    char* obase = reinterpret_cast<char*>(a.c_split) + (int64_t)(n >> 3) * 48;
 #pragma unroll
     for (int ps = 0; ps < TM * 32 / RP; ++ps) {
         const int r = r0 + ps * RP, m = m0 + r;
@@ -66,10 +65,11 @@ __device__ __forceinline__ void store_tile_split3(const GemmArgs& a, f32x16 (&ac
 #pragma unroll
         for (int u = 0; u < 4; ++u) split3_pair(v[2 * u], v[2 * u + 1], H[u], M[u], L[u]);
         if (m < a.M && n < a.N) {
-            u32x4* o = reinterpret_cast<u32x4*>(obase + (int64_t)m * a.ldcs * 6);
-            o[0] = u32x4{H[0], H[1], H[2], H[3]};
-            o[1] = u32x4{M[0], M[1], M[2], M[3]};
-            o[2] = u32x4{L[0], L[1], L[2], L[3]};
+            char* cb = reinterpret_cast<char*>(a.c_split);
+            const bool blk = a.cs_blk != 0;
+            *reinterpret_cast<u32x4*>(cb + split3_chunk_off(a.ldcs, m, n >> 3, 0, blk)) = u32x4{H[0], H[1], H[2], H[3]};
+            *reinterpret_cast<u32x4*>(cb + split3_chunk_off(a.ldcs, m, n >> 3, 1, blk)) = u32x4{M[0], M[1], M[2], M[3]};
+            *reinterpret_cast<u32x4*>(cb + split3_chunk_off(a.ldcs, m, n >> 3, 2, blk)) = u32x4{L[0], L[1], L[2], L[3]};
         }
     }
 }

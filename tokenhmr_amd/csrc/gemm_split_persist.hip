@@ -60,7 +60,6 @@ __device__ __forceinline__ void store_tile_split3_swapped(const GemmArgs& a, f32
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int m = m0 + mi * 32 + lrow;
-        char* orow = reinterpret_cast<char*>(a.c_split) + (int64_t)m * a.ldcs * 6;
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
@@ -97,10 +96,11 @@ __device__ __forceinline__ void store_tile_split3_swapped(const GemmArgs& a, f32
                 uint32_t H[4], M[4], L[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) split3_pair(v[2 * u], v[2 * u + 1], H[u], M[u], L[u]);
-                u32x4* o = reinterpret_cast<u32x4*>(orow + (int64_t)(n >> 3) * 48);
-                o[0] = u32x4{H[0], H[1], H[2], H[3]};
-                o[1] = u32x4{M[0], M[1], M[2], M[3]};
-                o[2] = u32x4{L[0], L[1], L[2], L[3]};
+                char* cb = reinterpret_cast<char*>(a.c_split);
+                const bool blk = a.cs_blk != 0;
+                *reinterpret_cast<u32x4*>(cb + split3_chunk_off(a.ldcs, m, n >> 3, 0, blk)) = u32x4{H[0], H[1], H[2], H[3]};
+                *reinterpret_cast<u32x4*>(cb + split3_chunk_off(a.ldcs, m, n >> 3, 1, blk)) = u32x4{M[0], M[1], M[2], M[3]};
+                *reinterpret_cast<u32x4*>(cb + split3_chunk_off(a.ldcs, m, n >> 3, 2, blk)) = u32x4{L[0], L[1], L[2], L[3]};
             }
         }
     }
@@ -109,7 +109,8 @@ __device__ __forceinline__ void store_tile_split3_swapped(const GemmArgs& a, f32
 // MODE: 0 = fp32 output (store_tile), pipeline continuous across tiles
 //       1 = split3 output through the LDS transposition (store_tile_split3): pipeline drained and refilled per tile
 //       2 = split3 output with swapped operand roles + v_permlane32_swap: pipeline continuous
-template <int EPI, int MODE>
+// ABLK: A is a row-blocked split3 operand (GemmArgs::a_blk; see gemm_split3_kernel)
+template <int EPI, int MODE, bool ABLK = false>
 __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(GemmArgs a, int tiles_m, int tiles_n, PersistWs ws) {
     constexpr int NW = 8, WN = 4, TM = 2, TN = 2;
     constexpr bool SWAP = MODE == 2, CONT = MODE != 1;
@@ -158,9 +159,15 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(GemmArgs a, in
     uint32_t Aoff[A_P], Woff[B_P];
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
-        const int c = (wave + i * NW) * 64 + lane, row = c / SLOTS, slot = c - row * SLOTS;
-        Aoff[i] = (uint32_t)row * (uint32_t)arow + (uint32_t)((slot + SLOTS - ((row >> 2) & 3)) % SLOTS) * 16u;
+        const int c = (wave + i * NW) * 64 + lane;
+        if constexpr (ABLK) {
+            Aoff[i] = (uint32_t)(c / 384) * (uint32_t)(a.lda * 192) + (uint32_t)(c % 384) * 16u;       // linear within a 32-row block
+        } else {
+            const int row = c / SLOTS, slot = c - row * SLOTS;
+            Aoff[i] = (uint32_t)row * (uint32_t)arow + (uint32_t)((slot + SLOTS - ((row >> 2) & 3)) % SLOTS) * 16u;
+        }
     }
+    constexpr int A_KSTEP = ABLK ? SLOTS * 512 : ROWB;               // bytes a K tile advances the A source by
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
         const int c = (wave + i * NW) * 64 + lane, row = c / SLOTS, slot = c - row * SLOTS;
@@ -175,11 +182,11 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(GemmArgs a, in
         tile_of(j, bm0, bn0);
         fk = kb;
         fke = ke;
-        fA = reinterpret_cast<const char*>(a.A) + (int64_t)bm0 * arow + (int64_t)kb * ROWB;
+        fA = reinterpret_cast<const char*>(a.A) + (int64_t)bm0 * arow + (int64_t)kb * A_KSTEP;
         fW = reinterpret_cast<const char*>(a.W) + (int64_t)bn0 * wrow + (int64_t)kb * ROWB;
     };
     auto fetch_advance = [&]() {
-        if (fk + 1 < fke) { ++fk; fA += ROWB; fW += ROWB; }
+        if (fk + 1 < fke) { ++fk; fA += A_KSTEP; fW += ROWB; }
         else if (CONT && fn + 1 < nseg) fetch_seg(++fn);
         // else: past the end (of the segment in MODE 1): the last K tile is copied again, into a buffer nobody reads any more
     };
@@ -197,12 +204,17 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(GemmArgs a, in
             fo[s][pc] = (uint32_t)lrow * ROWB + (uint32_t)((((2 * s + lhalf) * 3 + pc) + ((lrow >> 2) & 3)) % SLOTS) * 16u;
     const char* Afr = As + wm0 * ROWB;
     const char* Bfr = Bs + wn0 * ROWB;
+    uint32_t foa[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) foa[s][pc] = ABLK ? (uint32_t)(((2 * s + lhalf) * 3 + pc) * 512 + lrow * 16) : fo[s][pc];
     bf16x8 af[2][TM][3], bf[2][TN][3];
     constexpr int NR = 3 * (TM + TN);
     auto read_one = [&](int buf, int s, int set, int r) {
         if (r < 3 * TM) {
             const int mi = r / 3, pc = r % 3;
-            af[set][mi][pc] = *reinterpret_cast<const bf16x8*>(Afr + buf * A_STAGE + mi * 32 * ROWB + fo[s][pc]);
+            af[set][mi][pc] = *reinterpret_cast<const bf16x8*>(Afr + buf * A_STAGE + mi * 32 * ROWB + foa[s][pc]);
         } else {
             const int q = r - 3 * TM, ni = q / 3, pc = q % 3;
             bf[set][ni][pc] = *reinterpret_cast<const bf16x8*>(Bfr + buf * B_STAGE + ni * 32 * ROWB + fo[s][pc]);
@@ -370,10 +382,10 @@ __global__ __launch_bounds__(512) void gemm_split3_persist_kernel(GemmArgs a, in
     }
 }
 
-template <int EPI, int MODE>
+template <int EPI, int MODE, bool ABLK = false>
 int launch_persist_cfg(const GemmArgs& a, const PersistWs& ws, hipStream_t s) {
     const int tiles_m = a.M / PBM, tiles_n = a.N / PBN;
-    hipLaunchKernelGGL((gemm_split3_persist_kernel<EPI, MODE>), dim3(P_NWG), dim3(512), 0, s, a, tiles_m, tiles_n, ws);
+    hipLaunchKernelGGL((gemm_split3_persist_kernel<EPI, MODE, ABLK>), dim3(P_NWG), dim3(512), 0, s, a, tiles_m, tiles_n, ws);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -399,6 +411,12 @@ int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws_me
     PersistWs ws;
     ws.part = reinterpret_cast<float*>(ws_mem);
     ws.flag = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws_mem) + (size_t)P_NWG * P_SLAB * 4);
+    if (a.a_blk) {      // row-blocked A (fc2's operand): bias + residual, or no epilogue
+        if (mode != 0) return -1;
+        if (epi == EPI_BIAS_RESID) return launch_persist_cfg<EPI_BIAS_RESID, 0, true>(a, ws, s);
+        if (epi == EPI_NONE) return launch_persist_cfg<EPI_NONE, 0, true>(a, ws, s);
+        return -1;
+    }
 #define THMR_PERSIST_CASE(E, MD) \
     if (epi == E && mode == MD) return launch_persist_cfg<E, MD>(a, ws, s);
     THMR_PERSIST_CASE(EPI_NONE, 0)

@@ -95,29 +95,59 @@ def split3(x):
     return out
 
 
-def gemm_split3(a_s, w_s, bias=None, resid=None, epi="none", qscale=1.0, qcols=0, variant="128x256/w8", out_split=False):
+def split3_block(x_s):
+    """row-major split3 operand (R, K/8, 3, 8) -> the ROW-BLOCKED form (ceil(R/32), K/8, 3, 32, 8) the engine uses between fc1 and fc2
+    (csrc/common.h GemmArgs::a_blk): 32-row panels of 512 contiguous bytes per 16-byte chunk; rows past R are zero."""
+    R, G = x_s.shape[0], x_s.shape[1]
+    Rp = (R + 31) // 32 * 32
+    pad = torch.zeros(Rp, G, 3, 8, device=x_s.device, dtype=x_s.dtype)
+    pad[:R] = x_s
+    return pad.view(Rp // 32, 32, G, 3, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def split3_unblock(x_b, R):
+    """inverse of split3_block: (ceil(R/32), K/8, 3, 32, 8) -> (R, K/8, 3, 8)"""
+    nb, G = x_b.shape[0], x_b.shape[1]
+    return x_b.permute(0, 3, 1, 2, 4).reshape(nb * 32, G, 3, 8)[:R].contiguous()
+
+
+def gemm_split3(a_s, w_s, bias=None, resid=None, epi="none", qscale=1.0, qcols=0, variant="128x256/w8", out_split=False,
+                a_blocked_rows=None, out_blocked=False):
     """C = epilogue(a @ w.T) for split3 operands (`split3(a)`, `split3(w)`) on the bf16 matrix pipe with fp32-grade results: six
-    bf16 products per element pair, fp32 accumulation.  `out_split`: the result as a split3 operand (what the engine's fc1 hands fc2).
+    bf16 products per element pair, fp32 accumulation.  `out_split`: the result as a split3 operand (what the engine's fc1 hands fc2);
+    `out_blocked`: that operand in the row-blocked form (`split3_block`).  `a_blocked_rows=M`: `a_s` IS in the row-blocked form and has M rows.
     The engine runs it only in its opt-in mode `Engine.set_vit_gemm("split3")`."""
     _req(bias, resid)
-    for t in (a_s, w_s):
+    if a_blocked_rows is not None:
+        if not (a_s.is_cuda and a_s.dtype == torch.int16 and a_s.is_contiguous() and a_s.dim() == 5 and a_s.shape[2:] == (3, 32, 8)):
+            raise ValueError("a row-blocked split3 operand is int16 (ceil(R/32), K/8, 3, 32, 8)")
+        M, K = int(a_blocked_rows), a_s.shape[1] * 8
+    else:
+        M, K = a_s.shape[0], a_s.shape[1] * 8
+    for t in ((w_s,) if a_blocked_rows is not None else (a_s, w_s)):
         if not (t.is_cuda and t.dtype == torch.int16 and t.is_contiguous() and t.dim() == 4 and t.shape[2:] == (3, 8)):
             raise ValueError("gemm_split3 needs split3 operands (int16, (R, K/8, 3, 8))")
-    M, K = a_s.shape[0], a_s.shape[1] * 8
     N = w_s.shape[0]
     if w_s.shape[1] * 8 != K:
         raise ValueError("K mismatch")
     lib = _L_for(variant in SPLIT3_EXP_ONLY)
+    code = SPLIT3_VARIANT[variant]
+    if (out_blocked or a_blocked_rows is not None) and code < 0:
+        raise ValueError("name the kernel (not 'auto') with a row-blocked operand")
     if out_split:
-        out = torch.empty(M, N // 8, 3, 8, device=a_s.device, dtype=torch.int16)
+        if out_blocked:
+            alloc = torch.empty if M % 32 == 0 else torch.zeros            # the kernels never write the pad rows of the last block
+            out = alloc((M + 31) // 32, N // 8, 3, 32, 8, device=a_s.device, dtype=torch.int16)
+        else:
+            out = torch.empty(M, N // 8, 3, 8, device=a_s.device, dtype=torch.int16)
         with torch.cuda.device(a_s.device):
             _cabi.check(lib.thmr_op_gemm_split3_out_split3(_p(a_s), K, _p(w_s), K, _p(bias), _p(out), N, M, N, K, EPI[epi],
-                                                                   float(qscale), int(qcols), SPLIT3_VARIANT[variant], _s(a_s)), None, lib)
+                                                           float(qscale), int(qcols), code + (1000 if out_blocked else 0), _s(a_s)), None, lib)
         return out
     out = torch.empty(M, N, device=a_s.device, dtype=torch.float32)
     with torch.cuda.device(a_s.device):
         _cabi.check(lib.thmr_op_gemm_split3(_p(a_s), K, _p(w_s), K, _p(bias), _p(resid), _p(out), N, M, N, K, EPI[epi],
-                                                    float(qscale), int(qcols), SPLIT3_VARIANT[variant], _s(a_s)), None, lib)
+                                            float(qscale), int(qcols), code + (1000 if a_blocked_rows is not None else 0), _s(a_s)), None, lib)
     return out
 
 
