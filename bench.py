@@ -638,7 +638,7 @@ def main():
             # --vit-gemm split3: the dominant kernel is gemm_split3_kernel on the bf16 matrix pipe, which executes 6 bf16 MFMA flops per
             # fp32-equivalent flop: achieved / peak are in bf16 MFMA TFLOP/s there (f32_equivalent beside them)
             pk, mul = (PEAK_BF16_MFMA_TFLOPS, 6.0) if split_mode else (PEAK_F32_MFMA_TFLOPS, 1.0)
-            roof = {"bound": "mfma", "kernel": f"{'gemm_split3_kernel' if split_mode else 'gemm_f32_kernel'} ({dom})", "achieved": round(tf * mul, 2),
+            roof = {"bound": "mfma", "kernel": f"{'gemm_split3_persist_kernel / gemm_split3_kernel' if split_mode else 'gemm_f32_kernel'} ({dom})", "achieved": round(tf * mul, 2),
                     "peak": pk, "unit": "TFLOP/s" + (" (bf16 MFMA: 6 x the fp32-equivalent flops)" if split_mode else ""),
                     "frac": round(tf * mul / pk, 4),
                     "traffic": None, "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],
@@ -753,7 +753,7 @@ def main():
                           "dtype": "f32 operands as 3 x bf16 pieces, 6 bf16 MFMA products per pair, f32 accumulate (ViT GEMMs only)",
                           "parity": s_par,
                           "classes_ms_per_step": {k: round(v["ms"], 3) for k, v in s_prof.items() if v["launches"]},
-                          "roofline": {"bound": "mfma", "kernel": "gemm_split3_kernel (gemm_fc1)",
+                          "roofline": {"bound": "mfma", "kernel": "gemm_split3_persist_kernel<GELU, swapped roles> (gemm_fc1; gemm_split3_kernel below 32 crops / odd batches)",
                                        "achieved": round(6.0 * fc1["flops"] / (fc1["ms"] * 1e-3) / 1e12, 1) if fc1 and fc1["launches"] else None,
                                        "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s (bf16 MFMA: 6 x the fp32-equivalent flops)",
                                        "frac": round(6.0 * fc1["flops"] / (fc1["ms"] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if fc1 and fc1["launches"] else None,

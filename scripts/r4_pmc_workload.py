@@ -25,14 +25,15 @@ if which in ("all", "gemm"):
     a, w, b = mk(5120, 1280)
     sa, sw = ops.split3(a), ops.split3(w)
     for _ in range(6):
-        ops.gemm_split3(sa, sw, b, epi="bias_gelu", variant="persist/swap", out_split=True)
+        ops.gemm_split3(sa, sw, b, epi="bias_gelu", variant="persist/swap", out_split=True, out_blocked=True)     # as the engine runs fc1 now
     for _ in range(6):
         ops.gemm(a, w, b, epi="bias_gelu")                     # the headline's fc1: exact-fp32 MFMA
     a, w, b = mk(1280, 5120)
     r = torch.randn(M, 1280, generator=g).to(dev)
     sa, sw = ops.split3(a), ops.split3(w)
+    sab = ops.split3_block(sa)
     for _ in range(6):
-        ops.gemm_split3(sa, sw, b, r, epi="bias_resid", variant="persist")
+        ops.gemm_split3(sab, sw, b, r, epi="bias_resid", variant="persist", a_blocked_rows=M)                     # fc2 with its row-blocked A
     torch.cuda.synchronize()
 if which in ("all", "rows"):
     x = torch.randn(M, 1280, generator=g).to(dev)

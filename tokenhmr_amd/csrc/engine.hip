@@ -520,6 +520,8 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         {
             GemmArgs t1 = mk(nullptr, DIM, nullptr, DIM, nullptr, nullptr, 0, nullptr, 0, M, MLP, DIM), t2 = mk(nullptr, MLP, nullptr, MLP, nullptr, nullptr, 0, nullptr, 0, M, DIM, MLP);
             bs_blk = (e->s3_ws && e->s3_persist && e->s3_fc1_mode == 2 && s3_fc2 <= 1 && gemm_split3_persist_ok(t1) && gemm_split3_persist_ok(t2)) ? 1 : 0;
+            static const bool no_blk = [] { const char* k = thmr_knob("THMR_SPLIT3_BS_BLK"); return k && k[0] == '0'; }();      // A/B (experiments build)
+            if (no_blk) bs_blk = 0;
         }
         auto gemm_s = [&](int cls, const char* A, int K, const char* Wt, const float* bias, const float* resid, float* C, int N, int epi, int a_blk = 0) -> int {
             ProfScope ps(e, st, cls, 2.0 * M * (double)N * K, 6.0 * ((double)M * K + (double)N * K) + 4.0 * M * N * (resid ? 2.0 : 1.0));
