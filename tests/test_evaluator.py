@@ -61,3 +61,47 @@ def test_gpu_evaluator_matches_reference(built_lib, cuda_dev):
     assert re.abs().max().item() < 1e-2
     ref_mp, _, _ = E.evaluate_batch(y, torch.zeros(512, 4, 3), x, torch.zeros(512, 4, 3), KP, 39)
     assert (mp.cpu() - ref_mp).abs().max() < 1e-1 * 1e-1
+
+
+def test_evaluator_fills_its_host_arrays_lazily(monkeypatch):
+    """The drop-in evaluator keeps a batch's (B,) results where the kernels left them and copies them into the reference's host arrays
+    only when somebody looks — so eval.py's loop (evaluator(out, batch) per batch, :149) never synchronises per batch.  Host logic only:
+    the kernels are replaced by a stand-in that returns known per-sample values."""
+    from tokenhmr_amd import evaluator as EV
+    calls = []
+
+    def fake_eval(pred_j, gt_j, kpl, pelvis, mode=0, pv=None, gv=None):
+        B = pred_j.shape[0]
+        base = float(len(calls)) * 100
+        calls.append(B)
+        mk = lambda off: torch.arange(B, dtype=torch.float32) + base + off      # noqa: E731
+        return mk(0.0), mk(0.25), (mk(0.5) if pv is not None else None)
+
+    monkeypatch.setattr(EV, "eval_pose_gpu", fake_eval)
+    ev = EV.Evaluator(dataset_length=100, keypoint_list=[0, 1], pelvis_ind=0, metrics=["mode_re", "mode_mpjpe", "mode_pve"], max_pending=3)
+    out = {"pred_keypoints_3d": torch.zeros(4, 44, 3), "pred_vertices": torch.zeros(4, 10, 3)}
+    batch = {"keypoints_3d": torch.zeros(4, 44, 4), "vertices": torch.zeros(4, 10, 3), "imgname": ["a", "b", "c", "d"]}
+    r0 = ev(out, batch)
+    r1 = ev(out, batch)
+    assert ev.counter == 8 and len(ev._pending) == 2 and ev.imgnames == ["a", "b", "c", "d"] * 2
+    assert not ev._arrays["mode_mpjpe"][:8].any()                       # nothing copied yet
+    assert list(r1["mode_mpjpe"]) == [100.0, 101.0, 102.0, 103.0]       # looking at a returned batch dict fills the arrays
+    assert len(ev._pending) == 0 and list(r0["mode_re"]) == [0.25, 1.25, 2.25, 3.25]
+    assert set(r0.keys()) == {"mode_mpjpe", "mode_re", "mode_pve"} and r0.get("nope") is None and len(r0.get("mode_pve")) == 4
+    ev(out, batch)
+    ev(out, batch)
+    assert len(ev._pending) == 2
+    ev(out, batch)                                                      # max_pending batches: flushed without being asked
+    assert len(ev._pending) == 0 and ev._arrays["mode_pve"][16] == 400.5
+    ev(out, batch)
+    assert hasattr(ev, "mode_pve") and not hasattr(ev, "mode_nope")
+    assert ev.mode_mpjpe[20] == 500.0 and len(ev._pending) == 0          # reading a metric array is "looking"
+    d = ev.get_metrics_dict()
+    assert abs(d["mode_mpjpe"] - np.mean([b * 100 + i for b in range(6) for i in range(4)])) < 1e-9
+    ev.mode_re = np.full((100,), 7.0)                                    # merge_evaluator (dist.py) replaces arrays wholesale
+    assert ev.get_metrics_dict()["mode_re"] == 7.0
+    # the reference's default metric list spells 'model_pve' (pose_utils.py): that array exists and stays zero, and no PVE is computed
+    ev2 = EV.Evaluator(dataset_length=10, keypoint_list=[0], pelvis_ind=0)
+    ev2({"pred_keypoints_3d": torch.zeros(2, 44, 3), "pred_vertices": torch.zeros(2, 10, 3)},
+        {"keypoints_3d": torch.zeros(2, 44, 4), "vertices": torch.zeros(2, 10, 3), "imgname": []})
+    assert ev2.get_metrics_dict()["model_pve"] == 0.0 and "mode_pve" not in ev2._arrays

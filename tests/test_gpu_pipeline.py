@@ -325,3 +325,39 @@ def test_decoder_timeout_is_reported_once_and_the_engine_recovers(built_lib, cud
     out = b.forward(img)
     torch.cuda.synchronize()
     assert torch.equal(out["pred_vertices"], ref["pred_vertices"])
+
+
+def test_split3_handover_timeout_is_reported_once_and_the_engine_falls_back(built_lib, cuda_dev, monkeypatch):
+    """The persistent split3 GEMM hands accumulators from one workgroup to another with a bounded wait; when it runs out (another kernel
+    held the device for ~0.5 s) thmr_engine_status reports it ONCE, resets the workspace and switches the engine to the per-tile kernel —
+    whose results are the same bits, so the re-submitted batch equals what the persistent kernels give.  THMR_SPLIT3_FORCE_TIMEOUT=1
+    (experiments build) makes the status call report a timeout that did not happen."""
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd import weights as W, _cabi
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    from tokenhmr_amd.engine import Engine
+    if torch.cuda.get_device_properties(cuda_dev).multi_processor_count != 256:
+        pytest.skip("the persistent split3 GEMM needs 8 XCDs x 32 CUs")
+    cfg = HMRConfig(vit_depth=1, dec_depth=1)
+    sd, tok, smpl = W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0), make_synthetic_smpl(cfg, 0)
+    good = Engine(cfg, max_batch=32, device=cuda_dev)                    # shipped library, persistent kernels
+    good.load_state(sd, tok)
+    good.load_smpl(smpl)
+    good.finalize()
+    good.set_vit_gemm("split3")
+    img = torch.randn(32, 3, 256, 256, generator=torch.Generator().manual_seed(5)).to(cuda_dev)
+    ref = {k: v.clone() for k, v in good.forward(img).items()}
+    good.status()
+    monkeypatch.setenv("THMR_SPLIT3_FORCE_TIMEOUT", "1")
+    e = Engine(cfg, max_batch=32, device=cuda_dev, weight_arena=good.weight_arena, experiments=True)
+    e.finalize(assume_all_loaded=True)
+    e.set_vit_gemm("split3")
+    e.forward(img)
+    with pytest.raises(_cabi.EngineError, match="hand-over wait timed out"):
+        e.status()
+    e.status()                                                          # reported once
+    out = e.forward(img)                                                # per-tile kernels from here on
+    torch.cuda.synchronize()
+    e.status()
+    for k in ("pred_vertices", "pred_cam", "token_idx", "cls_logits_softmax"):
+        assert torch.equal(out[k], ref[k]), k

@@ -123,6 +123,7 @@ struct thmr_engine {
     // the per-tile kernel (THMR_SPLIT3_FC1_MODE)
     void* s3_ws = nullptr;
     int s3_persist = 1, s3_fc1_mode = 2;
+    bool s3_forced_once = false;      // experiments build: THMR_SPLIT3_FORCE_TIMEOUT=1 was honoured already
     struct SplitW { const char *qkv, *proj, *fc1, *fc2; };
     std::vector<SplitW> vitw_s;
     const char* kv_s = nullptr;       // split3 copy of the decoder's stacked to_kv weights (dec_depth * 1024 rows x 1280)
@@ -1463,6 +1464,13 @@ int thmr_engine_status(thmr_engine* e, void* stream) {
         // back to the per-tile kernel (same results) so the caller can simply re-submit.  Reported once.
         unsigned err = 0;
         if (gemm_split3_persist_error(e->s3_ws, st, &err) != 0) return fail(e, THMR_ERR_HIP, "reading the split3 hand-over error word failed");
+#ifdef THMR_EXPERIMENTS
+        // tests only: report a hand-over timeout that did not happen, once per engine, to exercise the recovery below
+        if (e->s3_persist && e->vit_gemm_mode == 1 && !e->s3_forced_once) {
+            const char* f = thmr_knob("THMR_SPLIT3_FORCE_TIMEOUT");
+            if (f && f[0] == '1') { err = 1; e->s3_forced_once = true; }
+        }
+#endif
         if (err != 0) {
             HIP_OK(hipMemsetAsync(e->s3_ws, 0, gemm_split3_persist_ws_bytes(), st));
             HIP_OK(hipStreamSynchronize(st));

@@ -81,6 +81,9 @@ class _BatchMetrics(dict):
             raise KeyError(k)
         return getattr(self._ev, k)[self._lo:self._hi]
 
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
     def values(self):
         return [self[k] for k in self]
 
