@@ -41,7 +41,10 @@ def parse(argv=None):
     ap.add_argument("--global-batch", type=int, default=0,
                     help="BASELINE configs[3]: shard ONE global batch of this many crops over the ranks (ragged shards allowed, "
                          "e.g. 509 over 8) instead of --batch crops per GPU; the line then says scaling = strong")
-    ap.add_argument("--workload", choices=["full", "vit"], default="full")
+    ap.add_argument("--workload", choices=["full", "vit", "pipeline"], default="full",
+                    help="full (default, the headline): thmr_forward on resident crops.  vit: the encoder only.  pipeline (one GPU): frames on the "
+                         "host -> H2D -> crop kernels -> forward -> evaluator kernels on two streams, nothing else — the `pipeline` block of the "
+                         "default line as its own run (e.g. under rocprofv3); its `value` is the pipeline's crops/s, not the headline")
     ap.add_argument("--vit-depth", type=int, default=32)
     ap.add_argument("--vit-gemm", choices=["f32", "split3"], default="f32",
                     help="f32 (default, the headline): exact-fp32 MFMA.  split3: run the WHOLE bench in the engine's opt-in mode — ViT GEMMs "
@@ -497,6 +500,18 @@ def main():
         shp = (sizes[r], 3, 8, 8) if cpu_dry else (sizes[r], 3, 256, 256)
         return torch.randn(*shp, generator=gen)
 
+    if a.workload == "pipeline":
+        if cpu_dry or world != 1:
+            sys.exit("--workload pipeline runs on one GPU with a real engine")
+        res = pipeline_bench(eng, dev, B, a.steps, a.warmup)
+        eng.status()
+        print(json.dumps({"metric": "crops_per_sec", "value": res["crops_per_s"], "unit": "crops/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": res["ms_per_batch"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32 (ViT GEMM operands as 3 x bf16 pieces)" if split_mode else "f32", "data": "synthetic",
+                          "config": {"workload": "frames -> crops -> TokenHMR full path -> evaluator pipeline (NOT the headline workload)", "batch_per_gpu": B,
+                                     "vit_depth": cfg.vit_depth},
+                          "pipeline": res, "build": build_info}), flush=True)
+        return
     img = crops_of(rank).to(dev)                         # resident in HBM before timing
     outs = eng._alloc_outputs(B, taps=False, want_probs=True)
     feats = None if cpu_dry else torch.empty(B, 192, 1280, device=dev)
