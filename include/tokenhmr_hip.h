@@ -192,8 +192,8 @@ int thmr_vq_decode(thmr_engine* e, const float* probs_dev, int32_t B, float* pos
 int thmr_op_gemm(const float* A_dev, int64_t lda, const float* W_dev, const float* bias_dev, const float* resid_dev,
                  float* C_dev, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi, float qscale, int32_t qcols,
                  int32_t variant, void* stream);
-/* fp32 GEMM on the bf16 matrix pipe (csrc/gemm_split.hip) — NOT what the engine runs (thmr_forward stays on exact-fp32 MFMA); an
- * operator of its own, measured beside thmr_op_gemm.  Every fp32 operand is carried as three bf16 pieces h + m + l (x == h + m + l
+/* fp32 GEMM on the bf16 matrix pipe (csrc/gemm_split.hip) — what the engine's OPT-IN mode thmr_set_vit_gemm(1) runs for the ViT GEMMs
+ * (by default thmr_forward stays on exact-fp32 MFMA); also an operator of its own, measured beside thmr_op_gemm.  Every fp32 operand is carried as three bf16 pieces h + m + l (x == h + m + l
  * up to 2^-24 |x|) in the "split3" layout [rows][K/8][3][8] bf16 (row stride 6 * ld bytes); the product keeps the six piece pairs
  * down to 2^-16 of |a b| (what is dropped is below one fp32 rounding of the product), accumulation is fp32 in the MFMA.
  * thmr_op_split3 converts (K % 8 == 0, ld_dst % 8 == 0, ld_dst >= K, ld_src % 4 == 0).  thmr_op_gemm_split3: A / W split3 with row
@@ -201,14 +201,21 @@ int thmr_op_gemm(const float* A_dev, int64_t lda, const float* W_dev, const floa
  * variant -1 = the engine's rule; 0 = 128x256 tile, 8 waves; 1 = 128x256, 4 waves; 2 = 128x128, 4 waves; 4 = 256x256, 4 waves of
  * 128x128 (all bit-identical to each other); 100 + j = the small-M ring kernel (64x64 tiles, 4-deep LDS-DMA ring) with split-K 2^j, j <= 2 — 100 is bit-identical to the big
  * tiles, the split ones associate K differently; 202 / 204 = split-K 2 / 4 on the big tiles (the engine's 5 ... 31 crops use 2, 3 and 4 crops 4);
- * (3, 31, 32, 34, 37: schedule experiments of scripts/split3_bench.py, epilogue 0 only;
- * 31-37 are timing-only and return garbage). */
+ * 300 = 256 PERSISTENT workgroups over a tile stream (csrc/gemm_split_persist.hip: M % 128 == 0, N % 256 == 0, at least 256 tiles; a ragged
+ * last round is split along K with the accumulators handed from one workgroup to the next through memory — bit-identical to 0 / 2; what the
+ * engine runs at 32 crops and more); + 1000 (1000, 1002, 1202, 1204, 1300; epi 0 / 4): A is a ROW-BLOCKED split3 operand
+ * [rows / 32][K / 8][3][32][8] (rows padded to 32; chunk (r, k-group, piece) at (r / 32) K 192 + (k-group 3 + piece) 512 + (r % 32) 16 bytes) —
+ * the form the engine's fc1 hands fc2.
+ * Variants 1, 4, 100-102 and (3, 31, 32, 34, 37: schedule experiments of scripts/split3_bench.py, epilogue 0 only; 31-37 are timing-only
+ * and return garbage) exist in the experiments build of the library only (libtokenhmr_hip_exp.so, -DTHMR_EXPERIMENTS). */
 int thmr_op_split3(const float* src_dev, int64_t ld_src, void* dst_dev, int64_t ld_dst, int64_t rows, int32_t K, void* stream);
 int thmr_op_gemm_split3(const void* A_split_dev, int64_t lda, const void* W_split_dev, int64_t ldw, const float* bias_dev,
                         const float* resid_dev, float* C_dev, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi,
                         float qscale, int32_t qcols, int32_t variant, void* stream);
 /* the same product with the epilogue's result written as a split3 operand (the next GEMM's A; row stride 6 * ldcs bytes, N % 8 == 0,
- * ldcs % 8 == 0) instead of fp32: bit-identical to thmr_op_split3 of thmr_op_gemm_split3's output.  epi 0, 1, 2, 5; variant -1, 0, 1, 2 or 100 (the ring kernel). */
+ * ldcs % 8 == 0) instead of fp32: bit-identical to thmr_op_split3 of thmr_op_gemm_split3's output.  epi 0, 1, 2, 5; variant -1, 0, 2;
+ * 302 = the persistent kernel with operand roles swapped and v_permlane32_swap in the epilogue (epi 0 / 2); + 1000 = the result in the
+ * row-blocked form (Cs holds ceil(M / 32) * 32 rows); 1, 4, 100 (ring kernel), 301 (persistent, LDS epilogue): experiments build only. */
 int thmr_op_gemm_split3_out_split3(const void* A_split_dev, int64_t lda, const void* W_split_dev, int64_t ldw, const float* bias_dev,
                                    void* C_split_dev, int64_t ldcs, int32_t M, int32_t N, int32_t K, int32_t epi, float qscale,
                                    int32_t qcols, int32_t variant, void* stream);
