@@ -66,15 +66,16 @@ def main():
             print(json.dumps(row), flush=True)
             continue
         persist_ok = M % 128 == 0 and (M // 128) * (N // 256) >= 256
-        variants = ("128x256/w8", "persist") if args.persist else ("128x256/w8", "128x256/w4", "128x128/w4", "256x256/w4", "persist")
+        # product kernels (16x16x32 MFMAs) and, for the A/B, the 32x32x16 kernels they replaced (experiments build)
+        variants = ("128x256/w8", "persist", "old/128x256/w8", "old/persist") if args.persist else ("128x256/w8", "128x256/w4", "128x128/w4", "256x256/w4", "persist", "old/128x256/w8", "old/persist")
         for v in variants:
-            if v == "persist" and not persist_ok:
+            if v.endswith("persist") and not persist_ok:
                 continue
             t = timed(lambda: ops.gemm_split3(sa, sw, db, res, epi=epi, variant=v, **kw), args.iters)
             row["split3 " + v] = {"us": round(t * 1e6, 1), "f32_equiv_tflops": round(flop / t * 1e-12, 1), "vs_f32_mfma": round(t32 / t, 3)}
         if name == "fc1":        # what the engine runs: the GELU result written as fc2's split3 operand
-            for v in ("128x256/w8", "persist/lds", "persist/swap"):
-                if v != "128x256/w8" and not persist_ok:
+            for v in ("128x256/w8", "persist/swap", "old/128x256/w8", "old/persist/lds", "old/persist/swap"):
+                if "persist" in v and not persist_ok:
                     continue
                 t = timed(lambda: ops.gemm_split3(sa, sw, db, epi=epi, variant=v, out_split=True), args.iters)
                 row["split3-out " + v] = {"us": round(t * 1e6, 1), "f32_equiv_tflops": round(flop / t * 1e-12, 1), "vs_f32_mfma": round(t32 / t, 3)}

@@ -242,14 +242,20 @@ def test_gemm_split3(built_lib, cuda_dev, shape):
             o = ops.gemm_split3(sa, sw, db, dr if epi == "bias_resid" else None, epi=epi, variant=variant, **kw)
             ref = _gemm_ref(a, w, b, r, epi, kw.get("qscale", 1.0), kw.get("qcols", 0))
             assert torch.allclose(o.cpu(), ref, atol=2e-4, rtol=1e-5), (variant, epi, (o.cpu() - ref).abs().max())
-    assert torch.equal(outs["128x256/w4"], outs["128x256/w8"]) and torch.equal(outs["128x128/w4"], outs["128x256/w8"])
-    assert torch.equal(outs["256x256/w4"], outs["128x256/w8"])
-    # the small-M ring kernel: without split-K bit-identical to the big tiles (same K order per element); with split-K another association
+    # the product kernels (v_mfma_f32_16x16x32_bf16, csrc/gemm_split16.hip): both tiles and the rule give the same bits
+    assert torch.equal(outs["128x128/w4"], outs["128x256/w8"]) and torch.equal(ops.gemm_split3(sa, sw, variant="auto"), outs["128x256/w8"])
+    # the round-3 / first round-4 kernels on 32x32x16 MFMAs (experiments build): bit-identical among themselves — 64x64 and 64x128 wave
+    # tiles, the 256x256 tile, the small-M ring kernel without split-K — and equal to the product kernels to fp32 rounding (another
+    # grouping of k inside the MFMA)
+    old = ops.gemm_split3(sa, sw, variant="old/128x256/w8")
     ring = ops.gemm_split3(sa, sw, variant="ring")
-    assert torch.equal(ring, outs["128x256/w8"]) and torch.equal(ops.gemm_split3(sa, sw, variant="auto"), outs["128x256/w8"])
+    assert torch.equal(outs["128x256/w4"], old) and torch.equal(outs["256x256/w4"], old) and torch.equal(ring, old)
+    assert torch.equal(ops.gemm_split3(sa, sw, variant="old/128x128/w4"), old)
+    assert (((old.cpu().double() - ref64).abs() / bound).max().item()) <= max(2.0 * e32, 2.0 ** -22)
+    assert torch.allclose(old, outs["128x256/w8"], atol=2e-4, rtol=1e-5)
     for epi, kw in (("bias", {}), ("bias_gelu", {}), ("bias_resid", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
         o = ops.gemm_split3(sa, sw, db, dr if epi == "bias_resid" else None, epi=epi, variant="ring", **kw)
-        assert torch.equal(o, ops.gemm_split3(sa, sw, db, dr if epi == "bias_resid" else None, epi=epi, variant="128x256/w8", **kw)), epi
+        assert torch.equal(o, ops.gemm_split3(sa, sw, db, dr if epi == "bias_resid" else None, epi=epi, variant="old/128x256/w8", **kw)), epi
     for ks, name in ((2, "ring/k2"), (4, "ring/k4"), (2, "auto/k2"), (4, "auto/k4")):
         if K % (32 * ks):
             continue
@@ -260,7 +266,7 @@ def test_gemm_split3(built_lib, cuda_dev, shape):
             half = ops.gemm_split3(ops.split3(da[:M // 2].contiguous()), sw, db, dr[:M // 2].contiguous(), epi="bias_resid", variant=name)
             assert torch.equal(half, o[:M // 2]), name
     if N % 8 == 0:      # the epilogue's result as the next GEMM's split3 operand: bit-identical to converting the fp32 result
-        for variant in ("128x256/w8", "128x256/w4", "128x128/w4", "256x256/w4", "ring"):
+        for variant in ("128x256/w8", "128x256/w4", "128x128/w4", "256x256/w4", "ring", "old/128x256/w8"):
             for epi, kw in (("none", {}), ("bias", {}), ("bias_gelu", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
                 bb = None if epi == "none" else db
                 fused = ops.gemm_split3(sa, sw, bb, epi=epi, variant=variant, out_split=True, **kw)
@@ -304,12 +310,19 @@ def test_gemm_split3_persistent(built_lib, cuda_dev, shape):
         want = ops.gemm_split3(sa, sw, db, rr, epi=epi, variant="128x256/w8", **kw)
         got = ops.gemm_split3(sa, sw, db, rr, epi=epi, variant="persist", **kw)
         assert torch.equal(got, want), (epi, int((got != want).sum()))
-    for epi in ("none", "bias_gelu"):
+    for epi in ("none", "bias", "bias_gelu", "bias_qscale"):
         bb = None if epi == "none" else db
-        want = ops.gemm_split3(sa, sw, bb, epi=epi, variant="128x256/w8", out_split=True)
-        for variant in ("persist/lds", "persist/swap"):
-            got = ops.gemm_split3(sa, sw, bb, epi=epi, variant=variant, out_split=True)
-            assert torch.equal(got, want), (variant, epi, int((got != want).sum()))
+        kw = dict(qscale=80 ** -0.5, qcols=N // 3) if epi == "bias_qscale" else {}
+        want = ops.gemm_split3(sa, sw, bb, epi=epi, variant="128x256/w8", out_split=True, **kw)
+        got = ops.gemm_split3(sa, sw, bb, epi=epi, variant="persist/swap", out_split=True, **kw)
+        assert torch.equal(got, want), (epi, int((got != want).sum()))
+    # the first round-4 persistent kernel (32x32x16 MFMAs; experiments build) against ITS per-tile twin: fp32 output, and the split3 output
+    # through the LDS transposition / swapped roles + permlane32 swaps
+    old = ops.gemm_split3(sa, sw, variant="old/128x256/w8")
+    assert torch.equal(ops.gemm_split3(sa, sw, variant="old/persist"), old) and torch.allclose(old, base, atol=2e-4, rtol=1e-5)
+    want = ops.gemm_split3(sa, sw, db, epi="bias_gelu", variant="old/128x256/w8", out_split=True)
+    for variant in ("old/persist/lds", "old/persist/swap"):
+        assert torch.equal(ops.gemm_split3(sa, sw, db, epi="bias_gelu", variant=variant, out_split=True), want), variant
     # another shape on the same (device, stream) workspace in between, then this one again
     a2, w2 = _rand(2048, 64, seed=21).to(cuda_dev), _rand(4096, 64, seed=22).to(cuda_dev)
     s2a, s2w = ops.split3(a2), ops.split3(w2)

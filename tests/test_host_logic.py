@@ -241,7 +241,7 @@ def test_gemm_k_loops_carry_no_valu_instruction(built_lib, tmp_path):
     import subprocess
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     texts = {}
-    for name in ("gemm_f32.o", "gemm_split.o"):
+    for name in ("gemm_f32.o", "gemm_split16.o"):
         obj = os.path.join(os.path.dirname(_cabi.LIB_PATH), name)
         if not (os.path.exists(objdump) and os.path.exists(obj)):
             pytest.skip("llvm-objdump or the GEMM object file is not available")
@@ -278,10 +278,13 @@ def test_gemm_k_loops_carry_no_valu_instruction(built_lib, tmp_path):
         assert loops, "no MFMA loop found in " + symbol_re
         return min(loops, key=len)                      # the innermost loop with that many MFMAs
 
-    # ... and the split3 GEMM (gemm_split.hip: bf16 MFMAs, whose issue slots are half as long): default tile, fc1 epilogue and the plain one
+    # ... and the split3 GEMM (gemm_split16.hip: 16x16x32 bf16 MFMAs, 96 per K tile and wave, two K tiles per loop trip): the per-tile
+    # instantiations of the 128 x 256 tile with the GELU and the residual epilogue, and the 128 x 128 tile (the persistent instantiations
+    # run the same K tile body; their loop also holds the cold branch that looks up the next tile of the stream)
     for name, sym, min_mfma in (("gemm_f32.o", r"gemm_f32_kernelILi4ELi1ELi1ELi5ELb1ELi2", 160), ("gemm_f32.o", r"gemm_ring_kernelILi4ELi5ELb0", 64),
-                                ("gemm_split.o", r"gemm_split3_kernelILi2ELi4ELi2ELi2ELi2ELi0ELi0E", 96),
-                                ("gemm_split.o", r"gemm_split3_kernelILi2ELi4ELi2ELi2ELi4ELi0ELi0E", 96)):
+                                ("gemm_split16.o", r"gemm_split16_kernelILi4ELi2ELb0ELb0E", 192),
+                                ("gemm_split16.o", r"gemm_split16_kernelILi4ELi4ELb0ELb0E", 192),
+                                ("gemm_split16.o", r"gemm_split16_kernelILi2ELi0ELb0ELb0E", 192)):
         seg = k_loop(name, sym, min_mfma)
         valu = [op for _, op, _ in seg if op.startswith("v_") and not op.startswith("v_mfma")]
         dma = [(op, args) for _, op, args in seg if op.startswith("global_load_lds")]
@@ -312,9 +315,9 @@ def test_shipped_library_reads_no_environment_and_carries_no_experiment(built_li
              b"THMR_ATTN_VARIANT", b"THMR_MID_SPLIT", b"THMR_SPLIT3_PERSIST"]
     for k in knobs:
         assert k not in shipped and k in exp, k
-    for sym in (b"gemm_split3_wide_kernel", b"gemm_split3_ring_kernel"):
-        assert sym not in shipped and sym in exp, sym
-    assert b"gemm_split3_persist_kernel" in shipped and b"gemm_split3_kernel" in shipped
+    for sym in (b"gemm_split3_wide_kernel", b"gemm_split3_ring_kernel", b"gemm_split3_persist_kernel", b"18gemm_split3_kernel"):
+        assert sym not in shipped and sym in exp, sym          # incl. the 32x32x16 split3 kernels the 16x16x32 ones replaced
+    assert b"gemm_split16_kernel" in shipped
     csrc = os.path.join(os.path.dirname(os.path.dirname(_cabi.LIB_PATH)), "csrc")
     for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
         n = len(re.findall(r"\bgetenv\s*\(", open(f).read()))

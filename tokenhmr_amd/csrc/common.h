@@ -362,6 +362,10 @@ bool gemm_split3_persist_ok(const GemmArgs& a);        // shape served by the pe
 int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws, hipStream_t s);
 int gemm_split3_persist_error(void* ws, hipStream_t s, unsigned* err_out);   // synchronises s; *err_out != 0: a hand-over spin timed out
 void* gemm_split3_persist_op_ws(hipStream_t s);        // zeroed workspace per (device, stream) for the stateless operators
+// gemm_split16.hip: the split3 GEMM on v_mfma_f32_16x16x32_bf16 (what launch_gemm_split3 / _splitk / _persist run since round 4):
+// one workgroup per tile (wide = 128 x 256 on 8 waves, else 128 x 128 on 4; a.ksplit copies of the grid) or 256 persistent workgroups
+int launch_split16_tiles(const GemmArgs& a, int epi, bool wide, hipStream_t s);
+int launch_split16_persist(const GemmArgs& a, int epi, void* ws, hipStream_t s);
 // small-M split3 GEMM (64x64 tiles, LDS-DMA ring, optional split-K into part[ksplit][M][N] without epilogue)
 int launch_gemm_split3_ring(const GemmArgs& a, int epi, int ksplit, float* part, hipStream_t s);
 // LayerNorm (D = 1280) whose result is written as a split3 operand [rows][D/8][3][8] instead of fp32 (same arithmetic as launch_layernorm)

@@ -1651,18 +1651,19 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
             return fail(e, THMR_ERR_INVALID, "split3 GEMM with a row-blocked A: variants 1000, 1002, 1202, 1204, 1300 and epilogues 0 / 4 only");
     }
     if (!(variant >= -1 && variant <= 4) && variant != 31 && variant != 32 && variant != 34 && variant != 37 && !(variant >= 100 && variant <= 102) &&
-        variant != 202 && variant != 204 && variant != 300)
-        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 1, 2, 100-102, 202, 204, 300 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
+        variant != 202 && variant != 204 && variant != 300 && variant != 20 && variant != 22 && variant != 310)
+        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 2, 202, 204, 300; experiments build: 1, 4, 20, 22, 100-102, 310 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, resid, ldc, C, ldc, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
     a.a_blk = a_blk;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (variant == 300) {
-        // 256 persistent workgroups over a tile stream (gemm_split_persist.hip): M % 128 == 0, N % 256 == 0, at least 256 tiles
+    if (variant == 300 || variant == 310) {
+        // 256 persistent workgroups over a tile stream: M % 128 == 0, N % 256 == 0, at least 256 tiles.  300 = the product kernel (gemm_split16.hip),
+        // 310 = the round-4 first version on 32x32x16 MFMAs (gemm_split_persist.hip; experiments build)
         if (!gemm_split3_persist_ok(a)) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM: M % 128 == 0, N % 256 == 0, M / 128 * N / 256 >= 256, K >= 64");
         void* ws = gemm_split3_persist_op_ws(st);
         if (!ws) return fail(e, THMR_ERR_NOMEM, "persistent split3 GEMM: workspace allocation failed");
-        LAUNCH_OK(launch_gemm_split3_persist(a, epi, 0, ws, st));
+        LAUNCH_OK(launch_gemm_split3_persist(a, epi, variant == 300 ? 0 : 10, ws, st));
         return 0;
     }
     if (variant == 202 || variant == 204) {
@@ -1738,21 +1739,21 @@ int thmr_op_gemm_split3_out_split3(const void* A, int64_t lda, const void* W, in
         cs_blk = 1;
         variant -= 1000;
     }
-    if ((variant < -1 || variant > 2) && variant != 4 && variant != 100 && variant != 301 && variant != 302)
-        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 1, 2, 4, 100 (small-M ring kernel), 301 / 302 (persistent workgroups: LDS / swapped-role epilogue)");
+    if ((variant < -1 || variant > 2) && variant != 4 && variant != 100 && variant != 20 && variant != 22 && variant != 302 && variant != 311 && variant != 312)
+        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 2, 302 (persistent workgroups); experiments build: 1, 4, 20, 22, 100 (ring kernel), 311 / 312 (32x32x16 persistent kernel: LDS / swapped-role epilogue)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, nullptr, 0, nullptr, 0, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
     a.c_split = Cs; a.ldcs = ldcs;
     a.cs_blk = cs_blk;
-    if (variant >= 301) {
+    if (variant >= 302) {
 #ifndef THMR_EXPERIMENTS
-        if (variant == 301) return fail(e, THMR_ERR_INVALID, "split3 GEMM: the LDS-epilogue persistent variant exists only in the experiments build");
+        if (variant != 302) return fail(e, THMR_ERR_INVALID, "split3 GEMM: this persistent variant exists only in the experiments build");
 #endif
-        if (epi != EPI_NONE && epi != EPI_BIAS_GELU) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM with split3 output: epilogue must be 0 or 2");
+        if (variant != 302 && epi != EPI_NONE && epi != EPI_BIAS_GELU) return fail(e, THMR_ERR_INVALID, "32x32x16 persistent split3 GEMM with split3 output: epilogue must be 0 or 2");
         if (!gemm_split3_persist_ok(a)) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM: M % 128 == 0, N % 256 == 0, M / 128 * N / 256 >= 256, K >= 64");
         void* ws = gemm_split3_persist_op_ws(static_cast<hipStream_t>(stream));
         if (!ws) return fail(e, THMR_ERR_NOMEM, "persistent split3 GEMM: workspace allocation failed");
-        LAUNCH_OK(launch_gemm_split3_persist(a, epi, variant - 300, ws, static_cast<hipStream_t>(stream)));
+        LAUNCH_OK(launch_gemm_split3_persist(a, epi, variant == 302 ? 2 : variant - 300, ws, static_cast<hipStream_t>(stream)));
         return 0;
     }
 #ifdef THMR_EXPERIMENTS
@@ -1761,7 +1762,7 @@ int thmr_op_gemm_split3_out_split3(const void* A, int64_t lda, const void* W, in
         return 0;
     }
 #else
-    if (variant == 100 || variant == 1 || variant == 4)
+    if (variant == 100 || variant == 1 || variant == 4 || variant >= 20)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: this variant exists only in the experiments build (libtokenhmr_hip_exp.so)");
 #endif
     LAUNCH_OK(launch_gemm_split3(a, epi, variant, static_cast<hipStream_t>(stream)));

@@ -665,9 +665,13 @@ static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStrea
         variant = t128 <= 256 ? 2 : 0;
     }
     switch (variant) {
-        case 0: return launch_split3_cfg<2, 4, 2, 2>(a, epi, s);
-        case 2: return launch_split3_cfg<2, 2, 2, 2>(a, epi, s);
+        // round 4: the product kernels multiply on v_mfma_f32_16x16x32_bf16 (gemm_split16.hip); the 32x32x16 kernels of this file are the
+        // experiments build's variants 20 / 22 (and 1, 4, 3x below) — another grouping of k inside the MFMA, so equal to rounding only
+        case 0: return launch_split16_tiles(a, epi, true, s);
+        case 2: return launch_split16_tiles(a, epi, false, s);
 #ifdef THMR_EXPERIMENTS
+        case 20: return launch_split3_cfg<2, 4, 2, 2>(a, epi, s);
+        case 22: return launch_split3_cfg<2, 2, 2, 2>(a, epi, s);
         case 1: return launch_split3_cfg<2, 2, 2, 4>(a, epi, s);    // 4 waves of 64 x 128: 3 % slower (r3v)
         case 4: return launch_split3_wide(a, epi, s);               // 256 x 256, 4 waves of 128 x 128, 16-deep stages: the same rate (r3ak)
         // experiments on the default tile, EPI_NONE only: 3 = step-0 fragment reads every 2nd MFMA (the first version's schedule);

@@ -1,0 +1,449 @@
+// The split3 GEMM on v_mfma_f32_16x16x32_bf16 — ONE kernel template for both decompositions: one workgroup per tile (any shape, split-K
+// copies of the grid) and 256 persistent workgroups over a tile stream (gemm_split_persist.hip's scheme: a ragged last round split along
+// K, the accumulators handed from one XCD's workgroup to the next through memory).  Same operand format, same LDS stage image and
+// LDS-DMA staging as gemm_split.hip (vit.py:82-87,104-126 are the products it serves).
+//
+// Why another MFMA shape (scripts/micro/mfma_bf16_sustained.hip, profiles/r4j_mfma_bf16_16x16x32_vs_32x32x16_sustained.log).  The split3
+// GEMMs run at the clock the part grants under 256 CUs of back-to-back bf16 MFMAs (1.4-1.5 GHz), so what counts is
+// flops per joule — and on random operand bits the part SUSTAINS 2.09-2.12 PFLOP/s with 16x16x32 against 1.83 with 32x32x16 (register
+// operands), 1.81 against 1.67 with this kernel's 24 fragment reads and 9 LDS-DMA copies per K tile beside them.
+//
+// Wave tile 64 x 64 = 4 x 4 MFMA tiles of 16 x 16; one MFMA consumes a whole 32-deep K tile: lane (l & 15, g = l >> 4) of an operand
+// fragment holds the 16-byte chunk of row l & 15, k-group g — exactly one chunk of the split3 format.  Operand ROLES are swapped for every
+// product (the MFMA's "A" is the weight fragment): an accumulator then holds, per lane, 4 CONSECUTIVE output columns n = 4 g ... 4 g + 3 of
+// output row m = l & 15 — one 16-byte store per accumulator for an fp32 result (a 16-byte load for the residual, the bias), and for a
+// split3 result four v_permlane16_swap per accumulator pair complete the 8-column chunks (lane pairs g, g + 1): no LDS epilogue exists.
+// Per K tile and wave: 96 MFMAs (6 piece products x 16 tiles), 24 ds_read_b128, its share of the LDS-DMA copies, ONE barrier.
+//
+// Schedule of K tile t (LDS buffer t & 1), no VALU instruction in the loop.  Weight fragments are double-buffered in registers (48 x 2),
+// activation fragments roll through one set (48): block mi = 0..3 multiplies activation tile mi with the four weight tiles (24 MFMAs) —
+//   block 0 : + the read of tile t's last activation fragment (its registers were busy until block 3 of tile t - 1); then the barrier:
+//             every wave's copies of tile t + 1 have landed and its reads of buffer t & 1 are done
+//   blocks 1-3 : + the reads of tile t + 1's weight fragments (4 per block) and activation fragments 0-2 (one per block, into the registers
+//             block mi - 1 just left) from the other buffer, and the copies of tile t + 2 into buffer t & 1
+// so every read has at least a block (24 MFMAs + the SIMD partner's) to return and a copy a whole K tile to land.
+// Per output element K is summed tile by tile, per tile the six piece products in the order lh hl mm mh hm hh (each over its 32 k inside one
+// MFMA): the same for every instantiation, decomposition and batch size — bit-identical results among them (tests), and NOT bit-identical to
+// the 32x32x16 kernels of gemm_split.hip (another grouping of k inside the MFMA), which are kept in the experiments build for the A/B.
+#include <map>
+#include <mutex>
+
+#include "common.h"
+#include "gemm_device.h"
+#include "gemm_split_device.h"
+
+namespace {
+
+constexpr int QG = 32;                                     // stream lanes (workgroups) per XCD of the persistent decomposition
+constexpr int QBM = 128;
+constexpr int Q_SLAB = 128 * 256;                          // floats of one raw accumulator tile (128 KB)
+constexpr int Q_NWG = 8 * QG;
+
+struct Ws16 {
+    float* part;        // [8 * QG] slabs: slab (x, i) = the accumulators of the first part of the tile shared by lane i of XCDs x and x + 1
+    unsigned* flag;     // [8 * QG] 0 / 1, set by the producer, cleared by the consumer; [8 * QG] = error word
+};
+
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+// the epilogue arithmetic on the 4 consecutive columns n ... n + 3 of row m a lane holds
+template <int EPI>
+__device__ __forceinline__ f32x4 epi4(const GemmArgs& a, f32x4 v, int m, int n) {
+    if constexpr (EPI == EPI_NONE) return v;
+    f32x4 b;
+    if (n + 3 < a.N) b = *reinterpret_cast<const f32x4*>(a.bias + n);
+    else
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[r] = a.bias[min(n + r, a.N - 1)];
+    v = v + b;
+    if constexpr (EPI == EPI_BIAS_GELU) {
+        const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
+        v = f32x4{g0.x, g0.y, g1.x, g1.y};
+    }
+    if constexpr (EPI == EPI_BIAS_RELU) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+    if constexpr (EPI == EPI_BIAS_RESID) {
+        const float* rp = a.resid + (int64_t)m * a.ldr + n;
+        f32x4 rs;
+        if (n + 3 < a.N && (a.ldr & 3) == 0) rs = *reinterpret_cast<const f32x4*>(rp);
+        else
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rs[r] = n + r < a.N ? rp[r] : 0.f;
+        v = rs + v;
+    }
+    if constexpr (EPI == EPI_BIAS_QSCALE)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (n + r < a.qcols) ? v[r] * a.qscale : v[r];
+    return v;
+}
+
+// WN = waves along N (4: 128 x 256 tile, 8 waves; 2: 128 x 128, 4 waves).  PERSIST: 256 workgroups over a tile stream (WN = 4; M % 128 == 0,
+// N % 256 == 0) instead of one workgroup per (tile, K slice).  ABLK: A is a row-blocked split3 operand (GemmArgs::a_blk).
+// (__launch_bounds__(512) for the 4-wave instantiation too: told that a workgroup has 256 threads hipcc budgets 512 registers per lane,
+// parks fragments in AGPRs and copies them back inside the K loop — ~40 v_accvgpr moves per 192 MFMAs.  A bound of 512 threads = 256
+// registers gives it the 8-wave instantiation's allocation: none.)
+template <int WN, int EPI, bool PERSIST, bool ABLK>
+__global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles_m, int tiles_n, int nwg, Ws16 ws) {
+    constexpr int NW = 2 * WN, BN = WN * 64;
+    constexpr int A_Q = QBM * SLOTS / 64, B_Q = BN * SLOTS / 64;
+    static_assert(A_Q % NW == 0 && B_Q % NW == 0, "tile / waves mismatch");
+    constexpr int A_P = A_Q / NW, B_P = B_Q / NW, NP = A_P + B_P;      // copies per wave and K tile: 3 + 6 (8 waves), 6 + 6 (4 waves)
+    constexpr int A_STAGE = QBM * ROWB, B_STAGE = BN * ROWB;
+    constexpr int A_KSTEP = ABLK ? SLOTS * 512 : ROWB;                 // bytes a K tile advances the A source by
+    static_assert(2 * (A_STAGE + B_STAGE) <= 160 * 1024, "LDS");
+    static_assert(!PERSIST || WN == 4, "the persistent decomposition uses the 128 x 256 tile");
+
+    __shared__ __attribute__((aligned(16))) char smem[2 * (A_STAGE + B_STAGE)];
+    char* As = smem;
+    char* Bs = smem + 2 * A_STAGE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * 64;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nk_all = a.K / SBK;
+
+    // ---- segments: (tile, K tiles [kb, ke), kind 0 whole / 1 first part: store the accumulators / 2 rest: start from stored accumulators)
+    int xcd = 0, ln = 0, j0 = 0, k0 = 0, j1 = 0, k1 = 0, has_pre = 0, has_post = 0, jf0 = 0, nfull = 1, nseg = 1;
+    int pt_tile = 0, pt_kb = 0, pt_ke = nk_all;                        // the one segment of the per-tile decomposition
+    if constexpr (PERSIST) {
+        xcd = blockIdx.x & 7;
+        ln = blockIdx.x >> 3;
+        const int T = (tiles_m * tiles_n - ln + QG - 1) / QG;          // >= 8 (launcher): a range is at least one tile long
+        const int S0 = (int)((int64_t)xcd * T * nk_all / 8), S1 = (int)((int64_t)(xcd + 1) * T * nk_all / 8);
+        j0 = S0 / nk_all; k0 = S0 - j0 * nk_all;
+        j1 = (S1 - 1) / nk_all; k1 = S1 - j1 * nk_all;
+        has_pre = k1 < nk_all ? 1 : 0;
+        has_post = k0 > 0 ? 1 : 0;
+        jf0 = j0 + has_post;
+        nfull = max(j1 - has_pre - jf0 + 1, 0);
+        nseg = has_pre + nfull + has_post;
+    } else {
+        int logical = logical_block(nwg, 0);
+        if (a.ksplit > 1) {      // copy ksp of the tile grid reduces K slice ksp into part[ksp] (raw, no epilogue)
+            const int tiles = tiles_m * tiles_n, ksp = logical / tiles;
+            logical -= ksp * tiles;
+            const int nks = nk_all / a.ksplit;
+            pt_kb = ksp * nks;
+            pt_ke = pt_kb + nks;
+            a.C += (int64_t)ksp * a.M * a.ldc;
+        }
+        pt_tile = logical;
+    }
+    auto seg_of = [&](int n, int& j, int& kb, int& ke, int& kind) {
+        if constexpr (PERSIST) {
+            const int m = n - has_pre;
+            if (has_pre && n == 0) { j = j1; kb = 0; ke = k1; kind = 1; }
+            else if (m < nfull) { j = jf0 + m; kb = 0; ke = nk_all; kind = 0; }
+            else { j = j0; kb = k0; ke = nk_all; kind = 2; }
+        } else {
+            j = pt_tile; kb = pt_kb; ke = pt_ke; kind = 0;
+        }
+    };
+    auto tile_of = [&](int j, int& bm0, int& bn0) {
+        int tm, tn;
+        tile_coords(tiles_m, tiles_n, PERSIST ? j * QG + ln : j, tm, tn);
+        bm0 = __builtin_amdgcn_readfirstlane(tm * QBM);
+        bn0 = __builtin_amdgcn_readfirstlane(tn * BN);
+    };
+
+    // ---- copies: wave instruction q = wave + i NW of an operand fills LDS chunks 64 q ... 64 q + 63 of its stage (rows past the edge clamped)
+    const int64_t arow = a.lda * 6, wrow = a.ldw * 6;
+    uint32_t Aoff[A_P], Woff[B_P];
+    auto set_offsets = [&](int bm0, int bn0) {
+#pragma unroll
+        for (int i = 0; i < A_P; ++i) {
+            const int c = (wave + i * NW) * 64 + lane;
+            if constexpr (ABLK) {
+                const int row = (c / 384) * 32 + (c & 31), rg = min(bm0 + row, a.M - 1) - bm0;
+                Aoff[i] = (uint32_t)(rg >> 5) * (uint32_t)(a.lda * 192) + (uint32_t)((c % 384) >> 5) * 512u + (uint32_t)(rg & 31) * 16u;
+            } else {
+                const int row = c / SLOTS, slot = c - row * SLOTS;
+                Aoff[i] = (uint32_t)(min(bm0 + row, a.M - 1) - bm0) * (uint32_t)arow + (uint32_t)((slot + SLOTS - ((row >> 2) & 3)) % SLOTS) * 16u;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_P; ++i) {
+            const int c = (wave + i * NW) * 64 + lane, row = c / SLOTS, slot = c - row * SLOTS;
+            Woff[i] = (uint32_t)(min(bn0 + row, a.N - 1) - bn0) * (uint32_t)wrow + (uint32_t)((slot + SLOTS - ((row >> 2) & 3)) % SLOTS) * 16u;
+        }
+    };
+    // fetch cursor: the K tile the NEXT copy brings in (two ahead of the multiply), wave-uniform
+    int fn = 0, fk = 0, fke = 0;
+    const char *fA = nullptr, *fW = nullptr;
+    auto fetch_seg = [&](int n) {
+        int j, kb, ke, kind, bm0, bn0;
+        seg_of(n, j, kb, ke, kind);
+        tile_of(j, bm0, bn0);
+        fk = kb;
+        fke = ke;
+        fA = reinterpret_cast<const char*>(a.A) + (int64_t)bm0 * arow + (int64_t)kb * A_KSTEP;
+        fW = reinterpret_cast<const char*>(a.W) + (int64_t)bn0 * wrow + (int64_t)kb * ROWB;
+    };
+    auto fetch_advance = [&]() {
+        if (fk + 1 < fke) { ++fk; fA += A_KSTEP; fW += ROWB; }
+        else if (PERSIST && fn + 1 < nseg) fetch_seg(++fn);
+        // else: past the end: the last K tile is copied again, into a buffer nobody reads any more
+    };
+    auto dma_piece = [&](int buf, int p) {
+        if (p < A_P) dma16_saddr(fA, Aoff[p], lds_addr_b(As + buf * A_STAGE + (wave + p * NW) * 1024));
+        else dma16_saddr(fW, Woff[p - A_P], lds_addr_b(Bs + buf * B_STAGE + (wave + (p - A_P) * NW) * 1024));
+    };
+
+    // ---- fragments: lane (l15, g) reads chunk (k-group g, piece pc) of row l15 of a 16-row tile.  Row-major stage image: physical slot
+    // (3 g + pc + rot(row)) % 12, rot(row) = (row >> 2) & 3 = (l15 >> 2) & 3 for every tile (tile offsets are multiples of 16).
+    uint32_t fow[3], foa[3];
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+        fow[pc] = (uint32_t)l15 * ROWB + (uint32_t)((3 * g + pc + ((l15 >> 2) & 3)) % SLOTS) * 16u;
+        foa[pc] = ABLK ? (uint32_t)((3 * g + pc) * 512 + l15 * 16) : fow[pc];
+    }
+    const char* Afr = As + wm0 * ROWB;                                 // (row-blocked A: wm0 / 32 blocks of 12 x 512 bytes — the same offset)
+    const char* Bfr = Bs + wn0 * ROWB;
+    bf16x8 af[4][3], wf[2][4][3];                                      // activation fragments (rolling), weight fragments of this / the next K tile
+    auto read_a = [&](int buf, int mi, int pc) {
+        const int off = ABLK ? (mi >> 1) * (SLOTS * 512) + (mi & 1) * 256 : mi * 16 * ROWB;
+        af[mi][pc] = *reinterpret_cast<const bf16x8*>(Afr + buf * A_STAGE + off + foa[pc]);
+    };
+    auto read_w = [&](int buf, int set, int ni, int pc) {
+        wf[set][ni][pc] = *reinterpret_cast<const bf16x8*>(Bfr + buf * B_STAGE + ni * 16 * ROWB + fow[pc]);
+    };
+    f32x4 acc[4][4];
+
+    // one K tile out of buffer `buf` (weight fragment set `buf`)
+    constexpr int NRB = 3 + 4;                                         // reads per block 1-3: one activation tile (3 pieces) + 4 weight fragments
+    constexpr int DB = (NP + 2) / 3;                                   // copies per block 1-3
+    static_assert(NRB + DB <= 24, "block too small for the staging interleave");
+    auto ktile = [&](auto bufc) {
+        constexpr int buf = decltype(bufc){};
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+            for (int p = 0; p < NPROD; ++p)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int idx = p * 4 + ni;
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[buf][ni][piece_w(p)], af[mi][piece_a(p)], acc[mi][ni], 0, 0, 0);
+                    bool any = false;
+                    if (mi == 0) {
+                        if (idx < 3) { read_a(buf, 3, idx); any = true; }                       // this tile's last activation fragment
+                    } else {
+                        if (idx < 3) { read_a(buf ^ 1, mi - 1, idx); any = true; }              // next tile: activation tile mi - 1 ...
+                        else if (idx < NRB) {                                                   // ... and 4 of its 12 weight fragments
+                            const int q = (mi - 1) * 4 + (idx - 3);
+                            read_w(buf ^ 1, buf ^ 1, q / 3, q % 3);
+                            any = true;
+                        } else if (idx - NRB < DB && (mi - 1) * DB + (idx - NRB) < NP) {
+                            dma_piece(buf, (mi - 1) * DB + (idx - NRB));                        // the K tile after next, into this buffer
+                            any = true;
+                        }
+                    }
+                    if (any) __builtin_amdgcn_sched_barrier(0);
+                }
+            if (mi == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                dma_wait_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        fetch_advance();
+    };
+    // fill: the first two K tiles of segment n into buffers 0 / 1, every fragment of tile 0 into registers
+    auto fill = [&](int n) {
+        fetch_seg(n);
+        fn = n;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) dma_piece(0, p);
+        fetch_advance();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) dma_piece(1, p);
+        fetch_advance();
+        dma_wait_barrier();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                read_a(0, t, pc);
+                read_w(0, 0, t, pc);
+            }
+    };
+
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ws.part, 0, Q_NWG * Q_SLAB * 4, 0x00020000);
+    const uint32_t slab_lane = (uint32_t)(wave * 16 * 1024 + lane * 16);       // a wave's 16 accumulators of 1 KiB each
+    int pub_pending = 0;         // the slab's stores are issued; the flag goes out after the next K tile's barrier (every wave drained)
+    int par = 0;                 // buffer of the next K tile
+    auto after_tile = [&]() {
+        if constexpr (PERSIST) {
+            if (pub_pending) {
+                if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pub_pending = 0;
+            }
+        }
+    };
+
+    {
+        int j, kb, ke, kind, bm0, bn0;
+        seg_of(0, j, kb, ke, kind);
+        tile_of(j, bm0, bn0);
+        set_offsets(bm0, bn0);          // persistent: M % 128 == 0 and N % 256 == 0, the offsets are the same for every tile
+    }
+    fill(0);
+    for (int n = 0; n < nseg; ++n) {
+        int j, kb, ke, kind, bm0, bn0;
+        seg_of(n, j, kb, ke, kind);
+        tile_of(j, bm0, bn0);
+        if (PERSIST && kind == 2) {
+            // the accumulators of K tiles [0, kb) from lane ln of the previous XCD: one thread polls one word, then sc1 loads
+            if (tid == 0) {
+                unsigned spins = 0;
+                unsigned* f = ws.flag + (xcd - 1) * QG + ln;
+                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 22)) {                        // ~0.5 s: report, never hang
+                        __hip_atomic_store(ws.flag + Q_NWG, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch (stream order)
+            }
+            asm volatile("s_barrier" ::: "memory");
+            const uint32_t base = (uint32_t)((xcd - 1) * QG + ln) * (uint32_t)(Q_SLAB * 4) + slab_lane;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (uint32_t)((mi * 4 + ni) * 1024), 0, 16);
+                    acc[mi][ni] = f32x4{__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])};
+                }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+        int cnt = ke - kb;
+        if (cnt > 0 && par) { ktile(IntC<1>{}); after_tile(); --cnt; par = 0; }
+        for (; cnt >= 2; cnt -= 2) {
+            ktile(IntC<0>{});
+            after_tile();
+            ktile(IntC<1>{});
+            after_tile();
+        }
+        if (cnt) { ktile(IntC<0>{}); after_tile(); par = 1; }
+
+        const int m0 = bm0 + wm0, n0 = bn0 + wn0;
+        if (PERSIST && kind == 1) {
+            // raw accumulators -> slab (xcd, ln), write-through; published after the next K tile's barrier
+            const uint32_t base = (uint32_t)(xcd * QG + ln) * (uint32_t)(Q_SLAB * 4) + slab_lane;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const u32x4 v = {__float_as_uint(acc[mi][ni][0]), __float_as_uint(acc[mi][ni][1]), __float_as_uint(acc[mi][ni][2]),
+                                     __float_as_uint(acc[mi][ni][3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, base + (uint32_t)((mi * 4 + ni) * 1024), 0, 16);
+                }
+            pub_pending = 1;
+        } else if (a.c_split != nullptr) {
+            // the result as a split3 operand: bias + activation, then lanes (g, g + 1) complete each other's 8-column chunks
+            // (v_permlane16_swap of accumulator pair (ni, ni + 1): even g ends with a chunk of tile ni, odd g with one of tile ni + 1)
+            char* cb = reinterpret_cast<char*>(a.c_split);
+            const bool blk = a.cs_blk != 0;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int m = m0 + mi * 16 + l15;
+#pragma unroll
+                for (int ni = 0; ni < 4; ni += 2) {
+                    f32x4 x = epi4<EPI>(a, acc[mi][ni], min(m, a.M - 1), n0 + ni * 16 + 4 * g);
+                    f32x4 y = epi4<EPI>(a, acc[mi][ni + 1], min(m, a.M - 1), n0 + (ni + 1) * 16 + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const u32x2_t sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[r]), __float_as_uint(y[r]), false, false);
+                        x[r] = __uint_as_float(sw.x);
+                        y[r] = __uint_as_float(sw.y);
+                    }
+                    const int n = n0 + (ni + (g & 1)) * 16 + (g & 2) * 4;          // first of this lane's 8 columns
+                    uint32_t H[4], M[4], L[4];
+                    split3_pair(x[0], x[1], H[0], M[0], L[0]);
+                    split3_pair(x[2], x[3], H[1], M[1], L[1]);
+                    split3_pair(y[0], y[1], H[2], M[2], L[2]);
+                    split3_pair(y[2], y[3], H[3], M[3], L[3]);
+                    if (m < a.M && n < a.N) {
+                        *reinterpret_cast<u32x4*>(cb + split3_chunk_off(a.ldcs, m, n >> 3, 0, blk)) = u32x4{H[0], H[1], H[2], H[3]};
+                        *reinterpret_cast<u32x4*>(cb + split3_chunk_off(a.ldcs, m, n >> 3, 1, blk)) = u32x4{M[0], M[1], M[2], M[3]};
+                        *reinterpret_cast<u32x4*>(cb + split3_chunk_off(a.ldcs, m, n >> 3, 2, blk)) = u32x4{L[0], L[1], L[2], L[3]};
+                    }
+                }
+            }
+        } else {
+            const bool vec = (a.ldc & 3) == 0 && ((uintptr_t)a.C & 15) == 0;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int m = m0 + mi * 16 + l15;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int n = n0 + ni * 16 + 4 * g;
+                    const f32x4 v = epi4<EPI>(a, acc[mi][ni], min(m, a.M - 1), n);
+                    if (m < a.M) {
+                        float* cp = a.C + (int64_t)m * a.ldc + n;
+                        if (vec && n + 3 < a.N) *reinterpret_cast<f32x4*>(cp) = v;
+                        else
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (n + r < a.N) cp[r] = v[r];
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no LDS-DMA write may outlive the workgroup's LDS allocation
+    if (pub_pending) {                                                 // (a first part is never a range's last segment; kept for safety)
+        __syncthreads();
+        after_tile();
+    }
+}
+
+template <int WN, int EPI, bool PERSIST, bool ABLK>
+int launch16(const GemmArgs& a, const Ws16& ws, hipStream_t s) {
+    constexpr int BN = WN * 64;
+    const int tiles_m = (a.M + QBM - 1) / QBM, tiles_n = (a.N + BN - 1) / BN;
+    const int nwg = PERSIST ? Q_NWG : tiles_m * tiles_n * (a.ksplit > 1 ? a.ksplit : 1);
+    hipLaunchKernelGGL((gemm_split16_kernel<WN, EPI, PERSIST, ABLK>), dim3(nwg), dim3(2 * WN * 64), 0, s, a, tiles_m, tiles_n, nwg, ws);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int WN, bool PERSIST>
+int dispatch16(const GemmArgs& a, int epi, const Ws16& ws, hipStream_t s) {
+    if (a.a_blk) {      // row-blocked A (fc2's operand): bias + residual, or no epilogue
+        if (epi == EPI_BIAS_RESID) return launch16<WN, EPI_BIAS_RESID, PERSIST, true>(a, ws, s);
+        if (epi == EPI_NONE) return launch16<WN, EPI_NONE, PERSIST, true>(a, ws, s);
+        return -1;
+    }
+    switch (epi) {
+        case EPI_NONE: return launch16<WN, EPI_NONE, PERSIST, false>(a, ws, s);
+        case EPI_BIAS: return launch16<WN, EPI_BIAS, PERSIST, false>(a, ws, s);
+        case EPI_BIAS_GELU: return launch16<WN, EPI_BIAS_GELU, PERSIST, false>(a, ws, s);
+        case EPI_BIAS_RESID: return launch16<WN, EPI_BIAS_RESID, PERSIST, false>(a, ws, s);
+        case EPI_BIAS_QSCALE: return launch16<WN, EPI_BIAS_QSCALE, PERSIST, false>(a, ws, s);
+        default: return -1;
+    }
+}
+
+}  // namespace
+
+// one workgroup per tile (and K slice): wide = 128 x 256 tile on 8 waves, else 128 x 128 on 4.  a.ksplit > 1: raw partial sums (epi must be EPI_NONE)
+int launch_split16_tiles(const GemmArgs& a, int epi, bool wide, hipStream_t s) {
+    if (a.c_split != nullptr && epi == EPI_BIAS_RESID) return -1;
+    const Ws16 none{nullptr, nullptr};
+    return wide ? dispatch16<4, false>(a, epi, none, s) : dispatch16<2, false>(a, epi, none, s);
+}
+
+// 256 persistent workgroups (gemm_split3_persist_ok shapes); ws = gemm_split3_persist_ws_bytes() of zeroed device memory
+int launch_split16_persist(const GemmArgs& a, int epi, void* ws_mem, hipStream_t s) {
+    if (a.c_split != nullptr && epi == EPI_BIAS_RESID) return -1;
+    Ws16 ws;
+    ws.part = reinterpret_cast<float*>(ws_mem);
+    ws.flag = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws_mem) + (size_t)Q_NWG * Q_SLAB * 4);
+    return dispatch16<4, true>(a, epi, ws, s);
+}

@@ -404,8 +404,18 @@ bool gemm_split3_persist_ok(const GemmArgs& a) {
 
 // ws: gemm_split3_persist_ws_bytes() of device memory, ZEROED once when it is allocated (the kernel leaves its flags zero); one launch at
 // a time per workspace.  mode: 0 fp32 output; 1 / 2 split3 output (a.c_split) through LDS / through swapped operand roles.
+// round 4: modes 0 / 2 run gemm_split16.hip's kernel (16x16x32 MFMAs; one epilogue for both outputs); the 32x32x16 kernels of this file are
+// the experiments build's modes 10 (fp32 output) / 11 (split3 output through LDS) / 12 (split3 output, swapped roles)
 int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws_mem, hipStream_t s) {
     if (!gemm_split3_persist_ok(a) || ws_mem == nullptr) return -1;
+    if (mode == 0 || mode == 2) {
+        if ((mode == 0) != (a.c_split == nullptr)) return -1;
+        return launch_split16_persist(a, epi, ws_mem, s);
+    }
+#ifndef THMR_EXPERIMENTS
+    return -1;
+#else
+    mode -= 10;
     if ((mode == 0) != (a.c_split == nullptr) || mode < 0 || mode > 2) return -1;
     if (a.c_split != nullptr && epi == EPI_BIAS_RESID) return -1;
     PersistWs ws;
@@ -426,12 +436,11 @@ int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws_me
     THMR_PERSIST_CASE(EPI_BIAS_GELU, 0)
     THMR_PERSIST_CASE(EPI_BIAS_GELU, 2)
     THMR_PERSIST_CASE(EPI_NONE, 2)
-#ifdef THMR_EXPERIMENTS      // split3 output through the LDS transposition: 796 vs 784 us on the fc1 shape (profiles/r4a_split3_gemm_persistent_b64.jsonl)
-    THMR_PERSIST_CASE(EPI_BIAS_GELU, 1)
+    THMR_PERSIST_CASE(EPI_BIAS_GELU, 1)      // split3 output through the LDS transposition: 796 vs 784 us on the fc1 shape (profiles/r4a_split3_gemm_persistent_b64.jsonl)
     THMR_PERSIST_CASE(EPI_NONE, 1)
-#endif
 #undef THMR_PERSIST_CASE
     return -1;
+#endif  // THMR_EXPERIMENTS
 }
 
 // the workspace's error word (a consumer's bounded spin ran out): 0 = none.  Synchronises the stream.

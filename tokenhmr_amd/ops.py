@@ -69,15 +69,17 @@ def gemm(a, w, bias=None, resid=None, epi="none", qscale=1.0, qcols=0, variant="
 SPLIT3_VARIANT = {"auto": -1, "128x256/w8": 0, "128x256/w4": 1, "128x128/w4": 2, "256x256/w4": 4, "ring": 100, "ring/k2": 101, "ring/k4": 102, "auto/k2": 202, "auto/k4": 204,
                   # 256 persistent workgroups over a tile stream (csrc/gemm_split_persist.hip; M % 128 == 0, N % 256 == 0, >= 256 tiles):
                   # fp32 output / split3 output through the LDS transposition / split3 output through swapped operand roles
-                  "persist": 300, "persist/lds": 301, "persist/swap": 302,
+                  "persist": 300, "persist/swap": 302,
+                  # round-4 first versions on v_mfma_f32_32x32x16_bf16 (the product kernels moved to 16x16x32, csrc/gemm_split16.hip): experiments build
+                  "old/128x256/w8": 20, "old/128x128/w4": 22, "old/persist": 310, "old/persist/lds": 311, "old/persist/swap": 312,
                   # schedule experiments (epilogue "none" only; the abl/* ones are timing-only, their results are garbage)
                   "exp/reads-every-2nd": 3, "abl/no-copies": 31, "abl/no-barrier": 32, "abl/no-reads": 34, "abl/none": 37}
 
 
 # variants that exist only in the experiments build (measured slower or timing-only; csrc/gemm_split.hip, gemm_split_persist.hip): asking
 # for one of them routes THAT call to libtokenhmr_hip_exp.so
-SPLIT3_EXP_ONLY = {"128x256/w4", "256x256/w4", "ring", "ring/k2", "ring/k4", "persist/lds", "exp/reads-every-2nd", "abl/no-copies",
-                   "abl/no-barrier", "abl/no-reads", "abl/none"}
+SPLIT3_EXP_ONLY = {"128x256/w4", "256x256/w4", "ring", "ring/k2", "ring/k4", "exp/reads-every-2nd", "abl/no-copies",
+                   "abl/no-barrier", "abl/no-reads", "abl/none", "old/128x256/w8", "old/128x128/w4", "old/persist", "old/persist/lds", "old/persist/swap"}
 
 
 def _L_for(exp_only):
