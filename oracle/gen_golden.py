@@ -87,12 +87,19 @@ def build_reference(cfg, sd, tok):
 
 
 @torch.no_grad()
-def reference_forward(img, cfg, sd, tok, smpl):
+def reference_forward(img, cfg, sd, tok, smpl, dtype=torch.float32):
+    """dtype = float64: the SAME reference modules evaluated in double precision (`.double()`): the value an fp32 implementation —
+    the reference's own included — approximates.  Used to put a fixture's fp32 rounding noise next to this build's deviation."""
     ns, vit, head, dec, quant = build_reference(cfg, sd, tok)
+    if dtype != torch.float32:
+        for mod in (vit, head, dec, quant):
+            mod.to(dtype)
+        img = img.to(dtype)
+        smpl = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in smpl.items()}
     B = img.shape[0]
     feats = vit(img)                                                        # tokenhmr.py:151
     x = feats.flatten(2).permute(0, 2, 1)                                   # token_head.py:69 (einops rearrange)
-    token = torch.zeros(B, 1, 1)                                            # token_head.py:91
+    token = torch.zeros(B, 1, 1, dtype=dtype)                               # token_head.py:91
     token_out = head.transformer(token, context=x).squeeze(1)               # :95-96
     grot = head.decpose_grot(token_out)                                     # :99
     dp = head.decpose                                                       # token_classifier.py:89-108
@@ -109,7 +116,7 @@ def reference_forward(img, cfg, sd, tok, smpl):
     betas = head.decshape(token_out) + head.init_betas
     cam = head.deccam(token_out) + head.init_cam
     R = ns.geometry.rot6d_to_rotmat(pose6d).view(B, 24, 3, 3)               # :123
-    focal = cfg.focal_length * torch.ones(B, 2)                             # tokenhmr.py:165-169
+    focal = cfg.focal_length * torch.ones(B, 2, dtype=dtype)                # tokenhmr.py:165-169
     cam_t = torch.stack([cam[:, 1], cam[:, 2], 2 * focal[:, 0] / (cfg.img_size * cam[:, 0] + 1e-9)], dim=-1)
     verts, joints = O.smpl_forward(R[:, [0]], R[:, 1:], betas, smpl)        # restated smplx (unpinned)
     kp2d = ns.geometry.perspective_projection(joints, translation=cam_t, focal_length=focal / cfg.img_size)
@@ -189,6 +196,18 @@ def main():
         img = make_inputs(B, seed)
         ref = reference_forward(img, cfg, sd, tok, smpl)
         g = freeze_compact(ref, cfg) if "_b64" in name else freeze(ref, cfg)
+        if "_b64" in name:
+            # the same modules in float64: how far the reference's OWN fp32 result is from the value it approximates, per fixture
+            r64 = reference_forward(img, cfg, sd, tok, smpl, dtype=torch.float64)
+            g["joints_f64"] = r64["joints"].numpy()
+            g["verts_sample_f64"] = r64["verts"][:, ::VERT_STRIDE_B64].numpy()
+            g["token_idx_f64"] = O.token_indices(r64["cls_logits"]).to(torch.int32).numpy()
+            g["ref32_vs_f64"] = np.array([float((ref["joints"].double() - r64["joints"]).abs().max()),
+                                          float((ref["verts"].double() - r64["verts"]).abs().max()),
+                                          float((O.token_indices(ref["cls_logits"]) != O.token_indices(r64["cls_logits"])).sum())])
+            print(f"[{name}] reference fp32 vs the same modules in fp64: joints {g['ref32_vs_f64'][0]:.3e} m, vertices {g['ref32_vs_f64'][1]:.3e} m, "
+                  f"token indices that differ {int(g['ref32_vs_f64'][2])} of {B * cfg.token_num}")
+            del r64
         g["meta"] = np.array([vd, dd, B, seed], dtype=np.int64)
         g["style"] = np.array(style)
         gap = torch.from_numpy(g["top2_gap"])

@@ -123,6 +123,11 @@ struct thmr_engine {
     // the per-tile kernel (THMR_SPLIT3_FC1_MODE)
     void* s3_ws = nullptr;
     int s3_persist = 1, s3_fc1_mode = 2;
+    // The persistent decomposition pays per tile boundary (hand-over slabs, segment bookkeeping, its epilogue's register spills) and wins
+    // the ragged last round: with the 16x16x32 kernel it is the faster one from K = 5120 on (fc2: 671 vs 715 us) and ties or loses at
+    // K = 1280 (qkv 518 vs 515, proj 199 vs 187, fc1 with split3 output 728 vs 702; profiles/r4k_split3_gemm_b64_mfma16.jsonl).
+    // Same bits either way.  THMR_SPLIT3_PERSIST_MIN_K (experiments build) moves the boundary for the A/B.
+    int s3_persist_min_k = 2560;
     bool s3_forced_once = false;      // experiments build: THMR_SPLIT3_FORCE_TIMEOUT=1 was honoured already
     struct SplitW { const char *qkv, *proj, *fc1, *fc2; };
     std::vector<SplitW> vitw_s;
@@ -513,14 +518,16 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         // write their results directly as three bf16 pieces (hs, bs): no conversion pass, no fp32 copy of those activations.
         char* hs = e->split_act;                                    // [M][1280] split3: LayerNorm / attention output
         char* bs = e->split_act + (size_t)M * DIM * 6;              // [M][5120] split3: GELU output
-        // fc1's output = fc2's A in the ROW-BLOCKED form (common.h GemmArgs::a_blk) when both run the persistent kernel — the swapped-role
-        // epilogue then writes 512 contiguous bytes per 32 lanes instead of 64 different lines per instruction (fc1 25.1 -> 23.7 ms per 64-crop
-        // step, profiles/r4f_engine_b64_row_blocked.log).  The per-tile kernels (fewer than 32 crops, odd batches) measured SLOWER with the
-        // blocked form on both sides (profiles/r4f_split3_gemm_b64_row_blocked.jsonl) and keep the row-major one.  Same values either way.
+        // fc1's output = fc2's A in the ROW-BLOCKED form (common.h GemmArgs::a_blk) when fc2 runs the persistent kernel: the epilogue (one output
+        // row per lane) then writes 256-512 contiguous bytes per 16-32 lanes instead of a different line per lane (same box: 830-832 -> 846-848
+        // crops/s at 64 crops, profiles/r4h_row_blocked_ab_same_box_b64.log; with the 16x16x32 kernel fc1 718 -> 702 us and fc2 677 -> 671,
+        // r4k_split3_gemm_b64_mfma16.jsonl).  A per-tile fc2 measured SLOWER with a blocked A (778 vs 715 us) and keeps the row-major form
+        // (fewer than 32 crops, odd batches).  Same values either way.
         int bs_blk = 0;
         {
             GemmArgs t1 = mk(nullptr, DIM, nullptr, DIM, nullptr, nullptr, 0, nullptr, 0, M, MLP, DIM), t2 = mk(nullptr, MLP, nullptr, MLP, nullptr, nullptr, 0, nullptr, 0, M, DIM, MLP);
-            bs_blk = (e->s3_ws && e->s3_persist && e->s3_fc1_mode == 2 && s3_fc2 <= 1 && gemm_split3_persist_ok(t1) && gemm_split3_persist_ok(t2)) ? 1 : 0;
+            (void)t1;
+            bs_blk = (e->s3_ws && e->s3_persist && s3_fc2 <= 1 && MLP >= e->s3_persist_min_k && gemm_split3_persist_ok(t2)) ? 1 : 0;      // fc2 runs the persistent kernel
             static const bool no_blk = [] { const char* k = thmr_knob("THMR_SPLIT3_BS_BLK"); return k && k[0] == '0'; }();      // A/B (experiments build)
             if (no_blk) bs_blk = 0;
         }
@@ -529,7 +536,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             GemmArgs a = mk(reinterpret_cast<const float*>(A), K, reinterpret_cast<const float*>(Wt), K, bias, resid, N, C, N, M, N, K);
             a.qscale = qscale; a.qcols = DIM;
             a.a_blk = a_blk;
-            if (e->s3_ws && e->s3_persist && gemm_split3_persist_ok(a)) return launch_gemm_split3_persist(a, epi, 0, e->s3_ws, st);
+            if (e->s3_ws && e->s3_persist && K >= e->s3_persist_min_k && gemm_split3_persist_ok(a)) return launch_gemm_split3_persist(a, epi, 0, e->s3_ws, st);
             return launch_gemm_split3(a, epi, -1, st);
         };
         {
@@ -563,8 +570,8 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 GemmArgs a = mk(reinterpret_cast<const float*>(hs), DIM, reinterpret_cast<const float*>(ws.fc1), DIM, w.f1b, nullptr, 0, nullptr, 0, M, MLP, DIM);
                 a.c_split = bs; a.ldcs = MLP;
                 a.cs_blk = bs_blk;
-                if (e->s3_ws && e->s3_persist && e->s3_fc1_mode && gemm_split3_persist_ok(a))
-                    LAUNCH_OK(launch_gemm_split3_persist(a, EPI_BIAS_GELU, e->s3_fc1_mode, e->s3_ws, st));
+                if (e->s3_ws && e->s3_persist && e->s3_fc1_mode && DIM >= e->s3_persist_min_k && gemm_split3_persist_ok(a))
+                    LAUNCH_OK(launch_gemm_split3_persist(a, EPI_BIAS_GELU, 2, e->s3_ws, st));
                 else
                     LAUNCH_OK(launch_gemm_split3(a, EPI_BIAS_GELU, -1, st));
             }
@@ -779,7 +786,7 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
             // on the bf16 matrix pipe (1.5 -> 1.0 ms at 64 crops)
             LAUNCH_OK(launch_split3(ctx, DIM, e->split_act, DIM, M, DIM, st));
             GemmArgs a = mk(reinterpret_cast<const float*>(e->split_act), DIM, reinterpret_cast<const float*>(e->kv_s), DIM, nullptr, nullptr, 0, big, ldkv, M, ldkv, DIM);
-            if (e->s3_ws && e->s3_persist && gemm_split3_persist_ok(a)) LAUNCH_OK(launch_gemm_split3_persist(a, EPI_NONE, 0, e->s3_ws, st));
+            if (e->s3_ws && e->s3_persist && DIM >= e->s3_persist_min_k && gemm_split3_persist_ok(a)) LAUNCH_OK(launch_gemm_split3_persist(a, EPI_NONE, 0, e->s3_ws, st));
             else LAUNCH_OK(launch_gemm_split3(a, EPI_NONE, -1, st));
         } else {
             GemmArgs a = mk(ctx, DIM, e->warena + e->o_kv_all, DIM, nullptr, nullptr, 0, big, ldkv, M, ldkv, DIM);
@@ -1136,6 +1143,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* sm = thmr_knob("THMR_SPLIT3_MIN_B"); e->split3_min_b = sm ? atoi(sm) : 0; }
     { const char* sp = thmr_knob("THMR_SPLIT3_PERSIST"); if (sp && sp[0] >= '0' && sp[0] <= '1') e->s3_persist = sp[0] - '0'; }
     { const char* fm = thmr_knob("THMR_SPLIT3_FC1_MODE"); if (fm && fm[0] >= '0' && fm[0] <= '2') e->s3_fc1_mode = fm[0] - '0'; }
+    { const char* mk_ = thmr_knob("THMR_SPLIT3_PERSIST_MIN_K"); if (mk_) e->s3_persist_min_k = atoi(mk_); }
     { const char* ms = thmr_knob("THMR_MID_SPLIT"); if (ms && ms[0] && ms[1]) { e->mid_split_force[0] = ms[0] - '0'; e->mid_split_force[1] = ms[1] - '0'; } }
     { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
     *out = e;

@@ -396,6 +396,25 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles
                 }
             }
         }
+        if constexpr (PERSIST) {
+            // The next tile's fragments were prefetched by the last K tile above; they are read AGAIN here, after the epilogue, so that
+            // they are dead across it: 84 registers the GELU + split3 epilogue otherwise spills around (113-115 scratch registers in the
+            // first build, and the persistent fc1 at 728 us against the per-tile kernel's 702, profiles/r4k_split3_gemm_b64_mfma16.jsonl).
+            // 21 LDS reads per tile; the copies they read landed before the last K tile's barrier.
+            if (n + 1 < nseg) {
+                auto refill = [&](auto bufc) {
+                    constexpr int buf = decltype(bufc){};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) {
+                            if (t < 3) read_a(buf, t, pc);
+                            read_w(buf, buf, t, pc);
+                        }
+                };
+                if (par) refill(IntC<1>{}); else refill(IntC<0>{});
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no LDS-DMA write may outlive the workgroup's LDS allocation
     if (pub_pending) {                                                 // (a first part is never a range's last segment; kept for safety)
