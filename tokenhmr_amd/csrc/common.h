@@ -204,8 +204,9 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& a, float acc, flo
 }
 
 // ---- "split3": an fp32 value as three bf16 pieces h + m + l (gemm_split.hip) ----
-// Round-to-nearest-even bf16 of x (any NaN -> 0x7fc0), integer arithmetic on purpose: v_cvt_pk_bf16_f32 is not bit-identical to the numpy
-// restatement the tests compare with on every input class (NaN payloads, and fp32 denormals depend on the wave's denormal mode).
+// Round-to-nearest-even bf16 of x (any NaN -> 0x7fc0) in integer arithmetic: the form of the stand-alone converter (split3_kernel: weights
+// at load time, ops.split3) and the one the numpy restatement in the tests states.  The producers inside the hot path use split3_pair
+// below (hardware conversion), which differs from it on NaN payloads only.
 // Round 4: the pieces are kept in the HIGH half of a register — (u + 0x7fff + lsb) & 0xffff0000 IS the fp32 value of the rounded piece,
 // so the exact residual needs no shift back, one NaN test serves the three pieces, and two values pack with ONE v_perm_b32: ~15 VALU
 // per value instead of ~24.  In the persistent fc1 kernel the epilogue's VALU is what is left exposed per tile (PMC: 64.6 M vector
@@ -233,14 +234,30 @@ __device__ __forceinline__ void split3_of(float x, uint32_t& h, uint32_t& m, uin
     split3_hi(x, H, M, L);
     h = H >> 16; m = M >> 16; l = L >> 16;
 }
-// two values -> three words of the operand format: piece(x0) in the low half, piece(x1) in the high half (v_perm_b32: bytes 2, 3 of each)
+// two values -> three words of the operand format: piece(x0) in the low half, piece(x1) in the high half.  v_cvt_pk_bf16_f32 rounds the
+// pair and packs it in ONE instruction, a shift / a mask give the fp32 value of each piece back, the residuals are one packed subtract:
+// 9 VALU per pair against ~30 for the integer form above.  Bit-identical to it on every zero, denormal, normal and infinity
+// (scripts/micro/bf16_cvt_classes.hip, profiles/r4e_bf16_cvt_classes.jsonl: 524,288 patterns around every rounding boundary); a NaN
+// stays a NaN in all three pieces but keeps payload bits where the integer form writes 0x7fc0.  (Round 4, second pass: with whole-line
+// stores in the row-blocked operand the fc1 epilogue IS bound by its instruction count — 2100 VALU per wave and tile, two waves per SIMD
+// at ~1.45 GHz = 11.6 us of the ~99 us a tile takes; the first attempt at this, profiles/r3z_hw_bf16_cvt_ab.log, was store-bound.)
+// (The conversion goes through the compiler — fptrunc <2 x float> to <2 x bfloat> — not through inline asm: gfx950 needs a wait state
+// between a packed-fp32 VALU result and its use by the next VALU instruction, which hipcc inserts (s_nop 0) only around instructions it
+// can see.  The asm form read stale registers right behind the GELU's v_pk_mul_f32: profiles/r4m_pytest_ops_inline_asm_hazard.log.
+// Contraction is off in here: r = x - h must subtract from the ROUNDED x the pieces' consumers see, not from the product that made it.)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
 __device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& H, uint32_t& M, uint32_t& L) {
-    uint32_t h0, m0, l0, h1, m1, l1;
-    split3_hi(x0, h0, m0, l0);
-    split3_hi(x1, h1, m1, l1);
-    H = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
-    M = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
-    L = __builtin_amdgcn_perm(l1, l0, 0x07060302u);
+#pragma clang fp contract(off)
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    H = cvt_pk_bf16(x0, x1);
+    f32x2_t r = f32x2_t{x0, x1} - f32x2_t{__uint_as_float(H << 16), __uint_as_float(H & 0xffff0000u)};      // exact
+    M = cvt_pk_bf16(r.x, r.y);
+    r = r - f32x2_t{__uint_as_float(M << 16), __uint_as_float(M & 0xffff0000u)};                            // exact
+    L = cvt_pk_bf16(r.x, r.y);
 }
 // 4 consecutive columns c ... c + 3 (c % 4 == 0) of one row of a split3 operand [rows][D/8][3][8]: the 8-byte half (c & 4) of the three
 // chunks of k-group c / 8.  `row` points at the row's first byte.

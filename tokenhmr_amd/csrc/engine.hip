@@ -123,11 +123,12 @@ struct thmr_engine {
     // the per-tile kernel (THMR_SPLIT3_FC1_MODE)
     void* s3_ws = nullptr;
     int s3_persist = 1, s3_fc1_mode = 2;
-    // The persistent decomposition pays per tile boundary (hand-over slabs, segment bookkeeping, its epilogue's register spills) and wins
-    // the ragged last round: with the 16x16x32 kernel it is the faster one from K = 5120 on (fc2: 671 vs 715 us) and ties or loses at
-    // K = 1280 (qkv 518 vs 515, proj 199 vs 187, fc1 with split3 output 728 vs 702; profiles/r4k_split3_gemm_b64_mfma16.jsonl).
-    // Same bits either way.  THMR_SPLIT3_PERSIST_MIN_K (experiments build) moves the boundary for the A/B.
-    int s3_persist_min_k = 2560;
+    // Which GEMMs run the persistent decomposition: bit 0 qkv, 1 proj, 2 fc1, 3 fc2, 4 the decoder's to_kv.  It pays per tile boundary
+    // (hand-over slabs, segment bookkeeping, register spills around its epilogue) and wins the ragged last round: with the 16x16x32
+    // kernel it is the faster one for fc2 (K = 5120: 671 vs 715 us) and ties or loses at K = 1280 (qkv 518 vs 515, proj 199 vs 187,
+    // fc1 with split3 output 728 vs 702; profiles/r4k_split3_gemm_b64_mfma16.jsonl; whole path 834 vs 822 crops/s with all four,
+    // profiles/r4l_engine_b64_persist_min_k_ab.log).  Same bits either way.  THMR_SPLIT3_PERSIST_MASK (experiments build) for the A/B.
+    int s3_persist_mask = 8;
     bool s3_forced_once = false;      // experiments build: THMR_SPLIT3_FORCE_TIMEOUT=1 was honoured already
     struct SplitW { const char *qkv, *proj, *fc1, *fc2; };
     std::vector<SplitW> vitw_s;
@@ -527,7 +528,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         {
             GemmArgs t1 = mk(nullptr, DIM, nullptr, DIM, nullptr, nullptr, 0, nullptr, 0, M, MLP, DIM), t2 = mk(nullptr, MLP, nullptr, MLP, nullptr, nullptr, 0, nullptr, 0, M, DIM, MLP);
             (void)t1;
-            bs_blk = (e->s3_ws && e->s3_persist && s3_fc2 <= 1 && MLP >= e->s3_persist_min_k && gemm_split3_persist_ok(t2)) ? 1 : 0;      // fc2 runs the persistent kernel
+            bs_blk = (e->s3_ws && e->s3_persist && s3_fc2 <= 1 && (e->s3_persist_mask & 8) && gemm_split3_persist_ok(t2)) ? 1 : 0;      // fc2 runs the persistent kernel
             static const bool no_blk = [] { const char* k = thmr_knob("THMR_SPLIT3_BS_BLK"); return k && k[0] == '0'; }();      // A/B (experiments build)
             if (no_blk) bs_blk = 0;
         }
@@ -536,7 +537,8 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             GemmArgs a = mk(reinterpret_cast<const float*>(A), K, reinterpret_cast<const float*>(Wt), K, bias, resid, N, C, N, M, N, K);
             a.qscale = qscale; a.qcols = DIM;
             a.a_blk = a_blk;
-            if (e->s3_ws && e->s3_persist && K >= e->s3_persist_min_k && gemm_split3_persist_ok(a)) return launch_gemm_split3_persist(a, epi, 0, e->s3_ws, st);
+            const int bit = cls == THMR_PROF_GEMM_QKV ? 1 : cls == THMR_PROF_GEMM_PROJ ? 2 : cls == THMR_PROF_GEMM_FC2 ? 8 : 0;
+            if (e->s3_ws && e->s3_persist && (e->s3_persist_mask & bit) && gemm_split3_persist_ok(a)) return launch_gemm_split3_persist(a, epi, 0, e->s3_ws, st);
             return launch_gemm_split3(a, epi, -1, st);
         };
         {
@@ -570,7 +572,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 GemmArgs a = mk(reinterpret_cast<const float*>(hs), DIM, reinterpret_cast<const float*>(ws.fc1), DIM, w.f1b, nullptr, 0, nullptr, 0, M, MLP, DIM);
                 a.c_split = bs; a.ldcs = MLP;
                 a.cs_blk = bs_blk;
-                if (e->s3_ws && e->s3_persist && e->s3_fc1_mode && DIM >= e->s3_persist_min_k && gemm_split3_persist_ok(a))
+                if (e->s3_ws && e->s3_persist && e->s3_fc1_mode && (e->s3_persist_mask & 4) && gemm_split3_persist_ok(a))
                     LAUNCH_OK(launch_gemm_split3_persist(a, EPI_BIAS_GELU, 2, e->s3_ws, st));
                 else
                     LAUNCH_OK(launch_gemm_split3(a, EPI_BIAS_GELU, -1, st));
@@ -786,7 +788,7 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
             // on the bf16 matrix pipe (1.5 -> 1.0 ms at 64 crops)
             LAUNCH_OK(launch_split3(ctx, DIM, e->split_act, DIM, M, DIM, st));
             GemmArgs a = mk(reinterpret_cast<const float*>(e->split_act), DIM, reinterpret_cast<const float*>(e->kv_s), DIM, nullptr, nullptr, 0, big, ldkv, M, ldkv, DIM);
-            if (e->s3_ws && e->s3_persist && DIM >= e->s3_persist_min_k && gemm_split3_persist_ok(a)) LAUNCH_OK(launch_gemm_split3_persist(a, EPI_NONE, 0, e->s3_ws, st));
+            if (e->s3_ws && e->s3_persist && (e->s3_persist_mask & 16) && gemm_split3_persist_ok(a)) LAUNCH_OK(launch_gemm_split3_persist(a, EPI_NONE, 0, e->s3_ws, st));
             else LAUNCH_OK(launch_gemm_split3(a, EPI_NONE, -1, st));
         } else {
             GemmArgs a = mk(ctx, DIM, e->warena + e->o_kv_all, DIM, nullptr, nullptr, 0, big, ldkv, M, ldkv, DIM);
@@ -1143,7 +1145,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* sm = thmr_knob("THMR_SPLIT3_MIN_B"); e->split3_min_b = sm ? atoi(sm) : 0; }
     { const char* sp = thmr_knob("THMR_SPLIT3_PERSIST"); if (sp && sp[0] >= '0' && sp[0] <= '1') e->s3_persist = sp[0] - '0'; }
     { const char* fm = thmr_knob("THMR_SPLIT3_FC1_MODE"); if (fm && fm[0] >= '0' && fm[0] <= '2') e->s3_fc1_mode = fm[0] - '0'; }
-    { const char* mk_ = thmr_knob("THMR_SPLIT3_PERSIST_MIN_K"); if (mk_) e->s3_persist_min_k = atoi(mk_); }
+    { const char* mk_ = thmr_knob("THMR_SPLIT3_PERSIST_MASK"); if (mk_) e->s3_persist_mask = atoi(mk_); }
     { const char* ms = thmr_knob("THMR_MID_SPLIT"); if (ms && ms[0] && ms[1]) { e->mid_split_force[0] = ms[0] - '0'; e->mid_split_force[1] = ms[1] - '0'; } }
     { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
     *out = e;

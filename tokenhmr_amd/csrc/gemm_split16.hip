@@ -47,14 +47,17 @@ struct Ws16 {
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 // the epilogue arithmetic on the 4 consecutive columns n ... n + 3 of row m a lane holds
-template <int EPI>
-__device__ __forceinline__ f32x4 epi4(const GemmArgs& a, f32x4 v, int m, int n) {
-    if constexpr (EPI == EPI_NONE) return v;
+__device__ __forceinline__ f32x4 bias4(const GemmArgs& a, int n) {
     f32x4 b;
     if (n + 3 < a.N) b = *reinterpret_cast<const f32x4*>(a.bias + n);
     else
 #pragma unroll
         for (int r = 0; r < 4; ++r) b[r] = a.bias[min(n + r, a.N - 1)];
+    return b;
+}
+template <int EPI>
+__device__ __forceinline__ f32x4 epi4(const GemmArgs& a, f32x4 v, f32x4 b, int m, int n) {
+    if constexpr (EPI == EPI_NONE) return v;
     v = v + b;
     if constexpr (EPI == EPI_BIAS_GELU) {
         const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
@@ -347,44 +350,58 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles
             pub_pending = 1;
         } else if (a.c_split != nullptr) {
             // the result as a split3 operand: bias + activation, then lanes (g, g + 1) complete each other's 8-column chunks
-            // (v_permlane16_swap of accumulator pair (ni, ni + 1): even g ends with a chunk of tile ni, odd g with one of tile ni + 1)
-            char* cb = reinterpret_cast<char*>(a.c_split);
+            // (v_permlane16_swap of accumulator pair (ni, ni + 1): even g ends with a chunk of tile ni, odd g with one of tile ni + 1).
+            // One address per lane; the 24 stores sit at offsets that are the same for every lane (row step, row-block step, chunk step).
             const bool blk = a.cs_blk != 0;
+            const int mb = m0 + l15, nb = n0 + (g & 1) * 16 + (g & 2) * 4;         // this lane's first row; first of its 8 columns for ni = 0
+            char* cb = reinterpret_cast<char*>(a.c_split) + split3_chunk_off(a.ldcs, mb, nb >> 3, 0, blk);
+            // mi -> row + 16 mi: row-blocked, 256 bytes inside the 32-row block for odd mi and one block (ld * 192 bytes) per two; row-major 16 rows
+            const int64_t step_m1 = blk ? 256 : a.ldcs * 96, step_m2 = blk ? a.ldcs * 192 : a.ldcs * 192;
+            const int step_n = blk ? 4 * 3 * 512 : 4 * 48, step_p = blk ? 512 : 16;            // ni -> + 32 columns = 4 k-groups; piece
+            f32x4 bv[4];                                  // the bias of this lane's columns, once (the stores below would force a reload per row tile)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bv[ni] = EPI == EPI_NONE ? f32x4{0.f, 0.f, 0.f, 0.f} : bias4(a, n0 + ni * 16 + 4 * g);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                const int m = m0 + mi * 16 + l15;
+                const int m = mb + mi * 16, mc = min(m, a.M - 1);
+                char* cm = cb + (mi & 1) * step_m1 + (mi >> 1) * step_m2;
 #pragma unroll
                 for (int ni = 0; ni < 4; ni += 2) {
-                    f32x4 x = epi4<EPI>(a, acc[mi][ni], min(m, a.M - 1), n0 + ni * 16 + 4 * g);
-                    f32x4 y = epi4<EPI>(a, acc[mi][ni + 1], min(m, a.M - 1), n0 + (ni + 1) * 16 + 4 * g);
+                    f32x4 x = epi4<EPI>(a, acc[mi][ni], bv[ni], mc, n0 + ni * 16 + 4 * g);
+                    f32x4 y = epi4<EPI>(a, acc[mi][ni + 1], bv[ni + 1], mc, n0 + (ni + 1) * 16 + 4 * g);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const u32x2_t sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[r]), __float_as_uint(y[r]), false, false);
                         x[r] = __uint_as_float(sw.x);
                         y[r] = __uint_as_float(sw.y);
                     }
-                    const int n = n0 + (ni + (g & 1)) * 16 + (g & 2) * 4;          // first of this lane's 8 columns
                     uint32_t H[4], M[4], L[4];
                     split3_pair(x[0], x[1], H[0], M[0], L[0]);
                     split3_pair(x[2], x[3], H[1], M[1], L[1]);
                     split3_pair(y[0], y[1], H[2], M[2], L[2]);
                     split3_pair(y[2], y[3], H[3], M[3], L[3]);
-                    if (m < a.M && n < a.N) {
-                        *reinterpret_cast<u32x4*>(cb + split3_chunk_off(a.ldcs, m, n >> 3, 0, blk)) = u32x4{H[0], H[1], H[2], H[3]};
-                        *reinterpret_cast<u32x4*>(cb + split3_chunk_off(a.ldcs, m, n >> 3, 1, blk)) = u32x4{M[0], M[1], M[2], M[3]};
-                        *reinterpret_cast<u32x4*>(cb + split3_chunk_off(a.ldcs, m, n >> 3, 2, blk)) = u32x4{L[0], L[1], L[2], L[3]};
+                    if (m < a.M && nb + ni * 16 < a.N) {
+                        char* o = cm + (ni >> 1) * step_n;
+                        *reinterpret_cast<u32x4*>(o) = u32x4{H[0], H[1], H[2], H[3]};
+                        *reinterpret_cast<u32x4*>(o + step_p) = u32x4{M[0], M[1], M[2], M[3]};
+                        *reinterpret_cast<u32x4*>(o + 2 * step_p) = u32x4{L[0], L[1], L[2], L[3]};
                     }
                 }
             }
         } else {
             const bool vec = (a.ldc & 3) == 0 && ((uintptr_t)a.C & 15) == 0;
+            f32x4 bv[4];
+            if constexpr (!PERSIST)                       // (the persistent instantiations are short of registers here: they load it per row tile)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) bv[ni] = EPI == EPI_NONE ? f32x4{0.f, 0.f, 0.f, 0.f} : bias4(a, n0 + ni * 16 + 4 * g);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int m = m0 + mi * 16 + l15;
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const int n = n0 + ni * 16 + 4 * g;
-                    const f32x4 v = epi4<EPI>(a, acc[mi][ni], min(m, a.M - 1), n);
+                    if constexpr (PERSIST) bv[ni] = EPI == EPI_NONE ? f32x4{0.f, 0.f, 0.f, 0.f} : bias4(a, n);
+                    const f32x4 v = epi4<EPI>(a, acc[mi][ni], bv[ni], min(m, a.M - 1), n);
                     if (m < a.M) {
                         float* cp = a.C + (int64_t)m * a.ldc + n;
                         if (vec && n + 3 < a.N) *reinterpret_cast<f32x4*>(cp) = v;
