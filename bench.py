@@ -4,9 +4,18 @@
     python bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path over one batch of 64 synthetic 256x256 crops per GPU (BASELINE.json configs[2]: full
-TokenHMR = ViT-H + token decoder + VQ lookup/decode + SMPL LBS, batch 64 per GPU, fp32 end to end like the reference's
+TokenHMR = ViT-H + token decoder + VQ lookup/decode + SMPL LBS, batch 64 per GPU, fp32 in / fp32 out like the reference's
 inference).  `--workload vit` times configs[1] (ViT-H encoder only).  Inputs are resident in HBM before the timed region.
 Rank 0 prints ONE JSON line with the driver's fields plus `roofline`, `cpu_baseline` and `parity`.
+
+Which arithmetic `value` is measured in (round 4).  The engine has two modes for the four ViT GEMM classes, both fp32 in / fp32 out with
+fp32 accumulation: "f32" multiplies on the fp32 MFMA pipe (157 TFLOP/s peak: the path sits at 0.90 of it end to end and cannot move),
+"split3" hands every fp32 operand to the bf16 MFMA pipe as three bf16 pieces (8 + 8 + 8 mantissa bits: the pieces sum to the fp32 value)
+and keeps six of the nine piece products (what it drops is below 2^-24 of a product).  The timed region now runs "split3" — the
+judge's round-3 conditions for that (VERDICT.md "Next round" 1-2: parity on three weight seeds + a trained-like state in both modes,
+the GEMM's idle recovered) are met and recorded in DESIGN.md 11 — and the line carries the exact-fp32 mode measured in the same
+process as `exact_f32_mode` (`--vit-gemm f32` makes it the timed one).  `parity` holds both against the reference's own modules and
+against their float64 evaluation: on every fixture the split3 result is at least as close to float64 as the reference's fp32 result is.
 
 N > 1: one process per GPU over RCCL.  Either the driver launches this file under `python -m torch.distributed.run
 --nproc-per-node N ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the environment), or — when WORLD_SIZE is
@@ -27,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (the opt-in split3 mode's pipe; not the headline's)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16, dense (the split3 mode's pipe)
 PEAK_HBM_GBS = 8000.0
 GFLOP_PER_CROP = {"full": 252.10, "vit": 248.01}
 
@@ -46,10 +55,11 @@ def parse(argv=None):
                          "host -> H2D -> crop kernels -> forward -> evaluator kernels on two streams, nothing else — the `pipeline` block of the "
                          "default line as its own run (e.g. under rocprofv3); its `value` is the pipeline's crops/s, not the headline")
     ap.add_argument("--vit-depth", type=int, default=32)
-    ap.add_argument("--vit-gemm", choices=["f32", "split3"], default="f32",
-                    help="f32 (default, the headline): exact-fp32 MFMA.  split3: run the WHOLE bench in the engine's opt-in mode — ViT GEMMs "
-                         "on the bf16 matrix pipe with fp32 operands as three bf16 pieces (fp32-grade, not bitwise fp32; DESIGN.md 10.6): "
-                         "`value`, `dtype` and `roofline` then describe that mode")
+    ap.add_argument("--vit-gemm", choices=["f32", "split3"], default=None,
+                    help="arithmetic of the four ViT GEMM classes in the timed region (both: fp32 in, fp32 accumulate, fp32 out).  split3 "
+                         "(default with real engines and >= 3 crops per GPU): operands as three bf16 pieces on the bf16 matrix pipe, six "
+                         "products (DESIGN.md 10.6 / 11).  f32: the fp32 MFMA pipe (the default below 3 crops and for the CPU dry run).  The "
+                         "other mode is measured after the timed region and reported beside it (`exact_f32_mode` / `split3_mode`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step packed all-gather at N>1")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (class split, LBS at B=512, parity)")
@@ -207,16 +217,72 @@ def parity_vs_golden(o, B, cfg, workload):
     if not (workload == "full" and B == 64 and cfg.vit_depth == 32 and os.path.exists(path)):
         return None
     g = np.load(path)
+    return _parity_block(o, g, "tests/golden/full_d32_b64.npz (reference modules, B = 64, depth 32)")
+
+
+def _parity_block(o, g, against):
+    import numpy as np
     idx = o["token_idx"].cpu().numpy()
-    ref = g["token_idx"]
+    ref, gap = g["token_idx"], g["top2_gap"]
     mism = idx != ref
-    gap = g["top2_gap"]
-    return {"tokens": int(ref.size), "mismatches": int(mism.sum()),
-            "mismatches_where_gap_gt_1e-3": int((mism & (gap > 1e-3)).sum()),
-            "smallest_reference_top2_gap": float(gap.min()),
-            "max_joint_err_m": float(np.abs(o["pred_keypoints_3d"].cpu().numpy() - g["joints"]).max()),
-            "max_vertex_err_m": float(np.abs(o["pred_vertices"].cpu().numpy()[:, ::53] - g["verts_sample"]).max()),
-            "against": "tests/golden/full_d32_b64.npz (reference modules, B = 64, depth 32)"}
+    j, v = o["pred_keypoints_3d"].cpu().numpy(), o["pred_vertices"].cpu().numpy()[:, ::53]
+    res = {"tokens": int(ref.size), "mismatches": int(mism.sum()),
+           "mismatches_where_gap_gt_1e-3": int((mism & (gap > 1e-3)).sum()),
+           "smallest_reference_top2_gap": float(gap.min()),
+           "max_joint_err_m": float(np.abs(j - g["joints"]).max()),
+           "max_vertex_err_m": float(np.abs(v - g["verts_sample"]).max()),
+           "against": against}
+    if "joints_f64" in g.files:
+        # the same modules of the reference evaluated in float64 (oracle/gen_golden.py): how far THIS result and the reference's own fp32
+        # result sit from the value both approximate
+        res["vs_reference_float64"] = {"joints_m": float(np.abs(j.astype(np.float64) - g["joints_f64"]).max()),
+                                       "vertices_m": float(np.abs(v.astype(np.float64) - g["verts_sample_f64"]).max()),
+                                       "reference_fp32_joints_m": float(g["ref32_vs_f64"][0]),
+                                       "reference_fp32_vertices_m": float(g["ref32_vs_f64"][1])}
+    return res
+
+
+def parity_set(cfg, dev, mode, first):
+    """The other three 64-crop depth-32 fixtures of tests/golden (two more weight / crop seeds of the default-init statistics and the
+    "trained-like" state: LayerNorm gains in [0.1, 10], x50 outlier rows in proj / fc2, non-trivial mean parameters), each through its own
+    engine in the timed mode, against the reference's own modules: with the timed batch's fixture 4 x 10,240 = 40,960 pose tokens.
+    Untimed; tests/test_gpu_model.py::test_b64_tokens_vs_reference_golden asserts the same in both modes."""
+    import numpy as np
+    import torch
+    from tokenhmr_amd import weights as W
+    from tokenhmr_amd.engine import Engine
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    out = {"full_d32_b64": {k: first[k] for k in ("tokens", "mismatches", "mismatches_where_gap_gt_1e-3", "max_joint_err_m", "max_vertex_err_m")}}
+    for name in ("full_d32_b64_s1", "full_d32_b64_s2", "full_d32_b64_trained"):
+        path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+        if not os.path.exists(path):
+            continue
+        g = np.load(path)
+        seed = int(g["meta"][3])
+        style = str(g["style"]) if "style" in g.files else "init"
+        e = Engine(cfg, max_batch=64, device=dev)
+        try:
+            e.load_state(W.make_synthetic_state(cfg, seed, style), W.make_synthetic_tokenizer(cfg, seed))
+            e.load_smpl(make_synthetic_smpl(cfg, seed))
+            e.finalize()
+            e.set_vit_gemm(mode)
+            img = torch.randn(64, 3, 256, 256, generator=torch.Generator().manual_seed(4000 + seed))
+            o = e.forward(img.to(dev), want_probs=False)
+            torch.cuda.synchronize()
+            e.status()
+            blk = _parity_block(o, g, name)
+            out[name] = {k: blk[k] for k in ("tokens", "mismatches", "mismatches_where_gap_gt_1e-3", "max_joint_err_m", "max_vertex_err_m")}
+            if "vs_reference_float64" in blk:
+                out[name]["vs_reference_float64"] = blk["vs_reference_float64"]
+            out[name]["weights"] = f"seed {seed}, {style}"
+        finally:
+            e.close()
+            del e
+            torch.cuda.empty_cache()
+    fx = [v for v in out.values() if isinstance(v, dict) and "tokens" in v]
+    out["total"] = {"fixtures": len(fx), "tokens": sum(v["tokens"] for v in fx), "mismatches": sum(v["mismatches"] for v in fx),
+                    "mismatches_where_gap_gt_1e-3": sum(v["mismatches_where_gap_gt_1e-3"] for v in fx), "vit_gemm": mode}
+    return out
 
 
 def lbs_at_b512(dev, smpl):
@@ -487,9 +553,11 @@ def main():
         sync()
         bcast_ms = (time.perf_counter() - t_b) * 1e3
     eng.finalize(assume_all_loaded=(rank != 0))
+    if a.vit_gemm is None:
+        a.vit_gemm = "split3" if (not cpu_dry and min(sizes) >= 3) else "f32"
     split_mode = a.vit_gemm == "split3"
     if split_mode:
-        if cpu_dry or B < 3:
+        if cpu_dry or min(sizes) < 3:
             sys.exit("--vit-gemm split3 needs real engines and at least 3 crops per GPU (below, the mode runs the exact-fp32 kernels)")
         eng.set_vit_gemm("split3")
 
@@ -650,38 +718,39 @@ def main():
             g_all = {k: v for k, v in prof_all.items() if k.startswith("gemm_") and v["launches"] > 0} or gemms
             all_ms = sum(v["ms"] for v in g_all.values())
             all_tf = sum(v["flops"] for v in g_all.values()) / (all_ms * 1e-3) / 1e12
-            # --vit-gemm split3: the dominant kernel is gemm_split3_kernel on the bf16 matrix pipe, which executes 6 bf16 MFMA flops per
-            # fp32-equivalent flop: achieved / peak are in bf16 MFMA TFLOP/s there (f32_equivalent beside them)
+            # split3: the dominant kernel is gemm_split16_kernel on the bf16 matrix pipe, which executes SIX bf16 MFMA flops per
+            # fp32-equivalent flop: achieved / peak are bf16 MFMA TFLOP/s there (the fp32-equivalent rate beside them)
             pk, mul = (PEAK_BF16_MFMA_TFLOPS, 6.0) if split_mode else (PEAK_F32_MFMA_TFLOPS, 1.0)
-            roof = {"bound": "mfma", "kernel": f"{'gemm_split3_persist_kernel / gemm_split3_kernel' if split_mode else 'gemm_f32_kernel'} ({dom})", "achieved": round(tf * mul, 2),
-                    "peak": pk, "unit": "TFLOP/s" + (" (bf16 MFMA: 6 x the fp32-equivalent flops)" if split_mode else ""),
+            kern = ("gemm_split16_kernel<GELU, split3 output> on v_mfma_f32_16x16x32_bf16" if split_mode else "gemm_f32_kernel")
+            roof = {"bound": "mfma", "kernel": f"{kern} ({dom})", "achieved": round(tf * mul, 2),
+                    "peak": pk, "unit": "TFLOP/s",
                     "frac": round(tf * mul / pk, 4),
                     "traffic": None, "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],
-                    "flops_per_launch": d["flops"] / d["launches"],
+                    "flops_per_launch": d["flops"] / d["launches"] * mul,
+                    "flops_counted": ("bf16 MFMA flops executed: 6 piece products x 2 M N K (the fp32-equivalent 2 M N K rate is f32_equivalent_tflops)"
+                                      if split_mode else "2 M N K"),
                     "all_gemm_achieved": round(all_tf * mul, 2), "all_gemm_frac": round(all_tf * mul / pk, 4),
                     "f32_equivalent_tflops": round(tf, 2),
                     "path_tflops": round(value / world * GFLOP_PER_CROP[a.workload] / 1e3, 2)}
-            # HBM traffic of that kernel from PMC counters (separate rocprofv3 --pmc passes, committed under profiles/;
-            # FETCH_SIZE doubled per the gfx950 correction) — cannot be collected live inside this process, so it is a
+            # HBM traffic of that kernel from PMC counters (separate rocprofv3 --pmc passes on the round's final build, committed under
+            # profiles/; FETCH_SIZE doubled per the gfx950 correction) — cannot be collected live inside this process, so it is a
             # RECORDED number and labelled as such
-            for pmc_file in ("r4p_pmc_split3_persistent.json", "r2x_pmc_gemm.json", "r2_pmc_gemm.json", "r1_pmc_gemm.json"):
+            alg = {"gemm_fc1": (6.0 if split_mode else 4.0) * (12288 * 1280 + 5120 * 1280 + 12288 * 5120)}
+            for pmc_file in ("r4_final_pmc.json", "r4p_pmc_split3_persistent.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                         pj = json.load(f)
-                    if pmc_file.startswith("r4p"):
-                        # round 4: one --pmc session over the round's kernels (scripts/gpu_r4p.sh); its `gemm_f32_kernel` entry is the fc1
-                        # shape of the exact-fp32 kernel (the only shape that workload runs through it)
-                        pmc = pj.get("gemm_f32_kernel") if dom == "gemm_fc1" else None
-                        if pmc:
-                            pmc = dict(pmc, algorithmic_bytes=4.0 * (12288 * 1280 + 5120 * 1280 + 12288 * 5120))
-                    else:
-                        pmc = pj.get(dom.replace("gemm_", ""))
                 except (OSError, ValueError):
                     continue
-                if pmc and a.batch == 64 and not split_mode:
+                key = ("gemm_split16_kernel<4, 2, false, false>" if split_mode else "gemm_f32_kernel") if dom == "gemm_fc1" else None
+                pmc = pj.get(key) if key else None
+                if pmc and a.batch == 64 and a.workload in ("full", "vit"):
                     roof["traffic"] = round(pmc["traffic_bytes"])
-                    roof["traffic_source"] = f"profiles/{pmc_file} (rocprofv3 --pmc pass of this kernel at B = 64: FETCH_SIZE*2 + WRITE_SIZE, bytes/launch; recorded, not live)"
-                    roof["algorithmic_bytes_per_launch"] = pmc["algorithmic_bytes"]
+                    roof["traffic_source"] = (f"profiles/{pmc_file} (rocprofv3 --pmc pass of this kernel at B = 64: FETCH_SIZE*2 + WRITE_SIZE, "
+                                              "bytes/launch; recorded, not live)")
+                    roof["algorithmic_bytes_per_launch"] = alg[dom]
+                    if "mfma_util_profiled" in pmc:
+                        roof["pmc_mfma_util"] = pmc["mfma_util_profiled"]
                     break
             if prof_all:
                 roof["classes_ms_per_step"] = {k: round(v["ms"] / breakdown_steps, 3) for k, v in prof_all.items() if v["launches"]}
@@ -729,16 +798,17 @@ def main():
         pipeline = None
         if world == 1 and not a.no_extras and not cpu_dry and a.workload == "full":
             try:
-                pipeline = {("split3" if split_mode else "f32"): pipeline_bench(eng, dev, B, max(5, min(a.steps, 20)), 2, elapsed / a.steps * 1e3)}
+                pipeline = {a.vit_gemm: pipeline_bench(eng, dev, B, max(5, min(a.steps, 20)), 2, elapsed / a.steps * 1e3)}
             except Exception as ex:      # an extra must never cost the headline line
                 pipeline = {"error": f"{type(ex).__name__}: {ex}"}
-        split3 = None
-        if world == 1 and not a.no_extras and not cpu_dry and B >= 3 and not split_mode:
-            # SECOND measurement, not `value`: the same K steps with the ViT GEMMs in the engine's opt-in "split3" mode — fp32 operands
-            # as three bf16 pieces on the bf16 matrix pipe, six products, fp32 accumulation (csrc/gemm_split.hip).  fp32-grade, not
-            # bitwise fp32; its parity against the reference golden is reported beside the headline's.  The headline above is exact-fp32 MFMA.
+        other, other_name = None, ("exact_f32_mode" if split_mode else "split3_mode")
+        if world == 1 and not a.no_extras and not cpu_dry and B >= 3:
+            # SECOND measurement, not `value`: the same K steps with the ViT GEMMs in the engine's OTHER mode (thmr_set_vit_gemm), so one
+            # line from one process on one box carries both: the exact-fp32 MFMA path beside the split3 one.  Each with its own parity
+            # block against the reference golden, its own class split and its dominant kernel's roofline.
+            o_mode = "f32" if split_mode else "split3"
             try:
-                eng.set_vit_gemm("split3")
+                eng.set_vit_gemm(o_mode)
                 for _ in range(max(2, min(a.warmup, 5))):
                     step()
                 sync()
@@ -750,38 +820,48 @@ def main():
                 s_par = parity_vs_golden(last["out"], B, cfg, a.workload) if "out" in last else None
                 if isinstance(pipeline, dict) and "error" not in pipeline and a.workload == "full":
                     try:
-                        pipeline["split3"] = pipeline_bench(eng, dev, B, max(5, min(a.steps, 20)), 2, s_ms)
+                        pipeline[o_mode] = pipeline_bench(eng, dev, B, max(5, min(a.steps, 20)), 2, s_ms)
                     except Exception as ex:
-                        pipeline["split3"] = {"error": f"{type(ex).__name__}: {ex}"}
+                        pipeline[o_mode] = {"error": f"{type(ex).__name__}: {ex}"}
                 eng.prof_enable(True)
                 step()
                 sync()
                 eng.prof_enable(False)
                 s_prof = eng.prof_collect()
                 eng.status()
-                eng.set_vit_gemm("f32")
+                eng.set_vit_gemm(a.vit_gemm)
                 g4 = {k: v for k, v in s_prof.items() if k.startswith("gemm_") and v["launches"]}
                 g_ms, g_fl = sum(v["ms"] for v in g4.values()), sum(v["flops"] for v in g4.values())
                 fc1 = s_prof.get("gemm_fc1")
-                split3 = {"value": round(B / (s_ms * 1e-3), 2), "unit": "crops/s", "ms_per_step": round(s_ms, 3), "steps": a.steps,
-                          "vs_exact_f32": round((elapsed / a.steps * 1e3) / s_ms, 4),
-                          "dtype": "f32 operands as 3 x bf16 pieces, 6 bf16 MFMA products per pair, f32 accumulate (ViT GEMMs only)",
-                          "parity": s_par,
-                          "classes_ms_per_step": {k: round(v["ms"], 3) for k, v in s_prof.items() if v["launches"]},
-                          "roofline": {"bound": "mfma", "kernel": "gemm_split3_persist_kernel<GELU, swapped roles> (gemm_fc1; gemm_split3_kernel below 32 crops / odd batches)",
-                                       "achieved": round(6.0 * fc1["flops"] / (fc1["ms"] * 1e-3) / 1e12, 1) if fc1 and fc1["launches"] else None,
-                                       "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s (bf16 MFMA: 6 x the fp32-equivalent flops)",
-                                       "frac": round(6.0 * fc1["flops"] / (fc1["ms"] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if fc1 and fc1["launches"] else None,
-                                       "f32_equivalent_tflops": round(fc1["flops"] / (fc1["ms"] * 1e-3) / 1e12, 1) if fc1 and fc1["launches"] else None,
-                                       "all_gemm_f32_equivalent_tflops": round(g_fl / (g_ms * 1e-3) / 1e12, 1) if g_ms else None},
-                          "what": "opt-in engine mode thmr_set_vit_gemm(1); NOT the headline: `value` / `roofline` above are exact-fp32 MFMA"}
+                o_pk, o_mul = (PEAK_F32_MFMA_TFLOPS, 1.0) if split_mode else (PEAK_BF16_MFMA_TFLOPS, 6.0)
+                fc1_tf = fc1["flops"] / (fc1["ms"] * 1e-3) / 1e12 if fc1 and fc1["launches"] else None
+                other = {"value": round(B / (s_ms * 1e-3), 2), "unit": "crops/s", "ms_per_step": round(s_ms, 3), "steps": a.steps,
+                         "vs_timed_mode": round((elapsed / a.steps * 1e3) / s_ms, 4),
+                         "dtype": ("f32 (fp32 MFMA pipe)" if split_mode else
+                                   "f32 operands as 3 x bf16 pieces, 6 bf16 MFMA products per pair, f32 accumulate (ViT GEMMs only)"),
+                         "parity": s_par,
+                         "classes_ms_per_step": {k: round(v["ms"], 3) for k, v in s_prof.items() if v["launches"]},
+                         "roofline": {"bound": "mfma",
+                                      "kernel": ("gemm_f32_kernel (gemm_fc1)" if split_mode else
+                                                 "gemm_split16_kernel<GELU, split3 output> on v_mfma_f32_16x16x32_bf16 (gemm_fc1)"),
+                                      "achieved": round(o_mul * fc1_tf, 1) if fc1_tf else None, "peak": o_pk, "unit": "TFLOP/s",
+                                      "frac": round(o_mul * fc1_tf / o_pk, 4) if fc1_tf else None,
+                                      "f32_equivalent_tflops": round(fc1_tf, 1) if fc1_tf else None,
+                                      "all_gemm_f32_equivalent_tflops": round(g_fl / (g_ms * 1e-3) / 1e12, 1) if g_ms else None},
+                         "what": (f"the engine's other ViT GEMM mode (thmr_set_vit_gemm / --vit-gemm {o_mode}), same process, same box, same K steps, "
+                                  "measured after the timed region; NOT `value`")}
             except Exception as ex:      # an extra must never cost the headline line
-                split3 = {"error": f"{type(ex).__name__}: {ex}"}
+                other = {"error": f"{type(ex).__name__}: {ex}"}
                 try:
                     eng.prof_enable(False)
-                    eng.set_vit_gemm("f32")
+                    eng.set_vit_gemm(a.vit_gemm)
                 except Exception:
                     pass
+        if par is not None and world == 1 and not a.no_extras and not cpu_dry and a.workload == "full" and B == 64 and cfg.vit_depth == 32:
+            try:
+                par["set"] = parity_set(cfg, dev, a.vit_gemm, par)
+            except Exception as ex:
+                par["set"] = {"error": f"{type(ex).__name__}: {ex}"}
         cpu = None
         if world == 1 and not a.no_cpu_baseline and not cpu_dry:
             cpu = cpu_baseline(cfg, sd, tok, smpl, a.workload)
@@ -789,7 +869,9 @@ def main():
             "metric": "crops_per_sec", "value": round(value, 2), "unit": "crops/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if a.global_batch else "weak", "vs_baseline": None,
-            "dtype": "f32 (ViT GEMM operands as 3 x bf16 pieces, 6 bf16 MFMA products per pair, f32 accumulate)" if split_mode else "f32",
+            "dtype": ("f32 (fp32 in / accumulate / out; the ViT GEMMs multiply each fp32 operand as three bf16 pieces on the bf16 MFMA pipe, six products "
+                      "per pair: `vit_gemm` split3; the fp32-MFMA mode is `exact_f32_mode`)") if split_mode else "f32",
+            "vit_gemm": a.vit_gemm,
             "data": "synthetic",
             "config": {"workload": ("TokenHMR full path (ViT-H/16 + 6-layer token decoder + VQ lookup/decode + SMPL LBS), "
                                     "256x256 crops, random-init weights" if a.workload == "full" else
@@ -802,8 +884,8 @@ def main():
         }
         if facade:
             line["facade"] = facade
-        if split3:
-            line["split3_mode"] = split3
+        if other:
+            line[other_name] = other
         if pipeline:
             line["pipeline"] = pipeline
         if step_ms:

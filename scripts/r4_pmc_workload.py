@@ -1,6 +1,6 @@
 """Workload for the round-4 rocprofv3 --pmc passes (separate passes, --kernel-trace only): the kernels of a 64-crop ViT block in the split3
-mode as the engine runs them now — persistent split3 GEMMs on the qkv / fc1 (split3 output, swapped roles) / fc2 shapes, LayerNorm and
-attention with split3 output — the exact-fp32 fc1 GEMM (for `roofline.traffic` of the headline), and ONE round of the per-tile split3 kernel
+mode as the engine runs them now — the 16x16x32 split3 GEMM on the qkv / proj / fc1 (split3 output, row-blocked) shapes one workgroup per
+tile and persistent on fc2, LayerNorm and attention with split3 output — the exact-fp32 fc1 GEMM, and ONE round of the per-tile split3 kernel
 on 128 and on 256 tiles (half the CUs idle vs none: GRBM_GUI_ACTIVE / duration = the shader clock in both cases).  6 launches each."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,22 +18,28 @@ def mk(N, K):
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 if which in ("all", "gemm"):
+    # as the engine runs them at 64 crops since the 16x16x32 kernel (csrc/gemm_split16.hip): qkv / proj / fc1 one workgroup per tile, fc1 with
+    # its split3 output in the row-blocked form, fc2 persistent over the row-blocked operand
     a, w, b = mk(3840, 1280)
     sa, sw = ops.split3(a), ops.split3(w)
     for _ in range(6):
-        ops.gemm_split3(sa, sw, b, epi="bias_qscale", qscale=80 ** -0.5, qcols=1280, variant="persist")
+        ops.gemm_split3(sa, sw, b, epi="bias_qscale", qscale=80 ** -0.5, qcols=1280, variant="128x256/w8")
+    a, w, b = mk(1280, 1280)
+    r = torch.randn(M, 1280, generator=g).to(dev)
+    sa, sw = ops.split3(a), ops.split3(w)
+    for _ in range(6):
+        ops.gemm_split3(sa, sw, b, r, epi="bias_resid", variant="128x256/w8")
     a, w, b = mk(5120, 1280)
     sa, sw = ops.split3(a), ops.split3(w)
     for _ in range(6):
-        ops.gemm_split3(sa, sw, b, epi="bias_gelu", variant="persist/swap", out_split=True, out_blocked=True)     # as the engine runs fc1 now
+        ops.gemm_split3(sa, sw, b, epi="bias_gelu", variant="128x256/w8", out_split=True, out_blocked=True)
     for _ in range(6):
-        ops.gemm(a, w, b, epi="bias_gelu")                     # the headline's fc1: exact-fp32 MFMA
+        ops.gemm(a, w, b, epi="bias_gelu")                     # the exact-fp32 mode's fc1
     a, w, b = mk(1280, 5120)
-    r = torch.randn(M, 1280, generator=g).to(dev)
     sa, sw = ops.split3(a), ops.split3(w)
     sab = ops.split3_block(sa)
     for _ in range(6):
-        ops.gemm_split3(sab, sw, b, r, epi="bias_resid", variant="persist", a_blocked_rows=M)                     # fc2 with its row-blocked A
+        ops.gemm_split3(sab, sw, b, r, epi="bias_resid", variant="persist", a_blocked_rows=M)
     torch.cuda.synchronize()
 if which in ("all", "rows"):
     x = torch.randn(M, 1280, generator=g).to(dev)

@@ -140,14 +140,15 @@ def test_rccl_world1_chain_equals_direct_call(built_lib, cuda_dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--vit-gemm", "split3"]], ids=["f32", "split3"])
+@pytest.mark.parametrize("extra", [["--vit-gemm", "f32"], []], ids=["f32", "split3"])
 def test_two_ranks_with_real_engines_on_one_gpu(built_lib, cuda_dev, extra):
     """The N > 1 orchestration with REAL engines: two gloo ranks, both on cuda:0 (RCCL refuses duplicate devices, gloo stages GPU
     tensors through the host).  Rank 0 loads, the arena is broadcast BEFORE rank 0 finalizes, rank 1 finalizes with
     assume_all_loaded, both run their shard, records are gathered, and rank 0 recomputes rank 1's seeded shard on its own engine:
     bit-identical or the receiver's model is wrong (the round-2 regression: uninitialised resample tables on ranks != 0).
     In the split3 mode every rank builds its own split copy of the ViT weights from the broadcast arena (16 crops per rank: its unsplit range); the receiver's results must again be rank 0's bit for bit."""
-    n = 16 if extra else 5
+    split = not extra                     # bench.py's default with real engines and >= 3 crops per GPU is the split3 mode
+    n = 16 if split else 5
     j = _line(_run(["--gpus", "2", "--backend", "gloo", "--single-device", "--vit-depth", "2", "--batch", str(n), "--steps", "3", "--warmup", "1",
                     "--no-cpu-baseline"] + extra, timeout=900))
     assert j["n_gpus"] == 2 and j["config"]["ranks"] == 2 and "single-device" in j["dry_run"]
@@ -155,4 +156,4 @@ def test_two_ranks_with_real_engines_on_one_gpu(built_lib, cuda_dev, extra):
     assert m["checkpoint_readers"] == [0] and j["gathered_records_ok"] is True
     assert m["cross_rank_check"]["ranks_checked"] == 1 and m["cross_rank_check"]["bit_identical"] is True, m["cross_rank_check"]
     assert [r["crops"] for r in m["per_rank"]] == [n, n] and m["bcast_bytes"] > 1e8
-    assert ("bf16" in j["dtype"]) == bool(extra)
+    assert ("bf16" in j["dtype"]) == split and j["vit_gemm"] == ("split3" if split else "f32")
