@@ -233,6 +233,12 @@ int thmr_op_vit_attention_variant(const float* qkv_dev, float* out_dev, int32_t 
  * order of the key sum), so there it is bit-identical to thmr_op_split3 of thmr_op_vit_attention_variant(..., 6, ...)'s output.
  * What the engine's split3 mode hands the proj GEMM. */
 int thmr_op_vit_attention_split3(const float* qkv_dev, void* out_split_dev, int32_t B, void* stream);
+/* The same attention (vit.py:113-122) on the bf16 matrix pipe: q, k, v and the un-normalised probabilities enter v_mfma_f32_16x16x32_bf16 as
+ * three bf16 pieces each, six products per pair, fp32 accumulate (csrc/attention_b16.hip) — the split3 mode's arithmetic applied to
+ * q k^T and p v; the two 96-key blocks are combined with a running row maximum.  fp32-grade, NOT bit-identical to thmr_op_vit_attention.
+ * out_split = 0: out_dev is fp32 (B,192,1280); 1: the split3 operand [B*192][1280/8][3][8] bf16.  qt = 0: batch-size rule; 1: three
+ * 64-query workgroups per (crop, head); 3: one workgroup of 192 queries (bit-identical to each other and for any B). */
+int thmr_op_vit_attention_b16(const float* qkv_dev, void* out_dev, int32_t B, int32_t out_split, int32_t qt, void* stream);
 /* rot6d_to_rotmat (geometry.py:64-84): (n,6) -> (n,3,3) */
 int thmr_op_rot6d(const float* x_dev, float* R_dev, int32_t n, void* stream);
 /* aa_to_rotmat (geometry.py:5-44; axis-angle -> quaternion -> rotation matrix, the reference's in-tree "Rodrigues" used for

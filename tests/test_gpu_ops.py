@@ -581,6 +581,40 @@ def test_vit_attention_persistent_matches_the_64_query_variant(built_lib, cuda_d
     assert (out[-2:].cpu().double() - ref).abs().max() < 5e-6
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 3, 11, 40])
+def test_vit_attention_b16(built_lib, cuda_dev, B):
+    """The attention on the bf16 matrix pipe (csrc/attention_b16.hip: q, k, v and the un-normalised probabilities as three bf16 pieces, six
+    products per pair, fp32 accumulate; three 64-key blocks combined with a running row maximum) against fp64 with the error class of
+    torch's own fp32 and of the fp32-MFMA kernel; the two workgroup shapes (64 / 192 queries) bit-identical; deterministic; batch-independent;
+    the split3 output = the conversion of the fp32 output; finite and in class on peaked scores (|scores| ~ 100)."""
+    from tokenhmr_amd import ops
+    for scale in (1.0, 6.0):
+        qkv = _rand(B, 192, 3840, seed=300 + B)
+        qkv[:, :, :1280] *= 80 ** -0.5
+        qkv[:, :, :2560] *= scale
+        d = qkv.to(cuda_dev)
+        out = ops.vit_attention_b16(d)
+        assert torch.isfinite(out).all()
+        for qt in (1, 3):
+            assert torch.equal(ops.vit_attention_b16(d, qt=qt), out), qt
+        for _ in range(3):
+            assert torch.equal(ops.vit_attention_b16(d), out)
+        assert torch.equal(ops.vit_attention_b16(d[-1:].contiguous()), out[-1:])
+        assert torch.equal(ops.vit_attention_b16(d, out_split=True), ops.split3(out.reshape(B * 192, 1280)))
+        assert torch.equal(ops.vit_attention_b16(d, out_split=True, qt=1), ops.vit_attention_b16(d, out_split=True, qt=3))
+        n = min(B, 4)
+        t = qkv[:n].reshape(n, 192, 3, 16, 80).permute(2, 0, 3, 1, 4)
+        ref32 = ((t[0] @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]).transpose(1, 2).reshape(n, 192, 1280)
+        t64 = t.double()
+        ref64 = ((t64[0] @ t64[1].transpose(-2, -1)).softmax(-1) @ t64[2]).transpose(1, 2).reshape(n, 192, 1280)
+        err_hip = (out[:n].cpu().double() - ref64).abs().max().item()
+        err_cpu = (ref32.double() - ref64).abs().max().item()
+        err_f32k = (ops.vit_attention(d[:n].contiguous()).cpu().double() - ref64).abs().max().item()
+        print(f"[attention b16 B={B} scale={scale}] max|err| vs fp64: bf16x3 kernel {err_hip:.2e}, fp32-MFMA kernel {err_f32k:.2e}, torch fp32 {err_cpu:.2e}")
+        assert err_hip <= max(4 * err_cpu, 2e-5 if scale > 1 else 5e-6), (scale, err_hip, err_cpu)
+
+
 def test_rot6d(built_lib, cuda_dev):
     from tokenhmr_amd import ops
     from oracle import tokenhmr_oracle as O

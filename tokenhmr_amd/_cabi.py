@@ -119,6 +119,7 @@ def load(exp=None):
     lib.thmr_op_vit_attention.argtypes = [vp, vp, i32, vp]
     lib.thmr_op_vit_attention_variant.argtypes = [vp, vp, i32, i32, vp]
     lib.thmr_op_vit_attention_split3.argtypes = [vp, vp, i32, vp]
+    lib.thmr_op_vit_attention_b16.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.thmr_op_split3.argtypes = [vp, i64, vp, i64, i64, i32, vp]
     lib.thmr_op_gemm_split3.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, f32, i32, i32, vp]
     lib.thmr_op_gemm_split3_out_split3.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, f32, i32, i32, vp]

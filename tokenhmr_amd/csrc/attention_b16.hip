@@ -1,0 +1,334 @@
+// ViT global self-attention on the bf16 matrix pipe: softmax(q k^T) v for one (crop, head) with every fp32 operand multiplied as three
+// bf16 pieces, six products per pair, fp32 accumulate ("split3") — what the ViT GEMMs of the split3 mode do, applied to
+// vit.py:113-122 (Attention.forward between the qkv and proj Linears).  Input / output as attention.hip: qkv (B,192,3840) fp32 with q
+// pre-scaled, out (B,192,1280) fp32 or the split3 operand of the proj GEMM.
+//
+// Why: in the split3 mode the fp32-MFMA attention kernel runs behind the GEMMs at the clock they leave (1.4-1.6 GHz): 129 us per launch
+// at 64 crops, 4.2 of a 73.5 ms step (profiles/r4n_kernel_stats_split3.csv), its matrix work alone 12.1 GFLOP / 157 TFLOP/s = 77 us at
+// full clock.  The same products as 6 x bf16 MFMAs are 72.5 GFLOP per launch on a pipe that sustains 1.4-1.8 PFLOP/s here: 40-50 us.
+//
+// Shape of the work.  v_mfma_f32_16x16x32_bf16: lane (l15 = l & 15, g = l >> 4) of an operand holds the 8 bf16 of row / column l15,
+// k = 8 g ... 8 g + 7 (one 16-byte register quad); the result D[i = 4 g + r][j = l15] in register r.
+//   S^T = K Q^T : A = K fragment (i = key, k = d), B = Q fragment (k = d, j = query).  d = 80 is three k steps of 32, the last one
+//                 half empty (zero columns in the K image, zero registers in Q).  As in attention.hip the transposed product leaves a
+//                 query's scores in 4 lanes x registers: s[qt][kt][r] = S[query 16 qt + l15][key 16 kt + 4 g + r].
+//   O^T = V^T P^T : A = V^T fragment (i = d, k = key), B = P (k = key, j = query).  A k step is 32 keys = two score tiles: the lane's 8
+//                 k slots are {tile 2 st: 4 g + r} then {tile 2 st + 1: 4 g + r} — its OWN score registers, split into pieces in place; the
+//                 V^T image stores a key at the slot that order implies.  Each lane ends with 4 consecutive d of one query (16-byte stores).
+// A workgroup = 4 waves x QT tiles of 16 queries; K and V are staged per BLOCK of 96 keys as bf16 pieces in ONE 60 KB LDS image
+// (K block: [piece][key][96 d], V block: [piece][d][96 key slots], rows of 208 bytes: 16 consecutive rows start at 16 distinct multiples
+// of 4 banks, so both fragment reads are conflict-free ds_read_b128) — two workgroups per CU, one's load / split / softmax phases under
+// the other's MFMAs.  The two key blocks are combined the flash-attention way (running row maximum, accumulators rescaled once):
+// the scores of a block live in 24 QT registers instead of 48 QT for the whole row, which is what lets Q pieces, P pieces, the output
+// accumulators and a block of loads in flight fit 256 registers.  global -> registers -> split3_pair (v_cvt_pk_bf16_f32) -> ds_write:
+// LDS-DMA cannot convert, and a split3 q / k / v from the qkv GEMM would cost its epilogue +50 % stores for operands read once.
+//
+// Per query the instruction sequence does not depend on QT, the grid or the batch size: QT = 3 (one workgroup per (crop, head)) and
+// QT = 1 (three workgroups of 64 queries: few crops) are bit-identical.  NOT bit-identical to attention.hip (fp32 products there,
+// 2^-24-truncated six-product sums here; another order of the key sum): the split3 mode's own attention, same error class as its GEMMs.
+#include "common.h"
+#include "attention_device.h"
+#include "gemm_split_device.h"
+
+namespace {
+
+constexpr int KB = 64;                   // keys per block (3 blocks)
+constexpr int NBLK = NTOK / KB;
+constexpr int KRS = 208;                 // K image row stride, bytes: 96 d x 2 (80 + 16 zero columns) + 16 pad
+constexpr int VRS = 144;                 // V^T image row stride, bytes: 64 key slots x 2 + 16 pad
+constexpr int KPL = KB * KRS;            // one piece plane of the K image: [64 keys][96 d]
+constexpr int VPL = HD * VRS;            // one piece plane of the V^T image: [80 d][64 key slots]
+constexpr int K_IMG = 3 * KPL, V_IMG = 3 * VPL;          // 39,936 + 34,560 bytes: two workgroups per CU
+constexpr float LOG2E_F = 1.44269504088896340736f;
+
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bf16x8 pieces8(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    return __builtin_bit_cast(bf16x8, u32x4{a, b, c, d});
+}
+
+// QT = 16-query tiles per wave: 3 = one workgroup per (crop, head), 1 = three workgroups of 64 queries.
+template <int QT, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* __restrict__ qkv, float* __restrict__ out) {
+    constexpr int QB = 3 / QT;
+    static_assert(QT == 1 || QT == 3, "192 queries = QB workgroups x 4 waves x QT tiles of 16");
+    __shared__ __attribute__((aligned(16))) char smem[K_IMG + V_IMG];
+    char* const kimg = smem;
+    char* const vimg = smem + K_IMG;
+    // XCD-aware order (attention.hip): workgroup b runs on XCD b % 8; the logical index walks each XCD's share contiguously, so the 16
+    // heads of a crop stream its 15 KB token rows through ONE L2
+    int logical;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, within = blockIdx.x >> 3, q = nwg >> 3, r = nwg & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int bh = logical / QB, qb = logical - bh * QB;
+    const int b = bh / NH, h = bh % NH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int q0 = (qb * 4 + wave) * 16 * QT;
+
+    // ---- global -> registers: buffer loads = {this crop's rows as the resource} + {wave-uniform SGPR offset} + {ONE 32-bit per-lane offset}.
+    //      (Plain pointers: hipcc folds uniform pointer + lane offset + constant into a 64-bit VGPR address per load: 16 registers a batch.) ----
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qkv + (int64_t)b * NTOK * QKV_LD), 0, NTOK * QKV_LD * 4, 0x00020000);
+    const int hcol = __builtin_amdgcn_readfirstlane(h * HD);
+    auto ld4 = [&](int uoff_floats, uint32_t off) {        // qkv[crop b][uoff_floats + off / 4 ... + 3], uoff wave-uniform
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, uoff_floats * 4, 0);
+        return f32x4{__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])};
+    };
+    auto ld1 = [&](int uoff_floats, uint32_t off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, uoff_floats * 4, 0)); };
+
+    // ---- staging roles (all 256 threads, 20 registers a block).
+    //      K block: thread (key tid >> 2, part tid & 3) takes the 4-d groups part + 4 m, m = 0..4, of its key.
+    //      V block: thread (key quad kq = tid >> 4, dg = tid & 15) takes d = dg + 16 m, m = 0..4, of keys 4 kq ... 4 kq + 3.  A k step of P.V is
+    //      32 keys: slot 8 gk + 4 a + r of the step <-> key 16 a + 4 gk + r (the lane's own score registers of two 16-key tiles). ----
+    const int kkey = tid >> 2, kpart = tid & 3;
+    const int vkq = tid >> 4, vdg = tid & 15;
+    const uint32_t koff = (uint32_t)(kkey * QKV_LD + kpart * 4) * 4u;
+    const uint32_t voff = (uint32_t)(vkq * 4 * QKV_LD + vdg) * 4u;
+    const uint32_t qoff = (uint32_t)(l15 * QKV_LD + g * 8) * 4u;
+    char* const kdst = kimg + kkey * KRS + kpart * 8;
+    char* const vdst = vimg + vdg * VRS + 2 * (32 * (vkq >> 3) + 8 * (vkq & 3) + 4 * ((vkq >> 2) & 1));
+    f32x4 kr[5];
+    float vr[5][4];
+    auto load_k = [&](int blk) {
+        const int ub = hcol + DIM + blk * KB * QKV_LD;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) kr[m] = ld4(ub + m * 16, koff);
+    };
+    auto write_k = [&]() {
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            uint32_t H[2], M[2], L[2];
+            split3_pair(kr[m][0], kr[m][1], H[0], M[0], L[0]);
+            split3_pair(kr[m][2], kr[m][3], H[1], M[1], L[1]);
+            char* o = kdst + m * 32;
+            *reinterpret_cast<u32x2v*>(o) = u32x2v{H[0], H[1]};
+            *reinterpret_cast<u32x2v*>(o + KPL) = u32x2v{M[0], M[1]};
+            *reinterpret_cast<u32x2v*>(o + 2 * KPL) = u32x2v{L[0], L[1]};
+        }
+    };
+    auto load_v = [&](int blk) {
+        const int ub = hcol + 2 * DIM + blk * KB * QKV_LD;
+#pragma unroll
+        for (int m = 0; m < 5; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vr[m][r] = ld1(ub + r * QKV_LD + m * 16, voff);
+    };
+    auto write_v = [&]() {
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            uint32_t H[2], M[2], L[2];
+            split3_pair(vr[m][0], vr[m][1], H[0], M[0], L[0]);
+            split3_pair(vr[m][2], vr[m][3], H[1], M[1], L[1]);
+            char* o = vdst + m * 16 * VRS;
+            *reinterpret_cast<u32x2v*>(o) = u32x2v{H[0], H[1]};
+            *reinterpret_cast<u32x2v*>(o + VPL) = u32x2v{M[0], M[1]};
+            *reinterpret_cast<u32x2v*>(o + 2 * VPL) = u32x2v{L[0], L[1]};
+        }
+    };
+
+    // ---- Q pieces of k step s: B operand of S^T = K Q^T, lane (query l15, g) holds d = 32 s + 8 g ... + 7 (nothing past d = 79) ----
+    f32x4 qraw[QT][2];
+    auto load_q = [&](int s) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const int ub = hcol + (q0 + qt * 16) * QKV_LD + s * 32;
+            if (s < 2 || g < 2) {
+                qraw[qt][0] = ld4(ub, qoff);
+                qraw[qt][1] = ld4(ub + 4, qoff);
+            } else {
+                qraw[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                qraw[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    bf16x8 qf[QT][3];
+    auto split_q = [&]() {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            uint32_t H[4], M[4], L[4];
+            split3_pair(qraw[qt][0][0], qraw[qt][0][1], H[0], M[0], L[0]);
+            split3_pair(qraw[qt][0][2], qraw[qt][0][3], H[1], M[1], L[1]);
+            split3_pair(qraw[qt][1][0], qraw[qt][1][1], H[2], M[2], L[2]);
+            split3_pair(qraw[qt][1][2], qraw[qt][1][3], H[3], M[3], L[3]);
+            qf[qt][0] = pieces8(H[0], H[1], H[2], H[3]);
+            qf[qt][1] = pieces8(M[0], M[1], M[2], M[3]);
+            qf[qt][2] = pieces8(L[0], L[1], L[2], L[3]);
+        }
+    };
+
+    f32x4 o[QT][5];
+    float lsum[QT], cneg[QT];            // per-lane partial row sums; -(running row maximum) log2 e
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        lsum[qt] = 0.f;
+        cneg[qt] = 3.0e38f;              // "no maximum yet": the first block's rescale factor is 2^(-huge) = 0 on sums and outputs that are 0
+    }
+
+    const char* const kfr = kimg + l15 * KRS + g * 16;   // K fragment of (tile kt, step s): + kt * 16 * KRS + s * 64 (+ plane)
+    const char* const vfr = vimg + l15 * VRS + g * 16;   // V^T fragment of (tile dt, step st): + dt * 16 * VRS + st * 64 (+ plane)
+
+    load_k(0);
+    load_q(0);
+    // d = 80 ... 95 of every row of the K image are zero, once: 3 x 64 rows x 2 chunks of 16 bytes
+    for (int idx = tid; idx < 3 * KB * 2; idx += 256) {
+        const int pl = idx / (2 * KB), rem = idx - pl * (2 * KB);
+        *reinterpret_cast<u32x4*>(kimg + pl * KPL + (rem >> 1) * KRS + 160 + (rem & 1) * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+    write_k();
+    __syncthreads();
+
+#pragma unroll 1
+    for (int blk = 0; blk < NBLK; ++blk) {
+        // ---- S^T of the block: 3 k steps x 4 key tiles x (6 products x QT) MFMAs; the fragment of the next (step, tile) is read before this one's MFMAs ----
+        f32x4 s[QT][4];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 kc[3], kn[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) kc[pc] = *reinterpret_cast<const bf16x8*>(kfr + pc * KPL);
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            split_q();
+            if (st + 1 < 3) load_q(st + 1);               // in flight under this step's MFMAs
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const int nx = st * 4 + kt + 1;
+                if (nx < 12) {
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc)
+                        kn[pc] = *reinterpret_cast<const bf16x8*>(kfr + pc * KPL + (nx % 4) * 16 * KRS + (nx / 4) * 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < NPROD; ++p)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[piece_w(p)], qf[qt][piece_a(p)], s[qt][kt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) kc[pc] = kn[pc];
+            }
+        }
+        // ---- this block's V and the next block's K: in flight under the softmax ----
+        load_v(blk);
+        if (blk + 1 < NBLK) load_k(blk + 1);
+        __syncthreads();                                   // every wave is done with the K image (and with the V^T image: its P.V came first)
+        // ---- running softmax: m = max(m, block max); e = 2^(s log2 e - m log2 e); earlier sums and outputs scaled by 2^((m_old - m) log2 e) ----
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float m = s[qt][0][0];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, s[qt][kt][r]);
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const float c = fminf(-(m * LOG2E_F), cneg[qt]);                   // -(maximum so far) log2 e
+            const float alpha = __builtin_amdgcn_exp2f(c - cneg[qt]);          // 1 exactly when the maximum did not move
+            cneg[qt] = c;
+            lsum[qt] *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 5; ++dt) o[qt][dt] = o[qt][dt] * alpha;
+            const f32x2 c2 = splat2(c), l2 = splat2(LOG2E_F);
+            f32x2 sum2 = splat2(0.f);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const f32x2 t = __builtin_elementwise_fma(f32x2{s[qt][kt][2 * hh], s[qt][kt][2 * hh + 1]}, l2, c2);
+                    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                    s[qt][kt][2 * hh] = e.x;
+                    s[qt][kt][2 * hh + 1] = e.y;
+                    sum2 += e;
+                }
+            lsum[qt] += sum2.x + sum2.y;
+        }
+        // ---- V block -> its image (transposed: rows = d, columns = key slots), next K block -> its image ----
+        write_v();
+        if (blk + 1 < NBLK) write_k();
+        __syncthreads();
+        if (blk + 1 < NBLK) load_q(0);                     // the next block's first Q step, in flight under P.V
+        // ---- O^T += V^T P^T: 2 k steps of 32 keys x 5 d tiles x (6 products x QT) MFMAs ----
+        bf16x8 vc[3], vn[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) vc[pc] = *reinterpret_cast<const bf16x8*>(vfr + pc * VPL);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 pf[QT][3];
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                uint32_t H[4], M[4], L[4];
+                split3_pair(s[qt][2 * st][0], s[qt][2 * st][1], H[0], M[0], L[0]);
+                split3_pair(s[qt][2 * st][2], s[qt][2 * st][3], H[1], M[1], L[1]);
+                split3_pair(s[qt][2 * st + 1][0], s[qt][2 * st + 1][1], H[2], M[2], L[2]);
+                split3_pair(s[qt][2 * st + 1][2], s[qt][2 * st + 1][3], H[3], M[3], L[3]);
+                pf[qt][0] = pieces8(H[0], H[1], H[2], H[3]);
+                pf[qt][1] = pieces8(M[0], M[1], M[2], M[3]);
+                pf[qt][2] = pieces8(L[0], L[1], L[2], L[3]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 5; ++dt) {
+                const int nx = st * 5 + dt + 1;
+                if (nx < 10) {
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc)
+                        vn[pc] = *reinterpret_cast<const bf16x8*>(vfr + pc * VPL + (nx % 5) * 16 * VRS + (nx / 5) * 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < NPROD; ++p)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc[piece_w(p)], pf[qt][piece_a(p)], o[qt][dt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) vc[pc] = vn[pc];
+            }
+        }
+    }
+
+    // ---- normalise + store: lane (l15, g) holds d = 16 dt + 4 g ... + 3 of query 16 qt + l15 ----
+    float inv[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l = lsum[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        inv[qt] = 1.0f / l;
+    }
+    if constexpr (SPLIT) {
+        store_o_split3<QT>(reinterpret_cast<char*>(out), (int64_t)b * NTOK + q0, h * HD, l15, g, o, inv);
+    } else {
+        float* obase = out + (int64_t)b * NTOK * DIM + h * HD;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < 5; ++dt)
+                *reinterpret_cast<f32x4*>(obase + (int64_t)(q0 + qt * 16 + l15) * DIM + dt * 16 + g * 4) = o[qt][dt] * inv[qt];
+    }
+}
+
+}  // namespace
+
+// out_split == true: `out` is the split3 operand [B*192][1280/8][3][8] bf16.  qt = 0: the batch-size rule (64-query workgroups while
+// 48 B of them fill the chip's 512 resident slots, like launch_vit_attention_variant); 1 / 3 force a shape (bit-identical).
+int launch_vit_attention_b16(const float* qkv, void* out, int B, bool out_split, int qt, hipStream_t s) {
+    if (B <= 0 || (qt != 0 && qt != 1 && qt != 3)) return -1;
+    if (qt == 0) qt = B <= 10 ? 1 : 3;
+    float* o = reinterpret_cast<float*>(out);
+    if (qt == 1) {
+        if (out_split) hipLaunchKernelGGL((vit_attention_b16_kernel<1, true>), dim3(B * NH * 3), dim3(256), 0, s, qkv, o);
+        else hipLaunchKernelGGL((vit_attention_b16_kernel<1, false>), dim3(B * NH * 3), dim3(256), 0, s, qkv, o);
+    } else {
+        if (out_split) hipLaunchKernelGGL((vit_attention_b16_kernel<3, true>), dim3(B * NH), dim3(256), 0, s, qkv, o);
+        else hipLaunchKernelGGL((vit_attention_b16_kernel<3, false>), dim3(B * NH), dim3(256), 0, s, qkv, o);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

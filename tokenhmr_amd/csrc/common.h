@@ -393,6 +393,9 @@ int launch_vit_attention(const float* qkv, float* out, int B, hipStream_t s);   
 int launch_vit_attention_split3(const float* qkv, void* out_split, int B, hipStream_t s);
 int launch_vit_attention_keysplit(const float* qkv, float* out, int B, hipStream_t s);   // few crops: keys split over the 4 waves
 int launch_vit_attention_variant(const float* qkv, float* out, int B, int variant, hipStream_t s);   // 0 = rule; 1 / 3 / 5 / 12 / 6
+// attention_b16.hip: the same attention with every product as 3 x 3 bf16 pieces on v_mfma_f32_16x16x32_bf16 (six products, fp32 accumulate);
+// out = fp32 (B,192,1280) or the split3 operand; qt = 0 (batch-size rule), 1 (64-query workgroups), 3 (one workgroup per (crop, head))
+int launch_vit_attention_b16(const float* qkv, void* out, int B, bool out_split, int qt, hipStream_t s);
 // rowops.hip
 int launch_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int D, float eps, int relu,
                      hipStream_t s);

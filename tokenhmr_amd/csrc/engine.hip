@@ -36,6 +36,7 @@ constexpr float FOCAL = 5000.0f, IMG = 256.0f;
 // small-batch ViT path (gemm_ring_kernel): used while M = 192*B <= kSmallM; crossovers measured in profiles/r1_small_gemm_variants.log
 constexpr int kSmallM = 1152, kSplitKMax = 4;     // B <= 6
 constexpr int kKeysplitMaxB = 2;                  // key-split attention kernel: one and two crops
+constexpr bool kAttnB16 = false;                  // split3 mode's attention: false = the fp32-MFMA kernels with split3 output, true = attention_b16.hip
 // mid-size batches: from 7 to 16 crops proj / fc2 (N = 1280: 110-240 output tiles of 128x128 on 512 resident slots) run split-K 2
 // on the big LDS-DMA tiles (measured per batch size and per GEMM, profiles/r3d_mid_batch_splitk_sweep.log, r3f_mid_batch_forced_tile.log:
 // -10 % per call at 9 and 10 crops, -2.5 ... -3.7 % at 11 ... 16, -2 % at 7 and 8 with the 64x128 tile; from 17 on the unsplit launch
@@ -106,6 +107,7 @@ struct thmr_engine {
     bool tiny_gemm = true;            // THMR_TINY_GEMM=0: the VQ decoder's GEMMs stay on the ring kernel in the small-batch regime (A/B only)
     bool qkv_ring16 = true;           // THMR_QKV_RING16=0: one and two crops keep the 64x64 ring kernel for qkv (A/B only)
     bool attn_keysplit = true;        // THMR_ATTN_KEYSPLIT=0: one and two crops keep the 64-query attention workgroups (A/B only)
+    bool attn_b16 = kAttnB16;         // split3 mode: the attention on the bf16 matrix pipe too (csrc/attention_b16.hip); THMR_ATTN_B16=0 / 1: A/B only
     int mid_split_force[2] = {-1, -1};   // THMR_MID_SPLIT=<p><f> (digits 0|2|4): force the split factors of proj and fc2 above 6 crops where the partial-sum buffer allows (A/B only)
     bool smpl_loaded = false, finalized = false;
     // thmr_set_vit_gemm(1): the four ViT GEMMs of batches of at least kSplit3LowMinB (3) crops run on the bf16 matrix pipe with fp32 operands
@@ -552,7 +554,8 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             LAUNCH_OK(gemm_s(THMR_PROF_GEMM_QKV, hs, DIM, ws.qkv, w.qkvb, nullptr, big, 3 * DIM, EPI_BIAS_QSCALE));
             {   // attention, its output written directly as proj's split3 operand
                 ProfScope ps(e, st, THMR_PROF_ATTN, 4.0 * B * HEADS * 192.0 * 192.0 * 80.0, 4.0 * (3.0 * M * DIM) + 6.0 * M * DIM);
-                LAUNCH_OK(launch_vit_attention_split3(big, hs, B, st));
+                if (e->attn_b16) LAUNCH_OK(launch_vit_attention_b16(big, hs, B, true, 0, st));
+                else LAUNCH_OK(launch_vit_attention_split3(big, hs, B, st));
             }
             if (s3_split > 1) {
                 {
@@ -1140,6 +1143,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* tg = thmr_knob("THMR_TINY_GEMM"); e->tiny_gemm = !(tg && tg[0] == '0'); }
     { const char* qr = thmr_knob("THMR_QKV_RING16"); e->qkv_ring16 = !(qr && qr[0] == '0'); }
     { const char* ak = thmr_knob("THMR_ATTN_KEYSPLIT"); e->attn_keysplit = !(ak && ak[0] == '0'); }
+    { const char* ab = thmr_knob("THMR_ATTN_B16"); if (ab && (ab[0] == '0' || ab[0] == '1')) e->attn_b16 = ab[0] == '1'; }
     { const char* ss = thmr_knob("THMR_SPLIT3_SMALL"); e->split3_small = ss && ss[0] == '1'; }
     { const char* fs = thmr_knob("THMR_SPLIT3_FC2_SPLIT"); e->split3_fc2_split = (fs && fs[0] == '1') ? 1 : kSplit3Fc2Split; }
     { const char* sm = thmr_knob("THMR_SPLIT3_MIN_B"); e->split3_min_b = sm ? atoi(sm) : 0; }
@@ -1798,6 +1802,13 @@ int thmr_op_vit_attention_split3(const float* qkv, void* out_split, int32_t B, v
     thmr_engine* e = nullptr;
     if (!qkv || !out_split || B <= 0) return fail(e, THMR_ERR_INVALID, "bad argument");
     LAUNCH_OK(launch_vit_attention_split3(qkv, out_split, B, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int thmr_op_vit_attention_b16(const float* qkv, void* out, int32_t B, int32_t out_split, int32_t qt, void* stream) {
+    thmr_engine* e = nullptr;
+    if (!qkv || !out || B <= 0) return fail(e, THMR_ERR_INVALID, "bad argument");
+    LAUNCH_OK(launch_vit_attention_b16(qkv, out, B, out_split != 0, qt, static_cast<hipStream_t>(stream)));
     return 0;
 }
 

@@ -189,6 +189,18 @@ def vit_attention_split3(qkv):
     return out
 
 
+def vit_attention_b16(qkv, out_split=False, qt=0):
+    """The attention on the bf16 matrix pipe (three bf16 pieces per operand, six products, fp32 accumulate: csrc/attention_b16.hip).
+    out_split: the result as a split3 operand (int16 (B*192, 160, 3, 8)) instead of fp32 (B,192,1280); qt: 0 = batch-size rule, 1 / 3 = forced."""
+    _req(qkv)
+    B = qkv.shape[0]
+    out = (torch.empty(B * 192, 160, 3, 8, device=qkv.device, dtype=torch.int16) if out_split
+           else torch.empty(B, 192, 1280, device=qkv.device, dtype=torch.float32))
+    with torch.cuda.device(qkv.device):
+        _check(_L().thmr_op_vit_attention_b16(_p(qkv), _p(out), B, int(out_split), int(qt), _s(qkv)))
+    return out
+
+
 def rot6d_to_rotmat(x):
     _req(x)
     x2 = x.reshape(-1, 6).contiguous()
