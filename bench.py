@@ -760,8 +760,13 @@ def main():
                 at = prof_all.get("attention")
                 if at and at["launches"]:
                     atf = at["flops"] / (at["ms"] * 1e-3) / 1e12
-                    roof["attention"] = {"bound": "mfma", "achieved": round(atf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                         "frac": round(atf / PEAK_F32_MFMA_TFLOPS, 4), "avg_launch_ms": round(at["ms"] / at["launches"], 4)}
+                    # split3 mode (>= 3 crops): csrc/attention_b16.hip — q k^T and p v as six bf16 MFMA products per element pair
+                    a_pk, a_mul = (PEAK_BF16_MFMA_TFLOPS, 6.0) if (split_mode and B >= 3) else (PEAK_F32_MFMA_TFLOPS, 1.0)
+                    roof["attention"] = {"bound": "mfma", "achieved": round(atf * a_mul, 2), "peak": a_pk, "unit": "TFLOP/s",
+                                         "frac": round(atf * a_mul / a_pk, 4), "avg_launch_ms": round(at["ms"] / at["launches"], 4),
+                                         "f32_equivalent_tflops": round(atf, 2),
+                                         "kernel": ("vit_attention_b16_kernel on v_mfma_f32_16x16x32_bf16 (6 piece products x 4 N N d flops)"
+                                                    if a_mul > 1 else "vit_attention_*_kernel on v_mfma_f32_16x16x4_f32")}
                 pe = prof_all.get("patch_embed")
                 if pe and pe["launches"]:   # north_star asks for the patch-embed HBM rate too (it is MFMA/latency-bound: AI 240 flop/B)
                     gbs = pe["bytes"] / (pe["ms"] * 1e-3) / 1e9

@@ -231,11 +231,12 @@ int thmr_op_vit_attention_variant(const float* qkv_dev, float* out_dev, int32_t 
 /* thmr_op_vit_attention with the output written as a split3 operand [B*192][1280/8][3][8] bf16 (see thmr_op_split3): for B >= 3
  * bit-identical to thmr_op_split3 of thmr_op_vit_attention's output; for B = 1 and 2 this operator runs the key-split kernel (another
  * order of the key sum), so there it is bit-identical to thmr_op_split3 of thmr_op_vit_attention_variant(..., 6, ...)'s output.
- * What the engine's split3 mode hands the proj GEMM. */
+ * (The engine's split3 mode ran this up to round 4; it now runs thmr_op_vit_attention_b16 with out_split = 1.) */
 int thmr_op_vit_attention_split3(const float* qkv_dev, void* out_split_dev, int32_t B, void* stream);
 /* The same attention (vit.py:113-122) on the bf16 matrix pipe: q, k, v and the un-normalised probabilities enter v_mfma_f32_16x16x32_bf16 as
  * three bf16 pieces each, six products per pair, fp32 accumulate (csrc/attention_b16.hip) — the split3 mode's arithmetic applied to
- * q k^T and p v; the two 96-key blocks are combined with a running row maximum.  fp32-grade, NOT bit-identical to thmr_op_vit_attention.
+ * q k^T and p v; the three 64-key blocks are combined with a running row maximum.  fp32-grade (error against fp64 at or below the fp32-MFMA
+ * kernel's, tests/test_gpu_ops.py::test_vit_attention_b16), NOT bit-identical to thmr_op_vit_attention.  What the engine's split3 mode runs.
  * out_split = 0: out_dev is fp32 (B,192,1280); 1: the split3 operand [B*192][1280/8][3][8] bf16.  qt = 0: batch-size rule; 1: three
  * 64-query workgroups per (crop, head); 3: one workgroup of 192 queries (bit-identical to each other and for any B). */
 int thmr_op_vit_attention_b16(const float* qkv_dev, void* out_dev, int32_t B, int32_t out_split, int32_t qt, void* stream);
@@ -320,7 +321,7 @@ const char* thmr_collective_last_error(void);
  *      (csrc/gemm_split.hip; thmr_op_gemm_split3 is the same kernel).  fp32-GRADE, not bitwise fp32: the measured error against an fp64
  *      product is no larger than the exact-fp32 kernel's (tests/test_gpu_ops.py::test_gemm_split3), at ~1.6x its rate.  Applies to calls of at
  *      least 3 crops (one and two crops run the exact-fp32 kernels regardless).  Four ranges, a crop's result is batch-independent within
- *      each: 3 and 4 crops split the K sums of proj and fc2 four ways, 5 ... 15 two ways, 16 ... 31 only fc2's (two ways), 32 and more neither; the decoder's stacked to_kv GEMM runs the same way; LayerNorm, attention, the epilogues and the rest of the head are unchanged.
+ *      each: 3 and 4 crops split the K sums of proj and fc2 four ways, 5 ... 15 two ways, 16 ... 31 only fc2's (two ways), 32 and more neither; the decoder's stacked to_kv GEMM runs the same way, and so does the ViT attention (thmr_op_vit_attention_b16: q k^T and p v as six bf16 products per pair, any batch size of the mode, a crop's result batch-independent); LayerNorm, the epilogues and the rest of the head are unchanged.
  * Setting 1 needs finalized weights; the engine then owns a split3 copy of the ViT weights (1.5x their fp32 bytes) and the operand
  * buffers (+ the partial-sum planes of its split-K ranges), rebuilt by thmr_finalize_weights while the mode is on and kept until
  * thmr_destroy (setting 0 again does not free them).  Like thmr_forward it allocates nothing per call, so a call in either mode can be

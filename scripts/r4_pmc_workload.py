@@ -40,6 +40,14 @@ if which in ("all", "gemm"):
     sab = ops.split3_block(sa)
     for _ in range(6):
         ops.gemm_split3(sab, sw, b, r, epi="bias_resid", variant="persist", a_blocked_rows=M)
+    # the split3 mode's attention (csrc/attention_b16.hip) beside the fp32-MFMA kernel with split3 output it replaced
+    qkv = torch.randn(64, 192, 3840, generator=g)
+    qkv[:, :, :1280] *= 80 ** -0.5
+    qkv = qkv.to(dev)
+    for _ in range(6):
+        ops.vit_attention_b16(qkv, out_split=True)
+    for _ in range(6):
+        ops.vit_attention_split3(qkv)
     torch.cuda.synchronize()
 if which in ("all", "rows"):
     x = torch.randn(M, 1280, generator=g).to(dev)

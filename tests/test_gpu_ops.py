@@ -582,12 +582,14 @@ def test_vit_attention_persistent_matches_the_64_query_variant(built_lib, cuda_d
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [1, 3, 11, 40])
+@pytest.mark.parametrize("B", [1, 3, 11, 33, 40, 100])
 def test_vit_attention_b16(built_lib, cuda_dev, B):
     """The attention on the bf16 matrix pipe (csrc/attention_b16.hip: q, k, v and the un-normalised probabilities as three bf16 pieces, six
     products per pair, fp32 accumulate; three 64-key blocks combined with a running row maximum) against fp64 with the error class of
     torch's own fp32 and of the fp32-MFMA kernel; the two workgroup shapes (64 / 192 queries) bit-identical; deterministic; batch-independent;
-    the split3 output = the conversion of the fp32 output; finite and in class on peaked scores (|scores| ~ 100)."""
+    the split3 output = the conversion of the fp32 output; finite and in class on peaked scores (|scores| ~ 100).  At most 512 workgroups
+    walk the items with the block pipeline running across item boundaries: B = 33 gives a grid where only some workgroups have a second
+    item, B = 100 three or four items per workgroup."""
     from tokenhmr_amd import ops
     for scale in (1.0, 6.0):
         qkv = _rand(B, 192, 3840, seed=300 + B)
@@ -601,6 +603,8 @@ def test_vit_attention_b16(built_lib, cuda_dev, B):
         for _ in range(3):
             assert torch.equal(ops.vit_attention_b16(d), out)
         assert torch.equal(ops.vit_attention_b16(d[-1:].contiguous()), out[-1:])
+        if B > 32:
+            assert torch.equal(ops.vit_attention_b16(d[:32].contiguous()), out[:32])          # one item per workgroup vs several
         assert torch.equal(ops.vit_attention_b16(d, out_split=True), ops.split3(out.reshape(B * 192, 1280)))
         assert torch.equal(ops.vit_attention_b16(d, out_split=True, qt=1), ops.vit_attention_b16(d, out_split=True, qt=3))
         n = min(B, 4)

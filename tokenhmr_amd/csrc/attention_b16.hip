@@ -47,37 +47,39 @@ __device__ __forceinline__ bf16x8 pieces8(uint32_t a, uint32_t b, uint32_t c, ui
     return __builtin_bit_cast(bf16x8, u32x4{a, b, c, d});
 }
 
-// QT = 16-query tiles per wave: 3 = one workgroup per (crop, head), 1 = three workgroups of 64 queries.
+// QT = 16-query tiles per wave: 3 = one workgroup per (crop, head), 1 = three workgroups of 64 queries.  `nitems` = B * 16 * (3 / QT) work
+// items; at most 512 workgroups (two per CU) walk them (workgroup (xcd, i) takes items i, i + grid / 8, ... of its XCD's contiguous share),
+// and the block pipeline does not drain between items: the next item's first K block and Q step are requested under the current item's
+// last P.V, exactly as block n + 1's are under block n's.
 template <int QT, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* __restrict__ qkv, float* __restrict__ out) {
+__global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* __restrict__ qkv, float* __restrict__ out, int nitems) {
     constexpr int QB = 3 / QT;
     static_assert(QT == 1 || QT == 3, "192 queries = QB workgroups x 4 waves x QT tiles of 16");
     __shared__ __attribute__((aligned(16))) char smem[K_IMG + V_IMG];
     char* const kimg = smem;
     char* const vimg = smem + K_IMG;
-    // XCD-aware order (attention.hip): workgroup b runs on XCD b % 8; the logical index walks each XCD's share contiguously, so the 16
-    // heads of a crop stream its 15 KB token rows through ONE L2
-    int logical;
-    {
-        const int nwg = gridDim.x, xcd = blockIdx.x & 7, within = blockIdx.x >> 3, q = nwg >> 3, r = nwg & 7;
-        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-    }
-    const int bh = logical / QB, qb = logical - bh * QB;
-    const int b = bh / NH, h = bh % NH;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    const int q0 = (qb * 4 + wave) * 16 * QT;
-
-    // ---- global -> registers: buffer loads = {this crop's rows as the resource} + {wave-uniform SGPR offset} + {ONE 32-bit per-lane offset}.
+    // XCD-aware order (attention.hip): workgroup b runs on XCD b % 8; an XCD's share of the items is contiguous, so the 16 heads of a crop
+    // stream its 15 KB token rows through ONE L2.  nitems and the grid are multiples of 8 (launcher).
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3, wpx = gridDim.x >> 3, per_xcd = nitems >> 3;
+    int it = within;
+    if (it >= per_xcd) return;
+    // an item: crop (its rows are the buffer resource), head column, first query of this wave
+    struct Item { int crop, hcol, q0; };
+    auto item_of = [&](int i) {
+        const int lg = xcd * per_xcd + i, bh = lg / QB, qb = lg - bh * QB;
+        return Item{bh / NH, (bh % NH) * HD, (qb * 4 + wave) * 16 * QT};
+    };
+    // ---- global -> registers: buffer loads = {a crop's rows as the resource} + {wave-uniform SGPR offset} + {ONE 32-bit per-lane offset}.
     //      (Plain pointers: hipcc folds uniform pointer + lane offset + constant into a 64-bit VGPR address per load: 16 registers a batch.) ----
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qkv + (int64_t)b * NTOK * QKV_LD), 0, NTOK * QKV_LD * 4, 0x00020000);
-    const int hcol = __builtin_amdgcn_readfirstlane(h * HD);
-    auto ld4 = [&](int uoff_floats, uint32_t off) {        // qkv[crop b][uoff_floats + off / 4 ... + 3], uoff wave-uniform
-        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, uoff_floats * 4, 0);
+    auto rsrc_of = [&](int crop) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qkv + (int64_t)crop * NTOK * QKV_LD), 0, NTOK * QKV_LD * 4, 0x00020000); };
+    auto ld4 = [&](const Item& im, int uoff_floats, uint32_t off) {        // qkv[crop][uoff_floats + off / 4 ... + 3], uoff wave-uniform
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc_of(im.crop), off, uoff_floats * 4, 0);
         return f32x4{__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])};
     };
-    auto ld1 = [&](int uoff_floats, uint32_t off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, uoff_floats * 4, 0)); };
+    auto ld1 = [&](const Item& im, int uoff_floats, uint32_t off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_of(im.crop), off, uoff_floats * 4, 0)); };
 
     // ---- staging roles (all 256 threads, 20 registers a block).
     //      K block: thread (key tid >> 2, part tid & 3) takes the 4-d groups part + 4 m, m = 0..4, of its key.
@@ -92,10 +94,10 @@ __global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* 
     char* const vdst = vimg + vdg * VRS + 2 * (32 * (vkq >> 3) + 8 * (vkq & 3) + 4 * ((vkq >> 2) & 1));
     f32x4 kr[5];
     float vr[5][4];
-    auto load_k = [&](int blk) {
-        const int ub = hcol + DIM + blk * KB * QKV_LD;
+    auto load_k = [&](const Item& im, int blk) {
+        const int ub = im.hcol + DIM + blk * KB * QKV_LD;
 #pragma unroll
-        for (int m = 0; m < 5; ++m) kr[m] = ld4(ub + m * 16, koff);
+        for (int m = 0; m < 5; ++m) kr[m] = ld4(im, ub + m * 16, koff);
     };
     auto write_k = [&]() {
 #pragma unroll
@@ -109,12 +111,12 @@ __global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* 
             *reinterpret_cast<u32x2v*>(o + 2 * KPL) = u32x2v{L[0], L[1]};
         }
     };
-    auto load_v = [&](int blk) {
-        const int ub = hcol + 2 * DIM + blk * KB * QKV_LD;
+    auto load_v = [&](const Item& im, int blk) {
+        const int ub = im.hcol + 2 * DIM + blk * KB * QKV_LD;
 #pragma unroll
         for (int m = 0; m < 5; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) vr[m][r] = ld1(ub + r * QKV_LD + m * 16, voff);
+            for (int r = 0; r < 4; ++r) vr[m][r] = ld1(im, ub + r * QKV_LD + m * 16, voff);
     };
     auto write_v = [&]() {
 #pragma unroll
@@ -131,13 +133,13 @@ __global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* 
 
     // ---- Q pieces of k step s: B operand of S^T = K Q^T, lane (query l15, g) holds d = 32 s + 8 g ... + 7 (nothing past d = 79) ----
     f32x4 qraw[QT][2];
-    auto load_q = [&](int s) {
+    auto load_q = [&](const Item& im, int s) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            const int ub = hcol + (q0 + qt * 16) * QKV_LD + s * 32;
+            const int ub = im.hcol + (im.q0 + qt * 16) * QKV_LD + s * 32;
             if (s < 2 || g < 2) {
-                qraw[qt][0] = ld4(ub, qoff);
-                qraw[qt][1] = ld4(ub + 4, qoff);
+                qraw[qt][0] = ld4(im, ub, qoff);
+                qraw[qt][1] = ld4(im, ub + 4, qoff);
             } else {
                 qraw[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
                 qraw[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -159,21 +161,12 @@ __global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* 
         }
     };
 
-    f32x4 o[QT][5];
-    float lsum[QT], cneg[QT];            // per-lane partial row sums; -(running row maximum) log2 e
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-#pragma unroll
-        for (int dt = 0; dt < 5; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        lsum[qt] = 0.f;
-        cneg[qt] = 3.0e38f;              // "no maximum yet": the first block's rescale factor is 2^(-huge) = 0 on sums and outputs that are 0
-    }
-
     const char* const kfr = kimg + l15 * KRS + g * 16;   // K fragment of (tile kt, step s): + kt * 16 * KRS + s * 64 (+ plane)
     const char* const vfr = vimg + l15 * VRS + g * 16;   // V^T fragment of (tile dt, step st): + dt * 16 * VRS + st * 64 (+ plane)
 
-    load_k(0);
-    load_q(0);
+    Item cur = item_of(it);
+    load_k(cur, 0);
+    load_q(cur, 0);
     // d = 80 ... 95 of every row of the K image are zero, once: 3 x 64 rows x 2 chunks of 16 bytes
     for (int idx = tid; idx < 3 * KB * 2; idx += 256) {
         const int pl = idx / (2 * KB), rem = idx - pl * (2 * KB);
@@ -183,152 +176,174 @@ __global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* 
     __syncthreads();
 
 #pragma unroll 1
-    for (int blk = 0; blk < NBLK; ++blk) {
-        // ---- S^T of the block: 3 k steps x 4 key tiles x (6 products x QT) MFMAs; the fragment of the next (step, tile) is read before this one's MFMAs ----
-        f32x4 s[QT][4];
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x8 kc[3], kn[3];
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) kc[pc] = *reinterpret_cast<const bf16x8*>(kfr + pc * KPL);
-#pragma unroll
-        for (int st = 0; st < 3; ++st) {
-            split_q();
-            if (st + 1 < 3) load_q(st + 1);               // in flight under this step's MFMAs
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const int nx = st * 4 + kt + 1;
-                if (nx < 12) {
-#pragma unroll
-                    for (int pc = 0; pc < 3; ++pc)
-                        kn[pc] = *reinterpret_cast<const bf16x8*>(kfr + pc * KPL + (nx % 4) * 16 * KRS + (nx / 4) * 64);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int p = 0; p < NPROD; ++p)
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt)
-                        s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[piece_w(p)], qf[qt][piece_a(p)], s[qt][kt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) kc[pc] = kn[pc];
-            }
-        }
-        // ---- this block's V and the next block's K: in flight under the softmax ----
-        load_v(blk);
-        if (blk + 1 < NBLK) load_k(blk + 1);
-        __syncthreads();                                   // every wave is done with the K image (and with the V^T image: its P.V came first)
-        // ---- running softmax: m = max(m, block max); e = 2^(s log2 e - m log2 e); earlier sums and outputs scaled by 2^((m_old - m) log2 e) ----
+    for (;;) {
+        const bool has_next = it + wpx < per_xcd;            // wave-uniform
+        const Item nxt = has_next ? item_of(it + wpx) : cur;
+        f32x4 o[QT][5];
+        float lsum[QT], cneg[QT];            // per-lane partial row sums; -(running row maximum) log2 e
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            float m = s[qt][0][0];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) m = fmaxf(m, s[qt][kt][r]);
-            m = fmaxf(m, __shfl_xor(m, 16, 64));
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            const float c = fminf(-(m * LOG2E_F), cneg[qt]);                   // -(maximum so far) log2 e
-            const float alpha = __builtin_amdgcn_exp2f(c - cneg[qt]);          // 1 exactly when the maximum did not move
-            cneg[qt] = c;
-            lsum[qt] *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < 5; ++dt) o[qt][dt] = o[qt][dt] * alpha;
-            const f32x2 c2 = splat2(c), l2 = splat2(LOG2E_F);
-            f32x2 sum2 = splat2(0.f);
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const f32x2 t = __builtin_elementwise_fma(f32x2{s[qt][kt][2 * hh], s[qt][kt][2 * hh + 1]}, l2, c2);
-                    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-                    s[qt][kt][2 * hh] = e.x;
-                    s[qt][kt][2 * hh + 1] = e.y;
-                    sum2 += e;
-                }
-            lsum[qt] += sum2.x + sum2.y;
+            for (int dt = 0; dt < 5; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            lsum[qt] = 0.f;
+            cneg[qt] = 3.0e38f;              // "no maximum yet": the first block's rescale factor is 2^(-huge) = 0 on sums and outputs that are 0
         }
-        // ---- V block -> its image (transposed: rows = d, columns = key slots), next K block -> its image ----
-        write_v();
-        if (blk + 1 < NBLK) write_k();
-        __syncthreads();
-        if (blk + 1 < NBLK) load_q(0);                     // the next block's first Q step, in flight under P.V
-        // ---- O^T += V^T P^T: 2 k steps of 32 keys x 5 d tiles x (6 products x QT) MFMAs ----
-        bf16x8 vc[3], vn[3];
+#pragma unroll 1
+        for (int blk = 0; blk < NBLK; ++blk) {
+            const bool more = blk + 1 < NBLK;                // this item has another block; else the next item's first block follows (if any)
+            // ---- S^T of the block: 3 k steps x 4 key tiles x (6 products x QT) MFMAs; the fragment of the next (step, tile) is read before this one's MFMAs ----
+            f32x4 s[QT][4];
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) vc[pc] = *reinterpret_cast<const bf16x8*>(vfr + pc * VPL);
+            for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            bf16x8 pf[QT][3];
+                for (int kt = 0; kt < 4; ++kt) s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 kc[3], kn[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) kc[pc] = *reinterpret_cast<const bf16x8*>(kfr + pc * KPL);
+#pragma unroll
+            for (int st = 0; st < 3; ++st) {
+                split_q();
+                if (st + 1 < 3) load_q(cur, st + 1);          // in flight under this step's MFMAs
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const int nx = st * 4 + kt + 1;
+                    if (nx < 12) {
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc)
+                            kn[pc] = *reinterpret_cast<const bf16x8*>(kfr + pc * KPL + (nx % 4) * 16 * KRS + (nx / 4) * 64);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int p = 0; p < NPROD; ++p)
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt)
+                            s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[piece_w(p)], qf[qt][piece_a(p)], s[qt][kt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) kc[pc] = kn[pc];
+                }
+            }
+            // ---- this block's V and the next block's K (this item's, or the next item's first): in flight under the softmax ----
+            load_v(cur, blk);
+            if (more) load_k(cur, blk + 1);
+            else if (has_next) load_k(nxt, 0);
+            __syncthreads();                                   // every wave is done with the K image (and with the V^T image: its P.V came first)
+            // ---- running softmax: m = max(m, block max); e = 2^(s log2 e - m log2 e); earlier sums and outputs scaled by 2^((m_old - m) log2 e) ----
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
-                uint32_t H[4], M[4], L[4];
-                split3_pair(s[qt][2 * st][0], s[qt][2 * st][1], H[0], M[0], L[0]);
-                split3_pair(s[qt][2 * st][2], s[qt][2 * st][3], H[1], M[1], L[1]);
-                split3_pair(s[qt][2 * st + 1][0], s[qt][2 * st + 1][1], H[2], M[2], L[2]);
-                split3_pair(s[qt][2 * st + 1][2], s[qt][2 * st + 1][3], H[3], M[3], L[3]);
-                pf[qt][0] = pieces8(H[0], H[1], H[2], H[3]);
-                pf[qt][1] = pieces8(M[0], M[1], M[2], M[3]);
-                pf[qt][2] = pieces8(L[0], L[1], L[2], L[3]);
+                float m = s[qt][0][0];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmaxf(m, s[qt][kt][r]);
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                const float c = fminf(-(m * LOG2E_F), cneg[qt]);                   // -(maximum so far) log2 e
+                const float alpha = __builtin_amdgcn_exp2f(c - cneg[qt]);          // 1 exactly when the maximum did not move
+                cneg[qt] = c;
+                lsum[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt) o[qt][dt] = o[qt][dt] * alpha;
+                const f32x2 c2 = splat2(c), l2 = splat2(LOG2E_F);
+                f32x2 sum2 = splat2(0.f);
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const f32x2 t = __builtin_elementwise_fma(f32x2{s[qt][kt][2 * hh], s[qt][kt][2 * hh + 1]}, l2, c2);
+                        const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                        s[qt][kt][2 * hh] = e.x;
+                        s[qt][kt][2 * hh + 1] = e.y;
+                        sum2 += e;
+                    }
+                lsum[qt] += sum2.x + sum2.y;
             }
+            // ---- V block -> its image (transposed: rows = d, columns = key slots), next K block -> its image ----
+            write_v();
+            if (more || has_next) write_k();
+            __syncthreads();
+            if (more) load_q(cur, 0);                          // the next block's first Q step, in flight under P.V
+            else if (has_next) load_q(nxt, 0);
+            // ---- O^T += V^T P^T: 2 k steps of 32 keys x 5 d tiles x (6 products x QT) MFMAs ----
+            bf16x8 vc[3], vn[3];
 #pragma unroll
-            for (int dt = 0; dt < 5; ++dt) {
-                const int nx = st * 5 + dt + 1;
-                if (nx < 10) {
+            for (int pc = 0; pc < 3; ++pc) vc[pc] = *reinterpret_cast<const bf16x8*>(vfr + pc * VPL);
 #pragma unroll
-                    for (int pc = 0; pc < 3; ++pc)
-                        vn[pc] = *reinterpret_cast<const bf16x8*>(vfr + pc * VPL + (nx % 5) * 16 * VRS + (nx / 5) * 64);
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 pf[QT][3];
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    uint32_t H[4], M[4], L[4];
+                    split3_pair(s[qt][2 * st][0], s[qt][2 * st][1], H[0], M[0], L[0]);
+                    split3_pair(s[qt][2 * st][2], s[qt][2 * st][3], H[1], M[1], L[1]);
+                    split3_pair(s[qt][2 * st + 1][0], s[qt][2 * st + 1][1], H[2], M[2], L[2]);
+                    split3_pair(s[qt][2 * st + 1][2], s[qt][2 * st + 1][3], H[3], M[3], L[3]);
+                    pf[qt][0] = pieces8(H[0], H[1], H[2], H[3]);
+                    pf[qt][1] = pieces8(M[0], M[1], M[2], M[3]);
+                    pf[qt][2] = pieces8(L[0], L[1], L[2], L[3]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int p = 0; p < NPROD; ++p)
+                for (int dt = 0; dt < 5; ++dt) {
+                    const int nx = st * 5 + dt + 1;
+                    if (nx < 10) {
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt)
-                        o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc[piece_w(p)], pf[qt][piece_a(p)], o[qt][dt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                        for (int pc = 0; pc < 3; ++pc)
+                            vn[pc] = *reinterpret_cast<const bf16x8*>(vfr + pc * VPL + (nx % 5) * 16 * VRS + (nx / 5) * 64);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) vc[pc] = vn[pc];
+                    for (int p = 0; p < NPROD; ++p)
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt)
+                            o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc[piece_w(p)], pf[qt][piece_a(p)], o[qt][dt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) vc[pc] = vn[pc];
+                }
             }
         }
-    }
 
-    // ---- normalise + store: lane (l15, g) holds d = 16 dt + 4 g ... + 3 of query 16 qt + l15 ----
-    float inv[QT];
+        // ---- normalise + store: lane (l15, g) holds d = 16 dt + 4 g ... + 3 of query 16 qt + l15 ----
+        float inv[QT];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        float l = lsum[qt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        inv[qt] = 1.0f / l;
-    }
-    if constexpr (SPLIT) {
-        store_o_split3<QT>(reinterpret_cast<char*>(out), (int64_t)b * NTOK + q0, h * HD, l15, g, o, inv);
-    } else {
-        float* obase = out + (int64_t)b * NTOK * DIM + h * HD;
+        for (int qt = 0; qt < QT; ++qt) {
+            float l = lsum[qt];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            inv[qt] = 1.0f / l;
+        }
+        if constexpr (SPLIT) {
+            store_o_split3<QT>(reinterpret_cast<char*>(out), (int64_t)cur.crop * NTOK + cur.q0, cur.hcol, l15, g, o, inv);
+        } else {
+            float* obase = out + (int64_t)cur.crop * NTOK * DIM + cur.hcol;
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
+            for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-            for (int dt = 0; dt < 5; ++dt)
-                *reinterpret_cast<f32x4*>(obase + (int64_t)(q0 + qt * 16 + l15) * DIM + dt * 16 + g * 4) = o[qt][dt] * inv[qt];
+                for (int dt = 0; dt < 5; ++dt)
+                    *reinterpret_cast<f32x4*>(obase + (int64_t)(cur.q0 + qt * 16 + l15) * DIM + dt * 16 + g * 4) = o[qt][dt] * inv[qt];
+        }
+        if (!has_next) break;
+        cur = nxt;
+        it += wpx;
     }
 }
 
 }  // namespace
 
-// out_split == true: `out` is the split3 operand [B*192][1280/8][3][8] bf16.  qt = 0: the batch-size rule (64-query workgroups while
-// 48 B of them fill the chip's 512 resident slots, like launch_vit_attention_variant); 1 / 3 force a shape (bit-identical).
+// out_split == true: `out` is the split3 operand [B*192][1280/8][3][8] bf16.  qt = 0: the batch-size rule (64-query workgroups up to 20 crops);
+// 1 / 3 force a shape (bit-identical).
 int launch_vit_attention_b16(const float* qkv, void* out, int B, bool out_split, int qt, hipStream_t s) {
     if (B <= 0 || (qt != 0 && qt != 1 && qt != 3)) return -1;
-    if (qt == 0) qt = B <= 10 ? 1 : 3;
+    if (qt == 0) qt = B <= 20 ? 1 : 3;        // stand-alone, us per launch qt = 1 / 3: 20.2 / 25.7 at 8 crops, 28.3 / 31.6 at 16, 53.1 / 50.0 at 32 (profiles/r4q_, r4r_attention_b16_*.jsonl)
     float* o = reinterpret_cast<float*>(out);
+    const int nitems = B * NH * (3 / qt);                        // a multiple of 16
+    const dim3 grid(nitems < 512 ? nitems : 512);
     if (qt == 1) {
-        if (out_split) hipLaunchKernelGGL((vit_attention_b16_kernel<1, true>), dim3(B * NH * 3), dim3(256), 0, s, qkv, o);
-        else hipLaunchKernelGGL((vit_attention_b16_kernel<1, false>), dim3(B * NH * 3), dim3(256), 0, s, qkv, o);
+        if (out_split) hipLaunchKernelGGL((vit_attention_b16_kernel<1, true>), grid, dim3(256), 0, s, qkv, o, nitems);
+        else hipLaunchKernelGGL((vit_attention_b16_kernel<1, false>), grid, dim3(256), 0, s, qkv, o, nitems);
     } else {
-        if (out_split) hipLaunchKernelGGL((vit_attention_b16_kernel<3, true>), dim3(B * NH), dim3(256), 0, s, qkv, o);
-        else hipLaunchKernelGGL((vit_attention_b16_kernel<3, false>), dim3(B * NH), dim3(256), 0, s, qkv, o);
+        if (out_split) hipLaunchKernelGGL((vit_attention_b16_kernel<3, true>), grid, dim3(256), 0, s, qkv, o, nitems);
+        else hipLaunchKernelGGL((vit_attention_b16_kernel<3, false>), grid, dim3(256), 0, s, qkv, o, nitems);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

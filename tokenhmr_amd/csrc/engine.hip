@@ -36,7 +36,8 @@ constexpr float FOCAL = 5000.0f, IMG = 256.0f;
 // small-batch ViT path (gemm_ring_kernel): used while M = 192*B <= kSmallM; crossovers measured in profiles/r1_small_gemm_variants.log
 constexpr int kSmallM = 1152, kSplitKMax = 4;     // B <= 6
 constexpr int kKeysplitMaxB = 2;                  // key-split attention kernel: one and two crops
-constexpr bool kAttnB16 = false;                  // split3 mode's attention: false = the fp32-MFMA kernels with split3 output, true = attention_b16.hip
+constexpr bool kAttnB16 = true;                   // split3 mode's attention: true = attention_b16.hip (the mode's arithmetic: three bf16 pieces per operand on the bf16
+                                                  // matrix pipe; 4.03 -> 3.48 ms per 64-crop step, profiles/r4r_engine_b64_attention_b16_ab.log), false = the fp32-MFMA kernels with split3 output
 // mid-size batches: from 7 to 16 crops proj / fc2 (N = 1280: 110-240 output tiles of 128x128 on 512 resident slots) run split-K 2
 // on the big LDS-DMA tiles (measured per batch size and per GEMM, profiles/r3d_mid_batch_splitk_sweep.log, r3f_mid_batch_forced_tile.log:
 // -10 % per call at 9 and 10 crops, -2.5 ... -3.7 % at 11 ... 16, -2 % at 7 and 8 with the 64x128 tile; from 17 on the unsplit launch
