@@ -361,3 +361,51 @@ def test_split3_handover_timeout_is_reported_once_and_the_engine_falls_back(buil
     e.status()
     for k in ("pred_vertices", "pred_cam", "token_idx", "cls_logits_softmax"):
         assert torch.equal(out[k], ref[k]), k
+
+
+@pytest.mark.parametrize("mode", ["f32", "split3"])
+def test_forward_is_captured_into_a_hip_graph_and_replays_bit_identically(built_lib, cuda_dev, mode):
+    """include/tokenhmr_hip.h: thmr_forward allocates nothing and never synchronises the host, "so a call in either mode can be captured
+    in a hipGraph".  Captured through torch.cuda.CUDAGraph (hipGraph on ROCm) on a side stream at 2 crops (exact-fp32 kernels, key-split
+    attention, the small-batch GEMM regime) and at 40 crops (split3: the persistent fc2 with its flag hand-over, the bf16-pipe attention
+    walking two items per workgroup, the persistent decoder kernel with its grid barrier): every replay must reproduce the eager call bit
+    for bit — a kernel whose device-side state (barrier counters, hand-over flags) is not re-armed by stream order alone would differ or hang —
+    with new inputs copied into the captured buffer between replays."""
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd import weights as W
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    from tokenhmr_amd.engine import Engine
+    cfg = HMRConfig(vit_depth=2, dec_depth=6)
+    eng = Engine(cfg, max_batch=40, device=cuda_dev)
+    eng.load_state(W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0))
+    eng.load_smpl(make_synthetic_smpl(cfg, 0))
+    eng.finalize()
+    eng.set_vit_gemm(mode)
+    keys = ("pred_vertices", "pred_keypoints_2d", "pred_cam", "token_idx", "cls_logits_softmax")
+    for B in (2, 40):
+        imgs = [torch.randn(B, 3, 256, 256, generator=torch.Generator().manual_seed(50 + B + i)).to(cuda_dev) for i in range(3)]
+        want = []
+        for im in imgs:
+            o = eng.forward(im, outputs=eng._alloc_outputs(B, taps=False, want_probs=True))
+            want.append({k: o[k].clone() for k in keys})
+        eng.status()
+        buf = imgs[0].clone()
+        outs = eng._alloc_outputs(B, taps=False, want_probs=True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            eng.forward(buf, outputs=outs)                      # warm-up on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            eng.forward(buf, outputs=outs)
+        for rep in range(2):
+            for im, w in zip(imgs, want):
+                buf.copy_(im)
+                for k in keys:
+                    outs[k].zero_()
+                graph.replay()
+                torch.cuda.synchronize()
+                for k in keys:
+                    assert torch.equal(outs[k], w[k]), (mode, B, rep, k)
+        eng.status()
