@@ -313,7 +313,61 @@ __global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* 
             inv[qt] = 1.0f / l;
         }
         if constexpr (SPLIT) {
-            store_o_split3<QT>(reinterpret_cast<char*>(out), (int64_t)cur.crop * NTOK + cur.q0, cur.hcol, l15, g, o, inv);
+            // A head's slice of a split3 row is 480 contiguous bytes (k-groups 10 h ... 10 h + 9 x 3 pieces x 16 bytes), but the MFMA leaves a
+            // lane with ONE row and 8 of its columns: written from the registers, a wave's store instruction touches 16 rows x two lines for
+            // 16 bytes each, three times over (the pieces H, M, L of a k-group are 16 bytes apart).  The V^T image is dead between the
+            // item's last P.V and the next block's write_v (one barrier away on both sides), so each wave assembles its 16-row tile there —
+            // rows of exactly 480 bytes, lane (l15, g) writes its chunks — and streams it out as 7.5 instructions of 64 x 16 CONSECUTIVE
+            // bytes: chunk c = 64 i + lane of the tile is LDS byte 16 c and row c / 30 of the operand.  Measured (profiles/r4y_ vs r4r_):
+            // 64-query workgroups 106.5 vs 111.0 us per launch at 64 crops, 27.1 vs 28.3 at 16; 192-query workgroups 98.9 vs 99.1 — the
+            // 16 us that split3 output costs over fp32 output there (82.9 us) are not the store pattern.
+            __syncthreads();                                   // every wave is done with the V^T image
+            char* const stg = vimg + wave * (16 * 480);
+            char* const orow = reinterpret_cast<char*>(out) + ((int64_t)cur.crop * NTOK + cur.q0) * (DIM * 6) + cur.hcol * 6;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                char* const srow = stg + l15 * 480;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {               // tiles (dt, dt + 1) = (0, 1), (2, 3): after the swap an even-g lane holds 8 columns of the first, an odd-g lane of the second
+                    f32x4 x = o[qt][2 * pr] * inv[qt], y = o[qt][2 * pr + 1] * inv[qt];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+                        const u32x2_t sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[j]), __float_as_uint(y[j]), false, false);
+                        x[j] = __uint_as_float(sw.x);
+                        y[j] = __uint_as_float(sw.y);
+                    }
+                    uint32_t H[4], M[4], L[4];
+                    split3_pair(x[0], x[1], H[0], M[0], L[0]);
+                    split3_pair(x[2], x[3], H[1], M[1], L[1]);
+                    split3_pair(y[0], y[1], H[2], M[2], L[2]);
+                    split3_pair(y[2], y[3], H[3], M[3], L[3]);
+                    char* c = srow + ((2 * pr + (g & 1)) * 2 + (g >> 1)) * 48;      // k-group (16 dt + 8 (g >> 1)) / 8 of the slice, dt = 2 pr + (g & 1)
+                    *reinterpret_cast<u32x4*>(c) = u32x4{H[0], H[1], H[2], H[3]};
+                    *reinterpret_cast<u32x4*>(c + 16) = u32x4{M[0], M[1], M[2], M[3]};
+                    *reinterpret_cast<u32x4*>(c + 32) = u32x4{L[0], L[1], L[2], L[3]};
+                }
+                {                                              // tile dt = 4: columns 64 + 4 g ... + 3 = the 8-byte half (g & 1) of k-group 8 + (g >> 1)
+                    const f32x4 v = o[qt][4] * inv[qt];
+                    uint32_t H[2], M[2], L[2];
+                    split3_pair(v[0], v[1], H[0], M[0], L[0]);
+                    split3_pair(v[2], v[3], H[1], M[1], L[1]);
+                    char* c = srow + (8 + (g >> 1)) * 48 + (g & 1) * 8;
+                    *reinterpret_cast<u32x2v*>(c) = u32x2v{H[0], H[1]};
+                    *reinterpret_cast<u32x2v*>(c + 16) = u32x2v{M[0], M[1]};
+                    *reinterpret_cast<u32x2v*>(c + 32) = u32x2v{L[0], L[1]};
+                }
+                // wave-private: the wave's own LDS writes are complete before its reads are issued (same queue, in order)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = i * 64 + lane;               // chunk of the 16 x 30 tile
+                    if (i < 7 || lane < 32) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(stg + c * 16);
+                        const int r = c / 30;
+                        *reinterpret_cast<u32x4*>(orow + (int64_t)(qt * 16 + r) * (DIM * 6) + (c - r * 30) * 16) = v;
+                    }
+                }
+            }
         } else {
             float* obase = out + (int64_t)cur.crop * NTOK * DIM + cur.hcol;
 #pragma unroll
