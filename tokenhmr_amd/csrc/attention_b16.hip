@@ -390,7 +390,8 @@ int launch_vit_attention_b16(const float* qkv, void* out, int B, bool out_split,
     if (B <= 0 || (qt != 0 && qt != 1 && qt != 3)) return -1;
     if (qt == 0) qt = B <= 20 ? 1 : 3;        // stand-alone, us per launch qt = 1 / 3: 20.2 / 25.7 at 8 crops, 28.3 / 31.6 at 16, 53.1 / 50.0 at 32 (profiles/r4q_, r4r_attention_b16_*.jsonl)
     float* o = reinterpret_cast<float*>(out);
-    const int nitems = B * NH * (3 / qt);                        // a multiple of 16
+    const int nitems = B * NH * (3 / qt);                        // a multiple of 16: the kernel splits items and grid by the 8 XCDs
+    static_assert(NH % 8 == 0, "items per crop must divide by the XCD count");
     const dim3 grid(nitems < 512 ? nitems : 512);
     if (qt == 1) {
         if (out_split) hipLaunchKernelGGL((vit_attention_b16_kernel<1, true>), grid, dim3(256), 0, s, qkv, o, nitems);
