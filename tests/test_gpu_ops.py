@@ -619,6 +619,41 @@ def test_vit_attention_b16(built_lib, cuda_dev, B):
         assert err_hip <= max(4 * err_cpu, 2e-5 if scale > 1 else 5e-6), (scale, err_hip, err_cpu)
 
 
+def test_vit_attention_b16_stress_determinism(built_lib, cuda_dev):
+    """The bf16-pipe attention stages K / V through registers into two LDS images that are rewritten every block while the other waves may
+    still be a phase behind, walks two items per workgroup at 64 crops and reuses the V^T image as the staging area of its split3 output: a
+    missing barrier shows up as a run-to-run difference.  30 repeats at 64 crops (both outputs) interleaved with launches that move the
+    co-resident workgroups' timing (the fp32-MFMA attention kernel, a LayerNorm), then the same on a second stream concurrently."""
+    from tokenhmr_amd import ops
+    B = 64
+    qkv = _rand(B, 192, 3840, seed=77)
+    qkv[:, :, :1280] *= 80 ** -0.5
+    d = qkv.to(cuda_dev)
+    first, first_s = ops.vit_attention_b16(d), ops.vit_attention_b16(d, out_split=True)
+    assert torch.equal(first_s, ops.split3(first.reshape(B * 192, 1280)))
+    x = _rand(4096, 1280, seed=3).to(cuda_dev)
+    gam, bet = torch.ones(1280, device=cuda_dev), torch.zeros(1280, device=cuda_dev)
+    for i in range(30):
+        if i % 3 == 1:
+            ops.vit_attention(d[:16].contiguous())
+        if i % 3 == 2:
+            ops.layernorm(x, gam, bet, 1e-6)
+        assert torch.equal(ops.vit_attention_b16(d, out_split=True), first_s), i
+        assert torch.equal(ops.vit_attention_b16(d), first), i
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    outs = []
+    for i in range(6):
+        a = ops.vit_attention_b16(d, out_split=True)
+        with torch.cuda.stream(side):
+            b = ops.vit_attention_b16(d[:40].contiguous(), out_split=True)
+        outs.append((a, b))
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for a, b in outs:
+        assert torch.equal(a, first_s) and torch.equal(b, first_s[:40 * 192])
+
+
 def test_rot6d(built_lib, cuda_dev):
     from tokenhmr_amd import ops
     from oracle import tokenhmr_oracle as O
