@@ -411,7 +411,10 @@ def test_split16_stage_image_reads_are_conflict_free_under_gfx950_lane_groups():
     src = open(os.path.join(os.path.dirname(_cabi.__file__), "csrc", "gemm_split16.hip")).read()
     m = re.search(r"constexpr int rot16\(int row\) \{ return (.+?); \}", src)
     assert m, "rot16 not found in gemm_split16.hip"
-    rot_src = eval("lambda row: " + m.group(1))
+    assert m.group(1).replace(" ", "") == "((row>>2)&1)*2", f"rot16 changed ({m.group(1)}): restate it below and re-run the model"
+
+    def rot_src(row):                       # the source's rot16, restated (checked textually above)
+        return ((row >> 2) & 1) * 2
 
     def cycles(rot, pc, tile_row0):
         def addr(lane):
