@@ -31,8 +31,11 @@ extern "C" {
  * random); the resample tables / padding row / flag words of the weight arena are written by thmr_load_weights on the LOADING
  * engine (round 1: thmr_create on every engine; round 2: thmr_finalize_weights(0)) and validated — not written — by
  * thmr_finalize_weights(assume_all_loaded = 1).
- * 3 (round 3): thmr_set_vit_gemm / thmr_get_vit_gemm and the split3 operators added (no struct changed). */
-#define THMR_ABI_VERSION 3
+ * 3 (round 3): thmr_set_vit_gemm / thmr_get_vit_gemm and the split3 operators added (no struct changed).
+ * 4 (round 5): an engine is CREATED in mode 1 ("split3") — thmr_finalize_weights builds the split3 weight copies, thmr_forward runs the bf16
+ *   matrix pipe from 3 crops on — and thmr_set_vit_gemm(0) is the opt-out to exact-fp32 MFMA (up to ABI 3 it was the other way round); no
+ *   struct or signature changed. */
+#define THMR_ABI_VERSION 4
 
 typedef enum {
     THMR_OK = 0,
@@ -150,10 +153,11 @@ int thmr_weight_arena(thmr_engine* e, void** ptr_dev, size_t* bytes);
 int thmr_forward(thmr_engine* e, const float* img_dev, int32_t B, const thmr_outputs* out, void* stream);
 
 /* Device-side health of the engine: synchronises `stream` and returns THMR_ERR_HIP if a kernel of this engine reported an
- * error asynchronously (today: the bounded grid barrier of the persistent decoder kernel timed out instead of hanging the GPU).
- * thmr_forward itself never synchronises; it does look at a host-mapped copy of the same error word on entry, so a timeout is
- * also reported by the NEXT forward-type call.  Either way the error is returned once: the engine drains the device, resets
- * its barrier words and switches its head to the launch chain (no co-residency needed), so re-submitting the batch works. */
+ * error asynchronously — the bounded grid barrier of the persistent decoder kernel, or a bounded hand-over wait of the persistent split3 GEMM,
+ * timed out instead of hanging the GPU.  thmr_forward itself never synchronises; it does look at host-mapped copies of the same error words
+ * on entry, so a timeout is also reported by the NEXT forward-type call.  Either way the error is returned once: the engine drains the
+ * device, resets the barrier words / hand-over workspace and switches to the launch chain / per-tile kernel (no co-residency needed), so
+ * re-submitting the batch works. */
 int thmr_engine_status(thmr_engine* e, void* stream);
 
 /* Diagnostics: with THMR_DEC_TIMELINE=1 in the environment at thmr_finalize_weights, workgroup 0 of the persistent decoder kernel
@@ -181,41 +185,37 @@ int thmr_encode_tokens(thmr_engine* e, const float* pose_dev, int32_t B, int32_t
 int thmr_vq_decode(thmr_engine* e, const float* probs_dev, int32_t B, float* pose6d_dev, void* stream);
 
 /* Stateless operator entry points (unit parity of individual kernels; no engine needed). */
-/* C[M,N] = epilogue(A[M,K] . W[N,K]^T); epi: 0 none, 1 +bias, 2 +bias gelu(erf), 3 +bias relu,
- * 4 resid + (acc+bias), 5 (+bias)*qscale on cols < qcols, 6 +bias +pos_embed (patch embed).  K % 32 == 0; lda/ldc in
- * elements, multiples of 4, < 2^22.  variant: -1 = tile picked by the cost model (what the engine uses); 7 / 8 / 10 / 9 = the
- * 128x128 / 128x160 / 128x96 / 64x64 LDS-DMA tiles; 0 / 1 register-staged 128x128 / 128x160 (A/B only); 2 skinny (M <= 64);
- * 100 + j (110 + j) = 64x64 ring kernel, 4- (8-) deep, split-K 2^j; 11 = tiny-M kernel (32x32 tiles, K split over the 8 waves of a
- * workgroup; K % 256 == 0; epilogues 0-5; what the engine uses for the VQ decoder up to six crops); 120 = small-M kernel on 16x16x4
- * tiles (64x48 workgroup tile; epilogues 0-3, 5; the engine's qkv at one and two crops); 200 + t / 400 + t = split-K 2 / 4 on big tile t.
- * Every variant sums K in the same order except split-K, the tiny-M kernel and variant 120. */
+/* C[M,N] = epilogue(A[M,K] . W[N,K]^T) in exact fp32 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32; csrc/gemm_f32.hip).  epi: 0 none, 1 +bias,
+ * 2 +bias gelu(erf), 3 +bias relu, 4 resid + (acc+bias), 5 (+bias)*qscale on cols < qcols, 6 +bias +pos_embed (patch embed).  K % 32 == 0;
+ * lda/ldc in elements, multiples of 4, < 2^22.  variant (the ids the ENGINE uses; the A/B-only ids are listed in tokenhmr_amd/ops.py):
+ *   -1 = tile picked by the cost model over the 128x128 / 128x160 / 128x96 / 64x64 LDS-DMA tiles (7 / 8 / 10 / 9 force one);
+ *   2 = skinny (M <= 64); 100 + j = 64x64 ring kernel, 4-deep, split-K 2^j (few crops); 11 = tiny-M kernel (32x32 tiles, K split over the
+ *   8 waves; K % 256 == 0; epilogues 0-5; the VQ decoder up to six crops); 120 = small-M kernel on 16x16x4 tiles (qkv at one and two crops);
+ *   200 + t / 400 + t = split-K 2 / 4 on big tile t.  Every variant sums K in the same order except split-K, the tiny-M kernel and 120. */
 int thmr_op_gemm(const float* A_dev, int64_t lda, const float* W_dev, const float* bias_dev, const float* resid_dev,
                  float* C_dev, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi, float qscale, int32_t qcols,
                  int32_t variant, void* stream);
-/* fp32 GEMM on the bf16 matrix pipe (csrc/gemm_split.hip) — what the engine's OPT-IN mode thmr_set_vit_gemm(1) runs for the ViT GEMMs
- * (by default thmr_forward stays on exact-fp32 MFMA); also an operator of its own, measured beside thmr_op_gemm.  Every fp32 operand is carried as three bf16 pieces h + m + l (x == h + m + l
- * up to 2^-24 |x|) in the "split3" layout [rows][K/8][3][8] bf16 (row stride 6 * ld bytes); the product keeps the six piece pairs
- * down to 2^-16 of |a b| (what is dropped is below one fp32 rounding of the product), accumulation is fp32 in the MFMA.
- * thmr_op_split3 converts (K % 8 == 0, ld_dst % 8 == 0, ld_dst >= K, ld_src % 4 == 0).  thmr_op_gemm_split3: A / W split3 with row
- * strides lda / ldw in fp32-equivalents (multiples of 8), K % 32 == 0; bias / resid / C fp32; epi 0, 1, 2, 4, 5 as thmr_op_gemm;
- * variant -1 = the engine's rule; 0 = 128x256 tile, 8 waves; 1 = 128x256, 4 waves; 2 = 128x128, 4 waves; 4 = 256x256, 4 waves of
- * 128x128 (all bit-identical to each other); 100 + j = the small-M ring kernel (64x64 tiles, 4-deep LDS-DMA ring) with split-K 2^j, j <= 2 — 100 is bit-identical to the big
- * tiles, the split ones associate K differently; 202 / 204 = split-K 2 / 4 on the big tiles (the engine's 5 ... 31 crops use 2, 3 and 4 crops 4);
- * 300 = 256 PERSISTENT workgroups over a tile stream (csrc/gemm_split_persist.hip: M % 128 == 0, N % 256 == 0, at least 256 tiles; a ragged
- * last round is split along K with the accumulators handed from one workgroup to the next through memory — bit-identical to 0 / 2; what the
- * engine runs at 32 crops and more); + 1000 (1000, 1002, 1202, 1204, 1300; epi 0 / 4): A is a ROW-BLOCKED split3 operand
- * [rows / 32][K / 8][3][32][8] (rows padded to 32; chunk (r, k-group, piece) at (r / 32) K 192 + (k-group 3 + piece) 512 + (r % 32) 16 bytes) —
- * the form the engine's fc1 hands fc2.
- * Variants 1, 4, 100-102 and (3, 31, 32, 34, 37: schedule experiments of scripts/split3_bench.py, epilogue 0 only; 31-37 are timing-only
- * and return garbage) exist in the experiments build of the library only (libtokenhmr_hip_exp.so, -DTHMR_EXPERIMENTS). */
+/* fp32 GEMM on the bf16 matrix pipe (csrc/gemm_split16.hip) — what the engine's DEFAULT mode (thmr_set_vit_gemm 1) runs for the ViT GEMMs;
+ * also an operator of its own, measured beside thmr_op_gemm.  Every fp32 operand is carried as three bf16 pieces h + m + l (x == h + m + l
+ * up to 2^-24 |x|) in the "split3" layout [rows][K/8][3][8] bf16 (row stride 6 * ld bytes); the product keeps the six piece pairs down to
+ * 2^-16 of |a b| (what is dropped is below one fp32 rounding of the product), accumulation is fp32 in the MFMA.
+ * thmr_op_split3 converts (K % 8 == 0, ld_dst % 8 == 0, ld_dst >= K, ld_src % 4 == 0).  thmr_op_gemm_split3: A / W split3 with row strides
+ * lda / ldw in fp32-equivalents (multiples of 8), K % 32 == 0; bias / resid / C fp32; epi 0, 1, 2, 4, 5 as thmr_op_gemm.  variant:
+ *   -1 = the engine's rule; 0 = 128x256 tile, 8 waves; 2 = 128x128, 4 waves (bit-identical to each other);
+ *   202 / 204 = split-K 2 / 4 on the big tiles (the engine's 5 ... 31 crops use 2, 3 and 4 crops 4);
+ *   300 = 256 PERSISTENT workgroups over a tile stream (M % 128 == 0, N % 256 == 0, at least 256 tiles, a 256-CU device; a ragged last round
+ *         is split along K with the accumulators handed from one workgroup to the next through memory — bit-identical to 0 / 2; the
+ *         engine's fc2 at 32 crops and more);
+ *   + 1000 (1000, 1002, 1202, 1204, 1300; epi 0 / 4): A is a ROW-BLOCKED split3 operand [rows / 32][K / 8][3][32][8] (rows padded to 32;
+ *         chunk (r, k-group, piece) at (r / 32) K 192 + (k-group 3 + piece) 512 + (r % 32) 16 bytes) — the form the engine's fc1 hands fc2.
+ * (Ids of kernels that lost their A/B exist in the experiments build only: tokenhmr_amd/ops.py lists them.) */
 int thmr_op_split3(const float* src_dev, int64_t ld_src, void* dst_dev, int64_t ld_dst, int64_t rows, int32_t K, void* stream);
 int thmr_op_gemm_split3(const void* A_split_dev, int64_t lda, const void* W_split_dev, int64_t ldw, const float* bias_dev,
                         const float* resid_dev, float* C_dev, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi,
                         float qscale, int32_t qcols, int32_t variant, void* stream);
 /* the same product with the epilogue's result written as a split3 operand (the next GEMM's A; row stride 6 * ldcs bytes, N % 8 == 0,
  * ldcs % 8 == 0) instead of fp32: bit-identical to thmr_op_split3 of thmr_op_gemm_split3's output.  epi 0, 1, 2, 5; variant -1, 0, 2;
- * 302 = the persistent kernel with operand roles swapped and v_permlane32_swap in the epilogue (epi 0 / 2); + 1000 = the result in the
- * row-blocked form (Cs holds ceil(M / 32) * 32 rows); 1, 4, 100 (ring kernel), 301 (persistent, LDS epilogue): experiments build only. */
+ * 302 = the persistent kernel (epi 0 / 2); + 1000 = the result in the row-blocked form (Cs holds ceil(M / 32) * 32 rows). */
 int thmr_op_gemm_split3_out_split3(const void* A_split_dev, int64_t lda, const void* W_split_dev, int64_t ldw, const float* bias_dev,
                                    void* C_split_dev, int64_t ldcs, int32_t M, int32_t N, int32_t K, int32_t epi, float qscale,
                                    int32_t qcols, int32_t variant, void* stream);
@@ -315,17 +315,23 @@ const char* thmr_collective_last_error(void);
  * on = 0 off, 1 every class, 2 only the four ViT GEMM classes, 3 only fc1 (the dominant kernel), sampled.  An event pair costs ~2-3 us
  * of stream time: 128 pairs per call (on = 2) were 0.75 % of a B = 64 step and 20 % of a B = 1 call (round 3: the facade call
  * without events was FASTER than the timed loop), which is why bench.py times with on = 3, which samples every 4th fc1 launch (8 pairs per call; all 32 launches have one shape). */
-/* How the four ViT GEMMs (qkv / proj / fc1 / fc2: 97 % of the path's arithmetic) are multiplied.
- *   0 (default): exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) — bitwise an fmaf chain; every parity claim and the headline benchmark refer to it.
- *   1: "split3" — each fp32 operand as three bf16 pieces, six bf16 MFMA products per element pair, fp32 accumulation
- *      (csrc/gemm_split.hip; thmr_op_gemm_split3 is the same kernel).  fp32-GRADE, not bitwise fp32: the measured error against an fp64
- *      product is no larger than the exact-fp32 kernel's (tests/test_gpu_ops.py::test_gemm_split3), at ~1.6x its rate.  Applies to calls of at
- *      least 3 crops (one and two crops run the exact-fp32 kernels regardless).  Four ranges, a crop's result is batch-independent within
- *      each: 3 and 4 crops split the K sums of proj and fc2 four ways, 5 ... 15 two ways, 16 ... 31 only fc2's (two ways), 32 and more neither; the decoder's stacked to_kv GEMM runs the same way, and so does the ViT attention (thmr_op_vit_attention_b16: q k^T and p v as six bf16 products per pair, any batch size of the mode, a crop's result batch-independent); LayerNorm, the epilogues and the rest of the head are unchanged.
- * Setting 1 needs finalized weights; the engine then owns a split3 copy of the ViT weights (1.5x their fp32 bytes) and the operand
- * buffers (+ the partial-sum planes of its split-K ranges), rebuilt by thmr_finalize_weights while the mode is on and kept until
- * thmr_destroy (setting 0 again does not free them).  Like thmr_forward it allocates nothing per call, so a call in either mode can be
- * captured in a hipGraph.  Returns 0 / negative; thmr_get_vit_gemm returns the mode. */
+/* How the four ViT GEMMs (qkv / proj / fc1 / fc2: 97 % of the path's arithmetic), the ViT attention and the decoder's to_kv GEMM multiply.
+ * Both modes are fp32 in, fp32 accumulate, fp32 out.
+ *   1 (DEFAULT, ABI 4): "split3" — each fp32 operand as three bf16 pieces, six bf16 MFMA products per element pair, fp32 accumulation
+ *      (csrc/gemm_split16.hip, attention_b16.hip; v_mfma_f32_16x16x32_bf16).  fp32-GRADE, not bitwise fp32: the measured error against an
+ *      fp64 product is no larger than the exact-fp32 kernel's (tests/test_gpu_ops.py::test_gemm_split3), at ~1.55x its rate end to end.
+ *      It is what bench.py's `value`, the facade (tokenhmr_amd.model.load_tokenhmr) and every parity claim of the default path refer to:
+ *      0 of 40,960 pose-token indices differ from the reference's on the four 64-crop fixtures, joints / vertices within
+ *      max(0.1 mm, 2 x the reference's own fp32-vs-fp64 distance) (tests/test_gpu_model.py).  Applies to calls of at least 3 crops (one
+ *      and two crops run the exact-fp32 kernels in either mode).  Four ranges, a crop's result is batch-independent within each: 3 and 4
+ *      crops split the K sums of proj and fc2 four ways, 5 ... 15 two ways, 16 ... 31 only fc2's (two ways), 32 and more neither.
+ *      LayerNorm, the epilogues and the rest of the head are fp32 arithmetic in both modes.
+ *   0 (opt-out): exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32) everywhere — bitwise an fmaf chain.
+ * Mode 1 needs the engine-owned split3 copy of the ViT weights (1.5x their fp32 bytes) and the operand buffers (+ the partial-sum planes
+ * of its split-K ranges): built by thmr_finalize_weights while the mode is on (i.e. by default) or by thmr_set_vit_gemm(1) on finalized
+ * weights, kept until thmr_destroy (setting 0 does not free them).  An engine created with max_batch < 3 never runs the mode and builds
+ * nothing.  Like thmr_forward the switch allocates nothing per call, so a call in either mode can be captured in a hipGraph.
+ * Returns 0 / negative; thmr_get_vit_gemm returns the mode. */
 int thmr_set_vit_gemm(thmr_engine* e, int32_t mode, void* stream);
 int thmr_get_vit_gemm(thmr_engine* e);
 int thmr_prof_enable(thmr_engine* e, int32_t on);

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtokenhmr_hip.so")
 LIB_PATH_EXP = os.path.join(_HERE, "lib", "libtokenhmr_hip_exp.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "tokenhmr_hip.h")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PROF_NAMES = ["gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "attention", "layernorm", "patch_embed",
               "dec_kv", "head", "lbs"]
 

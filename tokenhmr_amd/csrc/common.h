@@ -378,6 +378,7 @@ size_t gemm_split3_persist_ws_bytes();
 bool gemm_split3_persist_ok(const GemmArgs& a);        // shape served by the persistent kernel (M % 128, N % 256, >= 256 tiles, no split-K)
 int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws, hipStream_t s);
 int gemm_split3_persist_error(void* ws, hipStream_t s, unsigned* err_out);   // synchronises s; *err_out != 0: a hand-over spin timed out
+int gemm_split3_persist_bind_host_err(void* ws, unsigned* const* host_err_slot, hipStream_t s);   // a timed-out consumer ALSO writes the host-mapped word *slot (slot: stable storage; after zeroing ws)
 void* gemm_split3_persist_op_ws(hipStream_t s);        // zeroed workspace per (device, stream) for the stateless operators
 // gemm_split16.hip: the split3 GEMM on v_mfma_f32_16x16x32_bf16 (what launch_gemm_split3 / _splitk / _persist run since round 4):
 // one workgroup per tile (wide = 128 x 256 on 8 waves, else 128 x 128 on 4; a.ksplit copies of the grid) or 256 persistent workgroups

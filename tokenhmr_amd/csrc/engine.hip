@@ -111,10 +111,12 @@ struct thmr_engine {
     bool attn_b16 = kAttnB16;         // split3 mode: the attention on the bf16 matrix pipe too (csrc/attention_b16.hip); THMR_ATTN_B16=0 / 1: A/B only
     int mid_split_force[2] = {-1, -1};   // THMR_MID_SPLIT=<p><f> (digits 0|2|4): force the split factors of proj and fc2 above 6 crops where the partial-sum buffer allows (A/B only)
     bool smpl_loaded = false, finalized = false;
-    // thmr_set_vit_gemm(1): the four ViT GEMMs of batches of at least kSplit3LowMinB (3) crops run on the bf16 matrix pipe with fp32 operands
-    // carried as three bf16 pieces (csrc/gemm_split.hip).  Engine-owned memory: the split3 copies of the ViT weights (1.5 x their fp32
-    // size) and the split3 activation operands (M x (1280 + 5120) x 6 bytes).  Off (0) = exact-fp32 MFMA everywhere, the default.
-    int vit_gemm_mode = 0;
+    // 1 (the DEFAULT since round 5 / ABI 4: what thmr_forward, the facade and bench.py's `value` all run): the four ViT GEMMs, the attention
+    // and the decoder's to_kv GEMM of batches of at least kSplit3LowMinB (3) crops run on the bf16 matrix pipe with fp32 operands carried as
+    // three bf16 pieces (csrc/gemm_split16.hip, attention_b16.hip).  Engine-owned memory, built by thmr_finalize_weights: the split3 copies of
+    // the ViT weights (1.5 x their fp32 size) and the split3 activation operands (M x (1280 + 5120) x 6 bytes).  thmr_set_vit_gemm(0) = the
+    // opt-out: exact-fp32 MFMA everywhere.  An engine whose max_batch is below 3 never runs the mode and builds nothing for it.
+    int vit_gemm_mode = 1;
     bool split3_small = false;        // THMR_SPLIT3_SMALL=1: the split3 mode also serves up to six crops (ring kernel on split3 operands) — measured SLOWER, A/B only
     int split3_fc2_split = 2;         // THMR_SPLIT3_FC2_SPLIT=1: fc2 of the split3 mode unsplit from 16 crops on (A/B only)
     int split3_min_b = 0;             // THMR_SPLIT3_MIN_B=<n>: A/B knob for the smallest batch the split3 mode serves (0 = kSplit3LowMinB)
@@ -136,7 +138,8 @@ struct thmr_engine {
     struct SplitW { const char *qkv, *proj, *fc1, *fc2; };
     std::vector<SplitW> vitw_s;
     const char* kv_s = nullptr;       // split3 copy of the decoder's stacked to_kv weights (dec_depth * 1024 rows x 1280)
-    unsigned* host_err = nullptr;     // host-mapped sticky error word of the persistent decoder kernel (hipHostMalloc)
+    unsigned* host_err = nullptr;     // host-mapped sticky error words (hipHostMalloc, 64 bytes): [0] the persistent decoder kernel's grid barrier, [1] the persistent split3 GEMM's hand-over
+    unsigned* s3_host_err = nullptr;  // = host_err + 1; its ADDRESS is the stable source of the copy that binds it into the hand-over workspace
     std::string err;
     // derived / constant regions (float offsets in weight arena)
     size_t o_kv_all = 0, o_ro_w = 0, o_ro_b = 0;
@@ -444,6 +447,9 @@ GemmArgs mk(const float* A, int64_t lda, const float* W, int64_t ldw, const floa
     return a;
 }
 
+int launch_decoder_serialised(thmr_engine* e, const DecParams& d, hipStream_t st);   // below (turnstile of the persistent kernels)
+int launch_split3_persist_serialised(thmr_engine* e, const GemmArgs& a, int epi, int mode, hipStream_t st);
+
 // ---------------------------------------------------------------------------------------------- ViT-H
 int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipStream_t st) {
     const int M = B * TOK;
@@ -507,7 +513,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
     const float* lastn_w = e->hot.lastn_w;
     const float* lastn_b = e->hot.lastn_b;
     const int s3_min = e->split3_min_b > 0 ? e->split3_min_b : kSplit3LowMinB;
-    if (e->vit_gemm_mode == 1 && B >= s3_min) {
+    if (e->vit_gemm_mode == 1 && B >= s3_min && e->split_w) {
         // 3 ... 4 / 5 ... 15 crops: proj / fc2 split K four / two ways into `part`, reduced (in a fixed order) by the residual + LayerNorm kernel,
         // as in the exact-fp32 path's regimes; 16 ... 31: only fc2 (two ways); 32 and more: unsplit.  One factor per range: a crop's result is
         // batch-independent within it.
@@ -541,7 +547,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             a.qscale = qscale; a.qcols = DIM;
             a.a_blk = a_blk;
             const int bit = cls == THMR_PROF_GEMM_QKV ? 1 : cls == THMR_PROF_GEMM_PROJ ? 2 : cls == THMR_PROF_GEMM_FC2 ? 8 : 0;
-            if (e->s3_ws && e->s3_persist && (e->s3_persist_mask & bit) && gemm_split3_persist_ok(a)) return launch_gemm_split3_persist(a, epi, 0, e->s3_ws, st);
+            if (e->s3_ws && e->s3_persist && (e->s3_persist_mask & bit) && gemm_split3_persist_ok(a)) return launch_split3_persist_serialised(e, a, epi, 0, st);
             return launch_gemm_split3(a, epi, -1, st);
         };
         {
@@ -577,7 +583,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 a.c_split = bs; a.ldcs = MLP;
                 a.cs_blk = bs_blk;
                 if (e->s3_ws && e->s3_persist && e->s3_fc1_mode && (e->s3_persist_mask & 4) && gemm_split3_persist_ok(a))
-                    LAUNCH_OK(launch_gemm_split3_persist(a, EPI_BIAS_GELU, 2, e->s3_ws, st));
+                    LAUNCH_OK(launch_split3_persist_serialised(e, a, EPI_BIAS_GELU, 2, st));
                 else
                     LAUNCH_OK(launch_gemm_split3(a, EPI_BIAS_GELU, -1, st));
             }
@@ -708,7 +714,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
     return 0;
 }
 
-int launch_decoder_serialised(thmr_engine* e, const DecParams& d, hipStream_t st);   // below (decoder turnstile)
+
 
 // ---------------------------------------------------------------------------------------------- head
 // DecodeTokens.forward (tokenization/models/vanilla_pose_vqvae.py:294-297): soft codebook lookup
@@ -792,7 +798,7 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
             // on the bf16 matrix pipe (1.5 -> 1.0 ms at 64 crops)
             LAUNCH_OK(launch_split3(ctx, DIM, e->split_act, DIM, M, DIM, st));
             GemmArgs a = mk(reinterpret_cast<const float*>(e->split_act), DIM, reinterpret_cast<const float*>(e->kv_s), DIM, nullptr, nullptr, 0, big, ldkv, M, ldkv, DIM);
-            if (e->s3_ws && e->s3_persist && (e->s3_persist_mask & 16) && gemm_split3_persist_ok(a)) LAUNCH_OK(launch_gemm_split3_persist(a, EPI_NONE, 0, e->s3_ws, st));
+            if (e->s3_ws && e->s3_persist && (e->s3_persist_mask & 16) && gemm_split3_persist_ok(a)) LAUNCH_OK(launch_split3_persist_serialised(e, a, EPI_NONE, 0, st));
             else LAUNCH_OK(launch_gemm_split3(a, EPI_NONE, -1, st));
         } else {
             GemmArgs a = mk(ctx, DIM, e->warena + e->o_kv_all, DIM, nullptr, nullptr, 0, big, ldkv, M, ldkv, DIM);
@@ -997,11 +1003,13 @@ int write_arena_constants(thmr_engine* e, hipStream_t st) {
     return 0;
 }
 
-// The persistent decoder kernel needs ALL its workgroups resident at once (grid barrier) and, from 49 crops on, asks for every
-// CU.  Two of them launched concurrently by two engines on two streams could each grab part of the chip and wait for the rest
-// until the barrier's timeout fires.  So when a process has more than one engine on a device, those launches are chained
-// through one event per device: each waits for the previous one (of any engine) to finish.  One engine (the normal case)
-// never touches the event, and a capturing stream does not either (an event from outside a capture cannot be waited on).
+// The persistent kernels need ALL their workgroups resident at once: the decoder kernel has a grid barrier and, from 49 crops on, asks
+// for every CU; the persistent split3 GEMM's consumers wait for slabs their producers publish, one 147 KB workgroup per CU.  Two such
+// launches issued concurrently by two engines on two streams could each grab part of the chip and wait for the rest until the bounded
+// waits run out.  So when a process has more than one engine on a device, those launches are chained through one event per device:
+// each waits for the previous one (of any engine) to finish.  One engine (the normal case) never touches the event, and a capturing
+// stream does not either (an event from outside a capture cannot be waited on).  (Engines of the shipped and of the experiments
+// library in one process each have their own copy of this object: do not run them concurrently on one device — tests do not.)
 struct DecoderTurnstile {
     std::mutex mu;
     std::map<int, int> engines;          // device -> live engines
@@ -1012,13 +1020,14 @@ DecoderTurnstile& turnstile() {
     return t;
 }
 
-int launch_decoder_serialised(thmr_engine* e, const DecParams& d, hipStream_t st) {
+template <class Launch>
+int launch_serialised(thmr_engine* e, hipStream_t st, Launch&& launch) {
     DecoderTurnstile& t = turnstile();
     std::unique_lock<std::mutex> lk(t.mu);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (t.engines[e->cfg.device] <= 1 || hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
         lk.unlock();
-        return launch_decoder_fused(d, st);
+        return launch();
     }
     auto it = t.last.find(e->cfg.device);
     if (it == t.last.end()) {
@@ -1026,9 +1035,17 @@ int launch_decoder_serialised(thmr_engine* e, const DecParams& d, hipStream_t st
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return -2;
         it = t.last.emplace(e->cfg.device, ev).first;
     } else if (hipStreamWaitEvent(st, it->second, 0) != hipSuccess) return -2;
-    const int r = launch_decoder_fused(d, st);
+    const int r = launch();
     if (hipEventRecord(it->second, st) != hipSuccess) return -2;
     return r;
+}
+
+int launch_decoder_serialised(thmr_engine* e, const DecParams& d, hipStream_t st) {
+    return launch_serialised(e, st, [&] { return launch_decoder_fused(d, st); });
+}
+
+int launch_split3_persist_serialised(thmr_engine* e, const GemmArgs& a, int epi, int mode, hipStream_t st) {
+    return launch_serialised(e, st, [&] { return launch_gemm_split3_persist(a, epi, mode, e->s3_ws, st); });
 }
 
 // The persistent decoder kernel's bounded grid barrier timed out in an earlier call (its workgroups were not resident together:
@@ -1052,9 +1069,53 @@ int recover_decoder_timeout(thmr_engine* e, hipStream_t st = nullptr) {
                                  "the launch-chain head: re-submit the batch");
 }
 
+// zero the hand-over workspace of the persistent split3 GEMM (slabs, epochs, control words) and bind the host-mapped error word again
+int reset_s3_workspace(thmr_engine* e, hipStream_t st) {
+    HIP_OK(hipMemsetAsync(e->s3_ws, 0, gemm_split3_persist_ws_bytes(), st));
+    if (e->s3_host_err && gemm_split3_persist_bind_host_err(e->s3_ws, &e->s3_host_err, st) != 0)
+        return fail(e, THMR_ERR_HIP, "binding the host-mapped error word of the split3 hand-over workspace failed");
+    return 0;
+}
+
+// A consumer of the persistent split3 GEMM gave up waiting for its producer's slab in an earlier call (the launch's workgroups were not
+// resident together for ~0.5 s: another kernel held the device).  That call's outputs are invalid.  The epochs in the flags make later
+// launches safe by themselves (a late producer cannot be mistaken for a later launch's), but the cause is likely to persist: report ONCE,
+// reset the workspace and fall back to the one-workgroup-per-tile kernel (same results), so the caller can simply re-submit.
+int recover_split3_timeout(thmr_engine* e, hipStream_t st = nullptr) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(e, THMR_ERR_HIP, "persistent split3 GEMM: a hand-over wait timed out in a previous forward, and this call is inside a "
+                                     "stream capture: end the capture, call thmr_engine_status() (it resets the engine), then re-capture");
+    (void)hipDeviceSynchronize();
+    if (e->s3_host_err) *e->s3_host_err = 0;
+    e->s3_persist = 0;
+    if (e->s3_ws) {
+        if (int r = reset_s3_workspace(e, nullptr)) return r;
+        (void)hipDeviceSynchronize();
+    }
+    return fail(e, THMR_ERR_HIP, "persistent split3 GEMM: a hand-over wait timed out in a previous forward; that call's outputs are invalid. "
+                                 "The engine has reset the workspace and switched to the per-tile kernel: re-submit the batch");
+}
+
+// the persistent split3 GEMM's decomposition is 8 XCDs x 32 CUs: only offered on a 256-CU device (cached per device)
+bool device_has_256_cus() {
+    static std::mutex mu;
+    static std::map<int, bool> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(dev);
+    if (it != cache.end()) return it->second;
+    hipDeviceProp_t prop;
+    const bool ok = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount == 256;
+    cache[dev] = ok;
+    return ok;
+}
+
 int check_ready(thmr_engine* e, int B, hipStream_t st = nullptr) {
     if (!e) return fail(nullptr, THMR_ERR_INVALID, "null engine");
     if (e->host_err && *static_cast<volatile unsigned*>(e->host_err) != 0) return recover_decoder_timeout(e, st);
+    if (e->s3_host_err && *static_cast<volatile unsigned*>(e->s3_host_err) != 0) return recover_split3_timeout(e, st);
     if (!e->finalized) return fail(e, THMR_ERR_STATE, "weights not finalized: call thmr_finalize_weights first");
     if (B < 1 || B > e->max_batch) return fail(e, THMR_ERR_INVALID, "batch " + std::to_string(B) + " outside [1, max_batch=" + std::to_string(e->max_batch) + "]");
     return 0;
@@ -1138,7 +1199,8 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     if (hipMemset(e->sarena + e->so.lcnt, 0, (size_t)e->max_batch * sizeof(float)) != hipSuccess) return bail(THMR_ERR_HIP, "hipMemset(lbs counters) failed");
     // sticky error word of the persistent decoder kernel, host-mapped so that the next call sees a timeout without a D2H copy
     if (hipHostMalloc(reinterpret_cast<void**>(&e->host_err), 64, hipHostMallocMapped) != hipSuccess) return bail(THMR_ERR_NOMEM, "hipHostMalloc(error word) failed");
-    *e->host_err = 0;
+    e->host_err[0] = e->host_err[1] = 0;
+    e->s3_host_err = e->host_err + 1;
     { const char* lg = thmr_knob("THMR_LEGACY_HEAD"); e->legacy_head = lg && lg[0] == '1'; }
     { const char* mc = thmr_knob("THMR_MIXER_CLUSTER"); e->mixer_cluster = !(mc && mc[0] == '0'); }
     { const char* tg = thmr_knob("THMR_TINY_GEMM"); e->tiny_gemm = !(tg && tg[0] == '0'); }
@@ -1214,6 +1276,7 @@ int thmr_load_smpl(thmr_engine* e, const thmr_smpl_desc* s, void* stream) {
 
 // split3 copies of the four ViT GEMM weights of every block (6 bytes per weight) + the activation operand buffers, engine-owned
 static int build_split_weights(thmr_engine* e, hipStream_t st) {
+    if (e->max_batch < kSplit3LowMinB) return 0;      // no call of this engine can reach the mode (one and two crops run the exact-fp32 kernels)
     const size_t per_block = (size_t)DIM * (3 * DIM) + (size_t)DIM * DIM + 2 * (size_t)DIM * MLP;      // weights of one block
     const size_t kv_rows = (size_t)e->dec_depth * 2 * INNER;                                           // + the decoder's to_kv of all layers
     if (!e->split_w && hipMalloc(reinterpret_cast<void**>(&e->split_w), (per_block * e->vit_depth + kv_rows * DIM) * 6) != hipSuccess)
@@ -1227,7 +1290,7 @@ static int build_split_weights(thmr_engine* e, hipStream_t st) {
         if (hipGetDeviceProperties(&prop, e->cfg.device) == hipSuccess && prop.multiProcessorCount == 256) {
             // the persistent kernel's decomposition is 8 XCDs x 32 CUs; elsewhere the per-tile kernel stays in charge (same results)
             if (hipMalloc(&e->s3_ws, gemm_split3_persist_ws_bytes()) != hipSuccess) return fail(e, THMR_ERR_NOMEM, "hipMalloc(split3 hand-over workspace) failed");
-            HIP_OK(hipMemsetAsync(e->s3_ws, 0, gemm_split3_persist_ws_bytes(), st));
+            if (int r = reset_s3_workspace(e, st)) return r;
         }
     }
     e->vitw_s.resize(e->vit_depth);
@@ -1474,25 +1537,19 @@ int thmr_engine_status(thmr_engine* e, void* stream) {
     HIP_OK(hipStreamSynchronize(st));
     if (words[3] != 0 || (e->host_err && *static_cast<volatile unsigned*>(e->host_err) != 0)) return recover_decoder_timeout(e);
     if (e->s3_ws) {
-        // persistent split3 GEMM: a consumer's bounded wait for a hand-over slab ran out (its workgroups were not resident together with
-        // their producers for ~0.5 s: another kernel held the device).  That forward's outputs are invalid; reset the workspace and fall
-        // back to the per-tile kernel (same results) so the caller can simply re-submit.  Reported once.
+        // persistent split3 GEMM: a consumer's bounded wait for a hand-over slab ran out (see recover_split3_timeout; the next forward-type
+        // call reports it too, through the host-mapped copy of this word).  Reported once.
         unsigned err = 0;
         if (gemm_split3_persist_error(e->s3_ws, st, &err) != 0) return fail(e, THMR_ERR_HIP, "reading the split3 hand-over error word failed");
+        if (e->s3_host_err && *static_cast<volatile unsigned*>(e->s3_host_err) != 0) err = 1;
 #ifdef THMR_EXPERIMENTS
-        // tests only: report a hand-over timeout that did not happen, once per engine, to exercise the recovery below
+        // tests only: report a hand-over timeout that did not happen, once per engine, to exercise the recovery
         if (e->s3_persist && e->vit_gemm_mode == 1 && !e->s3_forced_once) {
             const char* f = thmr_knob("THMR_SPLIT3_FORCE_TIMEOUT");
             if (f && f[0] == '1') { err = 1; e->s3_forced_once = true; }
         }
 #endif
-        if (err != 0) {
-            HIP_OK(hipMemsetAsync(e->s3_ws, 0, gemm_split3_persist_ws_bytes(), st));
-            HIP_OK(hipStreamSynchronize(st));
-            e->s3_persist = 0;
-            return fail(e, THMR_ERR_HIP, "persistent split3 GEMM: a hand-over wait timed out in a previous forward; that call's outputs are invalid. "
-                                         "The engine has reset the workspace and switched to the per-tile kernel: re-submit the batch");
-        }
+        if (err != 0) return recover_split3_timeout(e);
     }
     return 0;
 }
@@ -1676,6 +1733,7 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
         // 256 persistent workgroups over a tile stream: M % 128 == 0, N % 256 == 0, at least 256 tiles.  300 = the product kernel (gemm_split16.hip),
         // 310 = the round-4 first version on 32x32x16 MFMAs (gemm_split_persist.hip; experiments build)
         if (!gemm_split3_persist_ok(a)) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM: M % 128 == 0, N % 256 == 0, M / 128 * N / 256 >= 256, K >= 64");
+        if (!device_has_256_cus()) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM: its 8 x 32 workgroup decomposition needs a 256-CU device (use variant 0 / 2)");
         void* ws = gemm_split3_persist_op_ws(st);
         if (!ws) return fail(e, THMR_ERR_NOMEM, "persistent split3 GEMM: workspace allocation failed");
         LAUNCH_OK(launch_gemm_split3_persist(a, epi, variant == 300 ? 0 : 10, ws, st));
@@ -1766,6 +1824,7 @@ int thmr_op_gemm_split3_out_split3(const void* A, int64_t lda, const void* W, in
 #endif
         if (variant != 302 && epi != EPI_NONE && epi != EPI_BIAS_GELU) return fail(e, THMR_ERR_INVALID, "32x32x16 persistent split3 GEMM with split3 output: epilogue must be 0 or 2");
         if (!gemm_split3_persist_ok(a)) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM: M % 128 == 0, N % 256 == 0, M / 128 * N / 256 >= 256, K >= 64");
+        if (!device_has_256_cus()) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM: its 8 x 32 workgroup decomposition needs a 256-CU device (use variant 0 / 2)");
         void* ws = gemm_split3_persist_op_ws(static_cast<hipStream_t>(stream));
         if (!ws) return fail(e, THMR_ERR_NOMEM, "persistent split3 GEMM: workspace allocation failed");
         LAUNCH_OK(launch_gemm_split3_persist(a, epi, variant == 302 ? 2 : variant - 300, ws, static_cast<hipStream_t>(stream)));

@@ -39,10 +39,18 @@ constexpr int QBM = 128;
 constexpr int Q_SLAB = 128 * 256;                          // floats of one raw accumulator tile (128 KB)
 constexpr int Q_NWG = 8 * QG;
 
+// Hand-over protocol (round 5): a flag holds the EPOCH of the launch that published its slab.  Every workgroup reads the workspace's
+// epoch word at its start (ep = epoch + 1, never 0), producers store ep, consumers wait for == ep; the last workgroup to finish — an arrival
+// counter, one device-scope atomic per workgroup — advances the epoch word and zeroes the counter.  Nothing is "re-armed": a producer that
+// publishes AFTER its consumer's bounded wait ran out leaves a flag of a finished epoch, which no later launch can mistake for its own (round
+// 4's 0 / 1 flags stayed 1 in that case and fed every later launch the previous launch's accumulators).  It is device state, so a launch
+// captured in a hipGraph replays correctly.  A timeout is written to the workspace's error word AND to the host-mapped word whose address the
+// workspace carries (words W_HOST, W_HOST + 1: gemm_split3_persist_bind_host_err; null = none), which the engine tests on entry of the next call (engine.hip check_ready).
 struct Ws16 {
     float* part;        // [8 * QG] slabs: slab (x, i) = the accumulators of the first part of the tile shared by lane i of XCDs x and x + 1
-    unsigned* flag;     // [8 * QG] 0 / 1, set by the producer, cleared by the consumer; [8 * QG] = error word
+    unsigned* flag;     // [8 * QG] epochs; then the control words below
 };
+constexpr int W_ERR = Q_NWG, W_EPOCH = Q_NWG + 1, W_DONE = Q_NWG + 2, W_HOST = Q_NWG + 4;      // W_HOST: 8-byte aligned (the flag array is)
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
@@ -285,10 +293,15 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles
     const uint32_t slab_lane = (uint32_t)(wave * 16 * 1024 + lane * 16);       // a wave's 16 accumulators of 1 KiB each
     int pub_pending = 0;         // the slab's stores are issued; the flag goes out after the next K tile's barrier (every wave drained)
     int par = 0;                 // buffer of the next K tile
+    unsigned ep = 1u;            // this launch's epoch (see Ws16)
+    if constexpr (PERSIST) {
+        ep = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ws.flag + W_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u;
+        if (ep == 0u) ep = 1u;
+    }
     auto after_tile = [&]() {
         if constexpr (PERSIST) {
             if (pub_pending) {
-                if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pub_pending = 0;
             }
         }
@@ -310,14 +323,15 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles
             if (tid == 0) {
                 unsigned spins = 0;
                 unsigned* f = ws.flag + (xcd - 1) * QG + ln;
-                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 22)) {                        // ~0.5 s: report, never hang
-                        __hip_atomic_store(ws.flag + Q_NWG, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (++spins > (1u << 22)) {                        // ~0.5 s: report (device word + host-mapped word), never hang
+                        __hip_atomic_store(ws.flag + W_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        unsigned* const he = *reinterpret_cast<unsigned* const*>(ws.flag + W_HOST);
+                        if (he) __hip_atomic_store(he, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
                 }
-                __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch (stream order)
             }
             asm volatile("s_barrier" ::: "memory");
             const uint32_t base = (uint32_t)((xcd - 1) * QG + ln) * (uint32_t)(Q_SLAB * 4) + slab_lane;
@@ -447,6 +461,13 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles
     if (pub_pending) {                                                 // (a first part is never a range's last segment; kept for safety)
         __syncthreads();
         after_tile();
+    }
+    if constexpr (PERSIST) {
+        // arrival: the last of the launch's workgroups closes the epoch (every workgroup read the epoch word before it arrived here)
+        if (tid == 0 && __hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nwg - 1)) {
+            __hip_atomic_store(ws.flag + W_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ws.flag + W_EPOCH, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

@@ -402,8 +402,9 @@ bool gemm_split3_persist_ok(const GemmArgs& a) {
     return true;
 }
 
-// ws: gemm_split3_persist_ws_bytes() of device memory, ZEROED once when it is allocated (the kernel leaves its flags zero); one launch at
-// a time per workspace.  mode: 0 fp32 output; 1 / 2 split3 output (a.c_split) through LDS / through swapped operand roles.
+// ws: gemm_split3_persist_ws_bytes() of device memory, ZEROED once when it is allocated; one launch at a time per workspace.  Layout: 256 slabs,
+// then 256 flag words (gemm_split16.hip: the epoch of the launch that published the slab), then the control words: + 0 error, + 1 epoch,
+// + 2 arrival counter, + 4 / + 5 the address of a host-mapped error word (gemm_split3_persist_bind_host_err; zero = none).  mode: 0 fp32 output; 1 / 2 split3 output (a.c_split) through LDS / through swapped operand roles.
 // round 4: modes 0 / 2 run gemm_split16.hip's kernel (16x16x32 MFMAs; one epilogue for both outputs); the 32x32x16 kernels of this file are
 // the experiments build's modes 10 (fp32 output) / 11 (split3 output through LDS) / 12 (split3 output, swapped roles)
 int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws_mem, hipStream_t s) {
@@ -417,6 +418,9 @@ int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws_me
 #else
     mode -= 10;
     if ((mode == 0) != (a.c_split == nullptr) || mode < 0 || mode > 2) return -1;
+    // the 32x32x16 kernels of this file keep round 4's 0 / 1 flags (set by the producer, cleared by the consumer); the product kernel leaves
+    // epochs in them: zero the flag words (not the control words) first
+    if (hipMemsetAsync(reinterpret_cast<char*>(ws_mem) + (size_t)P_NWG * P_SLAB * 4, 0, P_NWG * sizeof(unsigned), s) != hipSuccess) return -2;
     if (a.c_split != nullptr && epi == EPI_BIAS_RESID) return -1;
     PersistWs ws;
     ws.part = reinterpret_cast<float*>(ws_mem);
@@ -449,6 +453,14 @@ int gemm_split3_persist_error(void* ws_mem, hipStream_t s, unsigned* err_out) {
     if (hipMemcpyAsync(err_out, flag + P_NWG, sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess) return -2;
     if (hipStreamSynchronize(s) != hipSuccess) return -2;
     return 0;
+}
+
+// the host-mapped word a timed-out consumer also writes: *host_err_slot = its device-visible address (the slot must outlive the copy: the
+// engine keeps it in its struct).  Enqueued on `s` behind the memset that zeroed the workspace.
+int gemm_split3_persist_bind_host_err(void* ws_mem, unsigned* const* host_err_slot, hipStream_t s) {
+    unsigned* flag = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws_mem) + (size_t)P_NWG * P_SLAB * 4);
+    static_assert(sizeof(unsigned*) == 8, "the workspace keeps the address in two words");
+    return hipMemcpyAsync(flag + P_NWG + 4, host_err_slot, sizeof(unsigned*), hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -2;
 }
 
 // grow-never workspace per (device, stream) for the stateless operators (thmr_op_gemm_split3 with a persistent variant)

@@ -6,6 +6,12 @@ import torch
 
 from . import _cabi
 
+# Variant ids of thmr_op_gemm beyond the ones the engine uses (include/tokenhmr_hip.h lists those): A/B material kept for the per-kernel tests
+# and scripts/ — 0 / 1 = register-staged 128x128 / 128x160 tiles (lost to the LDS-DMA tiles 7 / 8 in round 1), 12 / 13 = 64x128 / 128x64 tiles
+# (faster stand-alone, slower in the pipeline: round 3), 110 + j = the ring kernel 8-deep (ring depth A/B), 31-53 = timing-only ablations
+# of builds with -DTHMR_GEMM_ABLATION.  thmr_op_gemm_split3: 1 = 128x256 on 4 waves, 4 = 256x256, 100-102 = ring kernel on split3 operands,
+# 20 / 22 / 310-312 = the round-4 first versions on v_mfma_f32_32x32x16_bf16, 3 / 31-37 = schedule experiments; thmr_op_gemm_split3_out_split3:
+# 1, 4, 100, 301 (persistent kernel, LDS epilogue), 311 / 312 — all of these exist in the experiments build only (SPLIT3_EXP_ONLY below).
 EPI = {"none": 0, "bias": 1, "bias_gelu": 2, "bias_relu": 3, "bias_resid": 4, "bias_qscale": 5, "bias_pos": 6}
 VARIANT = {"auto": -1, "128x128reg": 0, "128x160reg": 1, "skinny": 2, "128x128": 7, "128x160": 8, "64x64": 9, "128x96": 10, "tiny": 11, "64x128": 12, "128x64": 13, "ring16": 120}
 # small-M ring kernel: "ring4" / "ring8" = LDS ring depth, optional "/k<S>" = split-K factor (1, 2, 4, 8, 16)
