@@ -41,6 +41,24 @@ def test_load_tokenhmr_from_reference_style_files(built_lib, cuda_dev, tmp_path)
     pose = torch.randn(2, 21, 6, generator=torch.Generator().manual_seed(2)).to(cuda_dev)
     assert torch.equal(model.engine.encode_tokens(pose), ref.engine.encode_tokens(pose))
 
+    # the drop-in's DEFAULT is the mode the benchmark times: load_tokenhmr() without a mode argument (and without $THMR_VIT_GEMM) delivers an
+    # engine in "split3", whose 4-crop call runs the bf16-pipe kernels — equal to the in-memory model's, different from the exact-fp32 opt-out's
+    import os
+    assert "THMR_VIT_GEMM" not in os.environ
+    model4, _ = load_tokenhmr(ck, yml, max_batch=4, device=cuda_dev)
+    assert model4.engine.vit_gemm() == "split3"
+    ref4 = TokenHMR.from_state(cfg, sd, tok_full, smpl, max_batch=4, device=cuda_dev)
+    img4 = torch.randn(4, 3, 256, 256, generator=torch.Generator().manual_seed(5)).to(cuda_dev)
+    a4, b4 = model4({"img": img4}), ref4({"img": img4})
+    optout, _ = load_tokenhmr(ck, yml, max_batch=4, device=cuda_dev, vit_gemm="f32")
+    assert optout.engine.vit_gemm() == "f32"
+    c4 = optout({"img": img4})
+    for k in ("pred_vertices", "pred_keypoints_3d", "cls_logits_softmax"):
+        assert torch.equal(a4[k], b4[k]), k
+    assert not torch.equal(a4["pred_vertices"], c4["pred_vertices"]) and (a4["pred_vertices"] - c4["pred_vertices"]).abs().max() < 1e-4
+    assert int((a4["token_idx"] != c4["token_idx"]).sum()) <= 2          # 640 tokens: only a near-tie may flip between the two arithmetics
+    del model4, ref4, optout
+
     # strict-load failures are loud (load_state_dict(strict=True) semantics, misc.py:246-250)
     bad = dict(sd)
     bad.pop("backbone.blocks.0.attn.qkv.bias")

@@ -344,14 +344,13 @@ def test_split3_handover_timeout_is_reported_once_and_the_engine_falls_back(buil
     good.load_state(sd, tok)
     good.load_smpl(smpl)
     good.finalize()
-    good.set_vit_gemm("split3")
+    assert good.vit_gemm() == "split3"                                   # the creation default (ABI 4)
     img = torch.randn(32, 3, 256, 256, generator=torch.Generator().manual_seed(5)).to(cuda_dev)
     ref = {k: v.clone() for k, v in good.forward(img).items()}
     good.status()
     monkeypatch.setenv("THMR_SPLIT3_FORCE_TIMEOUT", "1")
     e = Engine(cfg, max_batch=32, device=cuda_dev, weight_arena=good.weight_arena, experiments=True)
     e.finalize(assume_all_loaded=True)
-    e.set_vit_gemm("split3")
     e.forward(img)
     with pytest.raises(_cabi.EngineError, match="hand-over wait timed out"):
         e.status()
@@ -361,6 +360,26 @@ def test_split3_handover_timeout_is_reported_once_and_the_engine_falls_back(buil
     e.status()
     for k in ("pred_vertices", "pred_cam", "token_idx", "cls_logits_softmax"):
         assert torch.equal(out[k], ref[k]), k
+    # (2) ADVICE r4: the NEXT forward-type call reports it too, without anybody calling status(): a timed-out consumer also writes a
+    # host-mapped word that thmr_forward tests on entry (= 2: the experiments build writes that word itself after one forward)
+    monkeypatch.setenv("THMR_SPLIT3_FORCE_TIMEOUT", "2")
+    f = Engine(cfg, max_batch=32, device=cuda_dev, weight_arena=good.weight_arena, experiments=True)
+    f.finalize(assume_all_loaded=True)
+    f.forward(img)
+    torch.cuda.synchronize()
+    with pytest.raises(_cabi.EngineError, match="hand-over wait timed out"):
+        f.forward(img)
+    out = f.forward(img)                                                # re-submit: works (per-tile kernels), and the error is not sticky
+    torch.cuda.synchronize()
+    f.status()
+    for k in ("pred_vertices", "pred_cam", "token_idx", "cls_logits_softmax"):
+        assert torch.equal(out[k], ref[k]), k
+    # the engine that never timed out still runs its persistent kernels, repeatedly, with the same bits (epochs advance per launch)
+    for _ in range(3):
+        again = good.forward(img)
+    torch.cuda.synchronize()
+    good.status()
+    assert torch.equal(again["pred_vertices"], ref["pred_vertices"])
 
 
 @pytest.mark.parametrize("mode", ["f32", "split3"])

@@ -66,13 +66,20 @@ _libs = {}
 
 
 def load(exp=None):
-    """The shipped library, or (exp=True, or exp=None with THMR_LIB=exp in the environment) the experiments build."""
+    """The shipped library, or (exp=True, or exp=None with THMR_LIB=exp in the environment) the experiments build.
+    exp = a PATH (str): that very file — another BUILD of this library, e.g. the previous round's, loaded beside the current one by
+    scripts/ab_same_box.py so that two builds are timed interleaved in one process on one box (A/B tooling only; ABI 3 builds accepted:
+    no struct or signature changed between 3 and 4, only the creation default of the ViT GEMM mode)."""
     if exp is None:
         exp = os.environ.get("THMR_LIB", "") == "exp"
-    exp = bool(exp)
+    if isinstance(exp, str):
+        path = os.path.abspath(exp)
+        exp = path
+    else:
+        exp = bool(exp)
+        path = LIB_PATH_EXP if exp else LIB_PATH
     if exp in _libs:
         return _libs[exp]
-    path = LIB_PATH_EXP if exp else LIB_PATH
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
@@ -150,7 +157,7 @@ def load(exp=None):
         if name not in ("thmr_build_info", "thmr_last_error", "thmr_destroy", "thmr_smpl_destroy", "thmr_cropper_destroy",
                         "thmr_cropper_last_error", "thmr_collective_last_error"):
             fn.restype = C.c_int
-    if lib.thmr_abi_version() != ABI_VERSION:
+    if lib.thmr_abi_version() != ABI_VERSION and not (isinstance(exp, str) and lib.thmr_abi_version() == 3):
         raise RuntimeError("libtokenhmr_hip.so ABI version mismatch")
     _libs[exp] = lib
     return lib

@@ -1594,6 +1594,14 @@ int thmr_forward(thmr_engine* e, const float* img_dev, int32_t B, const thmr_out
     const float* rot = out->rotmat ? out->rotmat : e->S(e->so.rot);
     const float* betas = out->betas ? out->betas : e->S(e->so.betas);
     const float* camt = out->pred_cam_t ? out->pred_cam_t : e->S(e->so.camt);
+#ifdef THMR_EXPERIMENTS
+    // tests only (THMR_SPLIT3_FORCE_TIMEOUT=2): write what a timed-out hand-over consumer writes into the host-mapped error word, once per
+    // engine, so that the NEXT forward-type call goes through check_ready's report-reset-fall-back path
+    if (e->s3_ws && e->s3_persist && e->vit_gemm_mode == 1 && !e->s3_forced_once && e->s3_host_err) {
+        const char* f = thmr_knob("THMR_SPLIT3_FORCE_TIMEOUT");
+        if (f && f[0] == '2') { *e->s3_host_err = 1; e->s3_forced_once = true; }
+    }
+#endif
     return lbs(e, rot, betas, camt, B, out->pred_vertices, out->pred_keypoints_3d, out->pred_keypoints_2d, st);
 }
 

@@ -28,13 +28,14 @@ class Engine:
         # THMR_* A/B knobs and carries the debug hooks — tests and scripts only
         self.lib = _cabi.load(exp=experiments)
         self.cfg = cfg
+        self._abi = self.lib.thmr_abi_version()          # (3 only for a previous round's build loaded by path: scripts/ab_same_box.py)
         self.max_batch = int(max_batch)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _cabi.EngineError("tokenhmr_amd runs on a HIP device only (no CPU fallback)")
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device("cuda", idx)
-        self._ccfg = _cabi.Config(abi_version=_cabi.ABI_VERSION, vit_depth=cfg.vit_depth, dec_depth=cfg.dec_depth,
+        self._ccfg = _cabi.Config(abi_version=self._abi, vit_depth=cfg.vit_depth, dec_depth=cfg.dec_depth,
                                   max_batch=self.max_batch, device=idx)
         wb, sb = C.c_size_t(0), C.c_size_t(0)
         self._check(self.lib.thmr_arena_bytes(C.byref(self._ccfg), C.byref(wb), C.byref(sb)))
@@ -254,9 +255,10 @@ class Engine:
     # ------------------------------------------------------------------ how the ViT GEMMs are multiplied
     VIT_GEMM = {"f32": 0, "split3": 1}
 
-    def set_vit_gemm(self, mode="f32"):
-        """"f32" (default): exact-fp32 MFMA.  "split3": fp32 operands as three bf16 pieces on the bf16 matrix pipe (six products, fp32
-        accumulate; fp32-grade, not bitwise fp32) for calls of at least 3 crops — see thmr_set_vit_gemm in the header."""
+    def set_vit_gemm(self, mode="split3"):
+        """"split3" (what an engine is created in): fp32 operands as three bf16 pieces on the bf16 matrix pipe (six products, fp32
+        accumulate; fp32-grade, not bitwise fp32) for calls of at least 3 crops.  "f32": the opt-out, exact-fp32 MFMA everywhere — see
+        thmr_set_vit_gemm in the header."""
         with torch.cuda.device(self.device):
             self._check(self.lib.thmr_set_vit_gemm(self.h, self.VIT_GEMM[mode], _stream_ptr(self.device)), self.h)
 

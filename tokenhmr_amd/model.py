@@ -200,15 +200,16 @@ def load_tokenhmr(checkpoint_path="", model_cfg="", dataset_dir="", is_train_sta
     """Drop-in for tokenhmr/lib/models/__init__.py:3-26: (model, cfg) from the reference's files.  See read_reference_files
     for what is read and how; `device` is where the engine is built (the reference builds on the CPU and the caller moves the
     module, eval.py:52-54 — an engine cannot be moved, so pass the target here; `.to()` of the same device is a no-op).
-    `vit_gemm`: "f32" (exact-fp32 MFMA, the default) or "split3" (Engine.set_vit_gemm: the ViT GEMMs of calls of 3 crops and more on
-    the bf16 matrix pipe with fp32 operands as three bf16 pieces — fp32-grade, ~1.4x the rate); None reads $THMR_VIT_GEMM, so that
-    an unmodified eval.py can be switched from the shell."""
+    `vit_gemm`: "split3" (the engine's default since round 5 — what bench.py's headline measures: the ViT GEMMs and attention of calls of 3
+    crops and more on the bf16 matrix pipe with fp32 operands as three bf16 pieces, fp32 accumulation; fp32-grade) or "f32" (the opt-out:
+    exact-fp32 MFMA everywhere, ~0.65x the rate); None reads $THMR_VIT_GEMM, so that an unmodified eval.py can be switched from the shell,
+    and leaves the engine's default alone when that is unset."""
     hcfg, state, tok, smpl, cfg = read_reference_files(checkpoint_path, model_cfg, dataset_dir, is_train_state, strict)
-    model = TokenHMR.from_state(hcfg, state, tok, smpl, max_batch=max_batch, device=device, model_cfg=cfg)
-    mode = vit_gemm if vit_gemm is not None else os.environ.get("THMR_VIT_GEMM", "f32")
-    if mode not in ("f32", "split3"):
+    mode = vit_gemm if vit_gemm is not None else os.environ.get("THMR_VIT_GEMM")
+    if mode not in (None, "f32", "split3"):
         raise ValueError(f"vit_gemm / $THMR_VIT_GEMM must be 'f32' or 'split3', got {mode!r}")
-    if mode != "f32":
+    model = TokenHMR.from_state(hcfg, state, tok, smpl, max_batch=max_batch, device=device, model_cfg=cfg)
+    if mode is not None and mode != model.engine.vit_gemm():
         model.engine.set_vit_gemm(mode)
     return model, cfg
 
