@@ -200,8 +200,9 @@ int thmr_op_gemm(const float* A_dev, int64_t lda, const float* W_dev, const floa
  * up to 2^-24 |x|) in the "split3" layout [rows][K/8][3][8] bf16 (row stride 6 * ld bytes); the product keeps the six piece pairs down to
  * 2^-16 of |a b| (what is dropped is below one fp32 rounding of the product), accumulation is fp32 in the MFMA.
  * thmr_op_split3 converts (K % 8 == 0, ld_dst % 8 == 0, ld_dst >= K, ld_src % 4 == 0).  thmr_op_gemm_split3: A / W split3 with row strides
- * lda / ldw in fp32-equivalents (multiples of 8), K % 32 == 0; bias / resid / C fp32; epi 0, 1, 2, 4, 5 as thmr_op_gemm.  variant:
- *   -1 = the engine's rule; 0 = 128x256 tile, 8 waves; 2 = 128x128, 4 waves (bit-identical to each other);
+ * lda / ldw in fp32-equivalents (multiples of 8), K % 32 == 0; bias / resid / C fp32; epi 0, 1, 2, 4, 5, 6 as thmr_op_gemm (6: per-tile variants, N % 4 == 0).  variant:
+ *   -1 = the engine's rule; 0 = 128x256 tile, 8 waves; 2 = 128x128, 4 waves; 5 = the 128x256 grid with its ragged last round as 128x128
+ *         half tiles (only shapes whose tile count leaves at most half a round: fc1 of a 64-crop batch; else an error) — all bit-identical;
  *   202 / 204 = split-K 2 / 4 on the big tiles (the engine's 5 ... 31 crops use 2, 3 and 4 crops 4);
  *   300 = 256 PERSISTENT workgroups over a tile stream (M % 128 == 0, N % 256 == 0, at least 256 tiles, a 256-CU device; a ragged last round
  *         is split along K with the accumulators handed from one workgroup to the next through memory — bit-identical to 0 / 2; the
@@ -214,7 +215,7 @@ int thmr_op_gemm_split3(const void* A_split_dev, int64_t lda, const void* W_spli
                         const float* resid_dev, float* C_dev, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi,
                         float qscale, int32_t qcols, int32_t variant, void* stream);
 /* the same product with the epilogue's result written as a split3 operand (the next GEMM's A; row stride 6 * ldcs bytes, N % 8 == 0,
- * ldcs % 8 == 0) instead of fp32: bit-identical to thmr_op_split3 of thmr_op_gemm_split3's output.  epi 0, 1, 2, 5; variant -1, 0, 2;
+ * ldcs % 8 == 0) instead of fp32: bit-identical to thmr_op_split3 of thmr_op_gemm_split3's output.  epi 0, 1, 2, 5; variant -1, 0, 2, 5;
  * 302 = the persistent kernel (epi 0 / 2); + 1000 = the result in the row-blocked form (Cs holds ceil(M / 32) * 32 rows). */
 int thmr_op_gemm_split3_out_split3(const void* A_split_dev, int64_t lda, const void* W_split_dev, int64_t ldw, const float* bias_dev,
                                    void* C_split_dev, int64_t ldcs, int32_t M, int32_t N, int32_t K, int32_t epi, float qscale,

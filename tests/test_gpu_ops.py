@@ -330,6 +330,68 @@ def test_gemm_split3_persistent(built_lib, cuda_dev, shape):
     assert torch.equal(ops.gemm_split3(sa, sw, variant="persist"), base)
 
 
+# (M, N, K) whose 128 x 256 tile count T divides by 8 and leaves, per XCD (q = T / 8 tiles on 32 CUs), 1 ... 16 tiles after the full rounds:
+# fc1 of a 64-crop batch (q = 240 = 7 x 32 + 16), qkv / proj of 48 crops (q = 135 = 4 x 32 + 7; q = 45 = 32 + 13), a ragged-M case with 3 K tiles
+TAIL_SHAPES = [(12288, 5120, 1280), (9216, 3840, 1280), (9216, 1280, 1280), (12238, 5120, 96)]
+
+
+@pytest.mark.parametrize("shape", TAIL_SHAPES)
+def test_gemm_split3_half_tile_tail(built_lib, cuda_dev, shape):
+    """Round 5: the per-tile split3 GEMM whose ragged last round runs as 128 x 128 half tiles on 4 of the workgroup's 8
+    waves (csrc/gemm_split16.hip gemm_split16_tail_kernel) is BIT-IDENTICAL to the plain 128 x 256 grid — every element's K sum is the
+    same chain, only which workgroup shape computes it changes — for every epilogue, the split3 output (row-major and row-blocked), ragged
+    M, repeatedly; the rule ("auto") picks it for these shapes; a shape that does not qualify is refused when asked for by name."""
+    import torch
+    from tokenhmr_amd import ops, _cabi
+    if torch.cuda.get_device_properties(cuda_dev).multi_processor_count != 256:
+        pytest.skip("the tail split is laid out for 8 XCDs x 32 CUs")
+    M, N, K = shape
+    a, w, b = _rand(M, K, seed=31), _rand(N, K, seed=32, scale=1 / math.sqrt(K)), _rand(N, seed=33)
+    a[:, ::7] *= 30.0
+    da, dw, db = a.to(cuda_dev), w.to(cuda_dev), b.to(cuda_dev)
+    dr = _rand(M, N, seed=34).to(cuda_dev)
+    sa, sw = ops.split3(da), ops.split3(dw)
+    base = ops.gemm_split3(sa, sw, variant="128x256/w8")
+    for rep in range(2):
+        o = ops.gemm_split3(sa, sw, variant="tail")
+        assert torch.equal(o, base), (rep, int((o != base).sum()), (o - base).abs().max().item())
+    assert torch.equal(ops.gemm_split3(sa, sw, variant="auto"), base)
+    for epi, kw in (("bias", {}), ("bias_gelu", {}), ("bias_resid", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
+        rr = dr if epi == "bias_resid" else None
+        want = ops.gemm_split3(sa, sw, db, rr, epi=epi, variant="128x256/w8", **kw)
+        got = ops.gemm_split3(sa, sw, db, rr, epi=epi, variant="tail", **kw)
+        assert torch.equal(got, want), (epi, int((got != want).sum()))
+    for epi in ("none", "bias_gelu"):
+        bb = None if epi == "none" else db
+        for blocked in (False, True):
+            want = ops.gemm_split3(sa, sw, bb, epi=epi, variant="128x256/w8", out_split=True, out_blocked=blocked)
+            got = ops.gemm_split3(sa, sw, bb, epi=epi, variant="tail", out_split=True, out_blocked=blocked)
+            assert torch.equal(got, want), (epi, blocked, int((got != want).sum()))
+    # does not qualify: 96 x 15 = 1440 tiles, q = 180 = 5 x 32 + 20 (qkv of a 64-crop batch): refused by name, plain grid by rule
+    small_a, small_w = ops.split3(_rand(12288, 64, seed=41).to(cuda_dev)), ops.split3(_rand(3840, 64, seed=42).to(cuda_dev))
+    with pytest.raises(_cabi.EngineError):
+        ops.gemm_split3(small_a, small_w, variant="tail")
+    assert torch.equal(ops.gemm_split3(small_a, small_w, variant="auto"), ops.gemm_split3(small_a, small_w, variant="128x256/w8"))
+
+
+@pytest.mark.parametrize("M", [192 * 3, 192 * 64, 700])
+def test_gemm_split3_pos_embed_epilogue(built_lib, cuda_dev, M):
+    """The patch-embed epilogue ((acc + bias) + pos[1 + row % 192]) + pos[0] (vit.py:327) on the split3 GEMM: equal to the exact-fp32 GEMM's
+    to the mode's rounding class, both tiles bit-identical, ragged M."""
+    from tokenhmr_amd import ops
+    N, K = 1280, 768
+    a, w, b, pos = _rand(M, K, seed=51), _rand(N, K, seed=52, scale=1 / math.sqrt(K)), _rand(N, seed=53), _rand(193, N, seed=54)
+    da, dw, db, dp = a.to(cuda_dev), w.to(cuda_dev), b.to(cuda_dev), pos.to(cuda_dev)
+    ref = ops.gemm(da, dw, db, dp, epi="bias_pos")
+    sa, sw = ops.split3(da), ops.split3(dw)
+    o0 = ops.gemm_split3(sa, sw, db, dp, epi="bias_pos", variant="128x256/w8")
+    o2 = ops.gemm_split3(sa, sw, db, dp, epi="bias_pos", variant="128x128/w4")
+    assert torch.equal(o0, o2) and torch.equal(o0, ops.gemm_split3(sa, sw, db, dp, epi="bias_pos", variant="auto"))
+    assert torch.allclose(o0, ref, atol=2e-5, rtol=1e-5), (o0 - ref).abs().max().item()
+    want = (a.double() @ w.double().t() + b.double()[None]) + pos[1:].double()[torch.arange(M) % 192] + pos[0].double()[None]
+    assert (o0.cpu().double() - want).abs().max().item() < 3e-5
+
+
 @pytest.mark.parametrize("shape", [(384, 512, 256), (200, 512, 96), (777, 1280, 1280), (2048, 4096, 320), (12288, 1280, 5120)])
 def test_gemm_split3_row_blocked_operand(built_lib, cuda_dev, shape):
     """The row-blocked split3 operand ([R/32][K/8][3][32][8]: what the engine's fc1 hands fc2) — written by both split3-output epilogues

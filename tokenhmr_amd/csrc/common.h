@@ -384,6 +384,8 @@ void* gemm_split3_persist_op_ws(hipStream_t s);        // zeroed workspace per (
 // one workgroup per tile (wide = 128 x 256 on 8 waves, else 128 x 128 on 4; a.ksplit copies of the grid) or 256 persistent workgroups
 int launch_split16_tiles(const GemmArgs& a, int epi, bool wide, hipStream_t s);
 int launch_split16_persist(const GemmArgs& a, int epi, void* ws, hipStream_t s);
+// the wide grid with its ragged last round as 128 x 128 half tiles; 0 launched, 1 = does not apply to this shape (nothing launched), < 0 error
+int launch_split16_tiles_tail(const GemmArgs& a, int epi, int cus, hipStream_t s);
 // small-M split3 GEMM (64x64 tiles, LDS-DMA ring, optional split-K into part[ksplit][M][N] without epilogue)
 int launch_gemm_split3_ring(const GemmArgs& a, int epi, int ksplit, float* part, hipStream_t s);
 // LayerNorm (D = 1280) whose result is written as a split3 operand [rows][D/8][3][8] instead of fp32 (same arithmetic as launch_layernorm)

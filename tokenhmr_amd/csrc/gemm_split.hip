@@ -29,6 +29,8 @@
 //                the buffer everybody just finished reading
 //     so a copy has a whole step (>= 24 MFMAs of this wave plus its SIMD partner's) to land and no fragment read is exposed.
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "common.h"
 #include "gemm_device.h"
@@ -651,9 +653,25 @@ int launch_gemm_split3_splitk(const GemmArgs& a0, int ksplit, float* part, hipSt
     return launch_split3_tiles(a, EPI_NONE, -1, s);
 }
 
+// compute units of the current device (cached per device)
+static int device_cus() {
+    static std::mutex mu;
+    static std::map<int, int> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(dev);
+    if (it != cache.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cache[dev] = n;
+    return n;
+}
+
 static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     static const int forced = [] { const char* e = thmr_knob("THMR_SPLIT3_TILE"); return e ? atoi(e) : -1; }();     // A/B knob (0 / 2)
     if (variant < 0 && forced >= 0) variant = forced;
+    bool by_rule = false;
     if (variant < 0) {
         // the tiles are bit-identical (same K order per element), so the choice is purely a matter of time:
         // 128 x 256 (8 waves) unless the whole grid of 128 x 128 tiles still fits ONE round of 256 CUs (the N = 1280 GEMMs at 16 crops, and
@@ -663,6 +681,19 @@ static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStrea
         const long ks = a.ksplit > 1 ? a.ksplit : 1;
         const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * ks;
         variant = t128 <= 256 ? 2 : 0;
+        by_rule = true;
+    }
+    if ((by_rule && variant == 0) || variant == 5) {
+        // round 5: the 128 x 256 grid with its ragged last round as 128 x 128 half tiles, where that applies (fc1 of a 64-crop batch: 1920
+        // tiles = 7.5 rounds of 256 CUs; gemm_split16.hip gemm_split16_tail_kernel).  Bit-identical to the plain grid.  THMR_SPLIT3_TAIL=0
+        // (experiments build) switches it off for the A/B; variant 5 asks for it explicitly and fails if the shape does not qualify.
+        static const bool tail_off = [] { const char* e = thmr_knob("THMR_SPLIT3_TAIL"); return e && e[0] == '0'; }();
+        if (variant == 5 || !tail_off) {
+            const int r = launch_split16_tiles_tail(a, epi, device_cus(), s);
+            if (r <= 0) return r;                 // launched, or failed
+            if (variant == 5) return -1;          // does not apply to this shape
+        }
+        if (variant == 5) return -1;
     }
     switch (variant) {
         // round 4: the product kernels multiply on v_mfma_f32_16x16x32_bf16 (gemm_split16.hip); the 32x32x16 kernels of this file are the

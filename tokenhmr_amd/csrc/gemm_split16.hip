@@ -84,6 +84,11 @@ __device__ __forceinline__ f32x4 epi4(const GemmArgs& a, f32x4 v, f32x4 b, int m
     if constexpr (EPI == EPI_BIAS_QSCALE)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (n + r < a.qcols) ? v[r] * a.qscale : v[r];
+    if constexpr (EPI == EPI_BIAS_POS) {      // patch embed (vit.py:327): ((acc + bias) + pos[1 + token]) + pos[0]; resid = pos_embed [193][N], N % 4 == 0
+        const f32x4 p1 = *reinterpret_cast<const f32x4*>(a.resid + (int64_t)(1 + m % 192) * a.N + n);
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(a.resid + n);
+        v = (v + p1) + p0;
+    }
     return v;
 }
 
@@ -97,23 +102,23 @@ __device__ __forceinline__ f32x4 epi4(const GemmArgs& a, f32x4 v, f32x4 b, int m
 // SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE, 8 instead of 4 LDS cycles per read, profiles/r4ah_pmc_lds.json.)
 __device__ __forceinline__ constexpr int rot16(int row) { return ((row >> 2) & 1) * 2; }
 
-// WN = waves along N (4: 128 x 256 tile, 8 waves; 2: 128 x 128, 4 waves).  PERSIST: 256 workgroups over a tile stream (WN = 4; M % 128 == 0,
-// N % 256 == 0) instead of one workgroup per (tile, K slice).  ABLK: A is a row-blocked split3 operand (GemmArgs::a_blk).
-// (__launch_bounds__(512) for the 4-wave instantiation too: told that a workgroup has 256 threads hipcc budgets 512 registers per lane,
-// parks fragments in AGPRs and copies them back inside the K loop — ~40 v_accvgpr moves per 192 MFMAs.  A bound of 512 threads = 256
-// registers gives it the 8-wave instantiation's allocation: none.)
+template <int WN>
+constexpr int split16_lds_bytes() { return 2 * (QBM * ROWB + WN * 64 * ROWB); }      // two stages of (A tile + W tile): 147,456 / 98,304 bytes
+
+// The kernel body (one workgroup of 2 WN waves; `smem` = its split16_lds_bytes<WN>() of LDS).  given_tile / half: -1 / -1 = the tile comes
+// from the block index (the plain kernels below); the tail kernel passes the tile — and, for its 128 x 128 half tiles, which half of the
+// 128 x 256 tile `given_tile` of the WIDE grid (tiles_n = that grid's) this workgroup computes.
 template <int WN, int EPI, bool PERSIST, bool ABLK>
-__global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles_m, int tiles_n, int nwg, Ws16 ws) {
+__device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles_n, int nwg, const Ws16& ws, char* smem, int given_tile, int half) {
     constexpr int NW = 2 * WN, BN = WN * 64;
     constexpr int A_Q = QBM * SLOTS / 64, B_Q = BN * SLOTS / 64;
     static_assert(A_Q % NW == 0 && B_Q % NW == 0, "tile / waves mismatch");
     constexpr int A_P = A_Q / NW, B_P = B_Q / NW, NP = A_P + B_P;      // copies per wave and K tile: 3 + 6 (8 waves), 6 + 6 (4 waves)
     constexpr int A_STAGE = QBM * ROWB, B_STAGE = BN * ROWB;
     constexpr int A_KSTEP = ABLK ? SLOTS * 512 : ROWB;                 // bytes a K tile advances the A source by
-    static_assert(2 * (A_STAGE + B_STAGE) <= 160 * 1024, "LDS");
+    static_assert(2 * (A_STAGE + B_STAGE) <= 160 * 1024 && 2 * (A_STAGE + B_STAGE) == split16_lds_bytes<WN>(), "LDS");
     static_assert(!PERSIST || WN == 4, "the persistent decomposition uses the 128 x 256 tile");
 
-    __shared__ __attribute__((aligned(16))) char smem[2 * (A_STAGE + B_STAGE)];
     char* As = smem;
     char* Bs = smem + 2 * A_STAGE;
 
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles
         nfull = max(j1 - has_pre - jf0 + 1, 0);
         nseg = has_pre + nfull + has_post;
     } else {
-        int logical = logical_block(nwg, 0);
+        int logical = given_tile >= 0 ? given_tile : logical_block(nwg, 0);
         if (a.ksplit > 1) {      // copy ksp of the tile grid reduces K slice ksp into part[ksp] (raw, no epilogue)
             const int tiles = tiles_m * tiles_n, ksp = logical / tiles;
             logical -= ksp * tiles;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles
         int tm, tn;
         tile_coords(tiles_m, tiles_n, PERSIST ? j * QG + ln : j, tm, tn);
         bm0 = __builtin_amdgcn_readfirstlane(tm * QBM);
-        bn0 = __builtin_amdgcn_readfirstlane(tn * BN);
+        bn0 = __builtin_amdgcn_readfirstlane(half >= 0 ? tn * 256 + half * 128 : tn * BN);
     };
 
     // ---- copies: wave instruction q = wave + i NW of an operand fills LDS chunks 64 q ... 64 q + 63 of its stage (rows past the edge clamped)
@@ -471,6 +476,38 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles
     }
 }
 
+// WN = waves along N (4: 128 x 256 tile, 8 waves; 2: 128 x 128, 4 waves).  PERSIST: 256 workgroups over a tile stream (WN = 4; M % 128 == 0,
+// N % 256 == 0) instead of one workgroup per (tile, K slice).  ABLK: A is a row-blocked split3 operand (GemmArgs::a_blk).
+// (__launch_bounds__(512) for the 4-wave instantiation too: told that a workgroup has 256 threads hipcc budgets 512 registers per lane,
+// parks fragments in AGPRs and copies them back inside the K loop — ~40 v_accvgpr moves per 192 MFMAs.  A bound of 512 threads = 256
+// registers gives it the 8-wave instantiation's allocation: none.)
+template <int WN, int EPI, bool PERSIST, bool ABLK>
+__global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles_m, int tiles_n, int nwg, Ws16 ws) {
+    __shared__ __attribute__((aligned(16))) char smem[split16_lds_bytes<WN>()];
+    split16_body<WN, EPI, PERSIST, ABLK>(a, tiles_m, tiles_n, nwg, ws, smem, -1, -1);
+}
+
+// One workgroup per 128 x 256 tile EXCEPT the ragged last round, which runs as 128 x 128 half tiles (round 5).  With T
+// tiles on C CUs (one 147 KB workgroup per CU) the last round holds T mod C tiles and the other CUs idle for a whole tile time: fc1 of a
+// 64-crop batch is 1920 tiles = 7.5 rounds on 256 CUs (6.25 % of the launch idle).  Block b runs on XCD b % 8 and XCD x owns the contiguous
+// logical tiles [x q, (x + 1) q), q = T / 8, dispatched in order `within` = b / 8.  Here the first tail_from = 32 floor(q / 32) of them stay
+// 8-wave workgroups on wide tiles; each of the remaining rem = q mod 32 <= 16 tiles becomes TWO blocks whose waves 0-3 run the 4-wave body on
+// one 128 x 128 half (waves 4-7 exit at once): 2 rem <= 32 blocks per XCD, one per CU, each with half the matrix work — the last round takes
+// about half a tile time instead of a whole one.  Same K order per element as every other instantiation: bit-identical results (tests).
+template <int EPI, bool ABLK>
+__global__ __launch_bounds__(512) void gemm_split16_tail_kernel(GemmArgs a, int tiles_m, int tiles_n, int q, int tail_from) {
+    __shared__ __attribute__((aligned(16))) char smem[split16_lds_bytes<4>()];
+    const Ws16 none{nullptr, nullptr};
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;           // workgroup-uniform
+    if (within < tail_from) {
+        split16_body<4, EPI, false, ABLK>(a, tiles_m, tiles_n, 0, none, smem, xcd * q + within, -1);
+    } else {
+        if (threadIdx.x >= 256) return;                                 // (an ended wave no longer counts at s_barrier)
+        const int h = within - tail_from;
+        split16_body<2, EPI, false, ABLK>(a, tiles_m, tiles_n, 0, none, smem, xcd * q + tail_from + (h >> 1), h & 1);
+    }
+}
+
 template <int WN, int EPI, bool PERSIST, bool ABLK>
 int launch16(const GemmArgs& a, const Ws16& ws, hipStream_t s) {
     constexpr int BN = WN * 64;
@@ -493,8 +530,18 @@ int dispatch16(const GemmArgs& a, int epi, const Ws16& ws, hipStream_t s) {
         case EPI_BIAS_GELU: return launch16<WN, EPI_BIAS_GELU, PERSIST, false>(a, ws, s);
         case EPI_BIAS_RESID: return launch16<WN, EPI_BIAS_RESID, PERSIST, false>(a, ws, s);
         case EPI_BIAS_QSCALE: return launch16<WN, EPI_BIAS_QSCALE, PERSIST, false>(a, ws, s);
+        case EPI_BIAS_POS:
+            if constexpr (!PERSIST) return (a.N % 4) == 0 && a.resid != nullptr && a.c_split == nullptr ? launch16<WN, EPI_BIAS_POS, false, false>(a, ws, s) : -1;
+            return -1;
         default: return -1;
     }
+}
+
+template <int EPI, bool ABLK>
+int launch16_tail(const GemmArgs& a, int tiles_m, int tiles_n, int q, int tail_from, hipStream_t s) {
+    const int nwg = 8 * (tail_from + 2 * (q - tail_from));
+    hipLaunchKernelGGL((gemm_split16_tail_kernel<EPI, ABLK>), dim3(nwg), dim3(512), 0, s, a, tiles_m, tiles_n, q, tail_from);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 }  // namespace
@@ -504,6 +551,32 @@ int launch_split16_tiles(const GemmArgs& a, int epi, bool wide, hipStream_t s) {
     if (a.c_split != nullptr && epi == EPI_BIAS_RESID) return -1;
     const Ws16 none{nullptr, nullptr};
     return wide ? dispatch16<4, false>(a, epi, none, s) : dispatch16<2, false>(a, epi, none, s);
+}
+
+// The 128 x 256 tiling with its ragged last round as 128 x 128 half tiles (gemm_split16_tail_kernel).  `cus` = compute units of the device.
+// Applies when the tile count divides by the 8 XCDs, an XCD's share q leaves 1 ... cus / 16 tiles after its full rounds and N % 256 == 0;
+// returns 1 (nothing launched) when it does not — the caller then launches the plain grid.
+int launch_split16_tiles_tail(const GemmArgs& a, int epi, int cus, hipStream_t s) {
+    if (a.ksplit > 1 || (a.N % 256) != 0 || cus < 16 || (cus % 8) != 0) return 1;
+    if (a.c_split != nullptr && epi == EPI_BIAS_RESID) return -1;
+    const int tiles_m = (a.M + QBM - 1) / QBM, tiles_n = a.N / 256, T = tiles_m * tiles_n, per = cus / 8;
+    if ((T % 8) != 0) return 1;
+    const int q = T / 8, full = q / per, rem = q - full * per;
+    if (full < 1 || rem < 1 || 2 * rem > per) return 1;
+    const int tf = full * per;
+    if (a.a_blk) {
+        if (epi == EPI_BIAS_RESID) return launch16_tail<EPI_BIAS_RESID, true>(a, tiles_m, tiles_n, q, tf, s);
+        if (epi == EPI_NONE) return launch16_tail<EPI_NONE, true>(a, tiles_m, tiles_n, q, tf, s);
+        return -1;
+    }
+    switch (epi) {
+        case EPI_NONE: return launch16_tail<EPI_NONE, false>(a, tiles_m, tiles_n, q, tf, s);
+        case EPI_BIAS: return launch16_tail<EPI_BIAS, false>(a, tiles_m, tiles_n, q, tf, s);
+        case EPI_BIAS_GELU: return launch16_tail<EPI_BIAS_GELU, false>(a, tiles_m, tiles_n, q, tf, s);
+        case EPI_BIAS_RESID: return launch16_tail<EPI_BIAS_RESID, false>(a, tiles_m, tiles_n, q, tf, s);
+        case EPI_BIAS_QSCALE: return launch16_tail<EPI_BIAS_QSCALE, false>(a, tiles_m, tiles_n, q, tf, s);
+        default: return 1;
+    }
 }
 
 // 256 persistent workgroups (gemm_split3_persist_ok shapes); ws = gemm_split3_persist_ws_bytes() of zeroed device memory
