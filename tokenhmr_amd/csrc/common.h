@@ -408,6 +408,7 @@ int launch_splitk_resid_ln(const float* part, int S, int rows, int D, const floa
 int launch_add_ln64(const float* x, const float* y, const float* g, const float* b, float* s_out, float* z_out, int rows,
                     float eps, hipStream_t s);
 int launch_im2col_patch(const float* img, float* A, int B, hipStream_t s);
+int launch_im2col_patch_split3(const float* img, void* A_split, int B, hipStream_t s);      // the same operand as [B*192][768/8][3][8] bf16 pieces
 int launch_transpose(const float* in, float* out, int Bn, int R, int C, hipStream_t s);
 int launch_softmax_argmax2048(const float* logits, float* probs, int32_t* idx, int rows, hipStream_t s);
 int launch_conv3_gather(const float* in, float* out, const int32_t* src, int Bn, int Tin, int Tout, int C, int dil,

@@ -138,6 +138,7 @@ struct thmr_engine {
     struct SplitW { const char *qkv, *proj, *fc1, *fc2; };
     std::vector<SplitW> vitw_s;
     const char* kv_s = nullptr;       // split3 copy of the decoder's stacked to_kv weights (dec_depth * 1024 rows x 1280)
+    const char* pe_s = nullptr;       // split3 copy of the patch-embed Conv2d weight as a (1280, 768) matrix
     unsigned* host_err = nullptr;     // host-mapped sticky error words (hipHostMalloc, 64 bytes): [0] the persistent decoder kernel's grid barrier, [1] the persistent split3 GEMM's hand-over
     unsigned* s3_host_err = nullptr;  // = host_err + 1; its ADDRESS is the stable source of the copy that binds it into the hand-over workspace
     std::string err;
@@ -456,12 +457,22 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
     float* x = e->S(e->so.x);
     float* h = e->S(e->so.h);
     float* big = e->S(e->so.big);
+    const bool s3_on = e->vit_gemm_mode == 1 && B >= (e->split3_min_b > 0 ? e->split3_min_b : kSplit3LowMinB) && e->split_w;
     {   // patch embed: crop + pad + im2col, then GEMM (+bias, +pos_embed)   vit.py:341,170-176,327
         ProfScope ps(e, st, THMR_PROF_PATCH, 2.0 * M * 768.0 * DIM,
                      4.0 * (B * 3.0 * 256 * 192 + (double)M * DIM + 768.0 * DIM));
-        LAUNCH_OK(launch_im2col_patch(img, big, B, st));
-        GemmArgs a = mk(big, 768, e->hot.pe_w, 768, e->hot.pe_b, e->hot.pos, 0, x, DIM, M, DIM, 768);
-        LAUNCH_OK(launch_gemm(a, EPI_BIAS_POS, -1, st));
+        if (s3_on && e->pe_s) {
+            // default mode: the im2col operand written as three bf16 pieces (into the idle fc1 -> fc2 operand buffer) and the Conv2d as a
+            // split3 product on the bf16 matrix pipe with the same bias + pos_embed epilogue (0.23 -> ~0.13 ms at 64 crops)
+            char* ims = e->split_act + (size_t)M * DIM * 6;
+            LAUNCH_OK(launch_im2col_patch_split3(img, ims, B, st));
+            GemmArgs a = mk(reinterpret_cast<const float*>(ims), 768, reinterpret_cast<const float*>(e->pe_s), 768, e->hot.pe_b, e->hot.pos, 0, x, DIM, M, DIM, 768);
+            LAUNCH_OK(launch_gemm_split3(a, EPI_BIAS_POS, -1, st));
+        } else {
+            LAUNCH_OK(launch_im2col_patch(img, big, B, st));
+            GemmArgs a = mk(big, 768, e->hot.pe_w, 768, e->hot.pe_b, e->hot.pos, 0, x, DIM, M, DIM, 768);
+            LAUNCH_OK(launch_gemm(a, EPI_BIAS_POS, -1, st));
+        }
     }
     const float qscale = 1.0f / sqrtf(80.0f);   // head_dim ** -0.5  (vit.py:101)
     // Few crops (M <= kSmallM): the N = 1280 GEMMs run split-K on the 64x64 ring kernel and their partial sums are reduced
@@ -512,8 +523,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
     };
     const float* lastn_w = e->hot.lastn_w;
     const float* lastn_b = e->hot.lastn_b;
-    const int s3_min = e->split3_min_b > 0 ? e->split3_min_b : kSplit3LowMinB;
-    if (e->vit_gemm_mode == 1 && B >= s3_min && e->split_w) {
+    if (s3_on) {
         // 3 ... 4 / 5 ... 15 crops: proj / fc2 split K four / two ways into `part`, reduced (in a fixed order) by the residual + LayerNorm kernel,
         // as in the exact-fp32 path's regimes; 16 ... 31: only fc2 (two ways); 32 and more: unsplit.  One factor per range: a crop's result is
         // batch-independent within it.
@@ -1279,7 +1289,7 @@ static int build_split_weights(thmr_engine* e, hipStream_t st) {
     if (e->max_batch < kSplit3LowMinB) return 0;      // no call of this engine can reach the mode (one and two crops run the exact-fp32 kernels)
     const size_t per_block = (size_t)DIM * (3 * DIM) + (size_t)DIM * DIM + 2 * (size_t)DIM * MLP;      // weights of one block
     const size_t kv_rows = (size_t)e->dec_depth * 2 * INNER;                                           // + the decoder's to_kv of all layers
-    if (!e->split_w && hipMalloc(reinterpret_cast<void**>(&e->split_w), (per_block * e->vit_depth + kv_rows * DIM) * 6) != hipSuccess)
+    if (!e->split_w && hipMalloc(reinterpret_cast<void**>(&e->split_w), (per_block * e->vit_depth + kv_rows * DIM + (size_t)DIM * 768) * 6) != hipSuccess)
         return fail(e, THMR_ERR_NOMEM, "hipMalloc(split3 ViT weights) failed");
     const size_t M = (size_t)e->max_batch * TOK;
     // activations: [M][1280] + [M][5120] split3 operands, then the two fp32 partial-sum planes of fc2's split-K ([2][M][1280])
@@ -1310,6 +1320,9 @@ static int build_split_weights(thmr_engine* e, hipStream_t st) {
     }
     e->kv_s = p;
     LAUNCH_OK(launch_split3(e->warena + e->o_kv_all, DIM, p, DIM, (int64_t)kv_rows, DIM, st));
+    p += kv_rows * DIM * 6;
+    e->pe_s = p;
+    LAUNCH_OK(launch_split3(e->hot.pe_w, 768, p, 768, DIM, 768, st));
     return 0;
 }
 

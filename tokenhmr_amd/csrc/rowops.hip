@@ -121,6 +121,35 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restri
     *reinterpret_cast<f32x4*>(A + rowi * 768 + k) = v;
 }
 
+// The same operand written directly as the split3 A of the patch-embed GEMM of the default mode ([M][768 / 8][3][8] bf16: three bf16 pieces per
+// pixel, exact to 2^-24): one thread per k-group of 8 consecutive kx of one (row, c, ky) = four aligned 8-byte reads (the window starts at
+// image column 30 + 16 px + kx0: even) and 48 contiguous bytes written.  No fp32 copy of the im2col matrix exists in that mode.
+__global__ __launch_bounds__(256) void im2col_patch_split3_kernel(const float* __restrict__ img, char* __restrict__ A, int B) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)B * 192 * 96;
+    if (idx >= total) return;
+    const int g8 = (int)(idx % 96);
+    const int64_t rowi = idx / 96;
+    const int tok = (int)(rowi % 192), b = (int)(rowi / 192);
+    const int py = tok / 12, px = tok % 12;
+    const int k = g8 * 8, c = k >> 8, ky = (k >> 4) & 15, kx0 = k & 15;
+    const int iy = py * 16 + ky - 2;
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+    if (iy >= 0 && iy < 256) {
+        const float* src = img + (((int64_t)b * 3 + c) * 256 + iy) * 256 + 32;
+        const int ix0 = px * 16 + kx0 - 2;                  // even; a pair (ix, ix + 1) is inside [0, 192) or outside as a whole
+        f32x2 p[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ix = ix0 + 2 * e;
+            p[e] = (ix >= 0 && ix < 192) ? *reinterpret_cast<const f32x2*>(src + ix) : f32x2{0.f, 0.f};
+        }
+        lo = f32x4{p[0].x, p[0].y, p[1].x, p[1].y};
+        hi = f32x4{p[2].x, p[2].y, p[3].x, p[3].y};
+    }
+    store_split3_oct(A + rowi * (768 * 6), k, lo, hi);
+}
+
 // ------------------------------------------------------------------------------------------------ batched transpose
 // (Bn, R, C) -> (Bn, C, R); MixerLayer y.transpose(2,1) (heads/modules.py:56-58)
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
@@ -415,6 +444,12 @@ int launch_add_ln64(const float* x, const float* y, const float* g, const float*
 int launch_im2col_patch(const float* img, float* A, int B, hipStream_t s) {
     const int64_t total = (int64_t)B * 192 * 192;
     hipLaunchKernelGGL(im2col_patch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, A, B);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_im2col_patch_split3(const float* img, void* A_split, int B, hipStream_t s) {
+    const int64_t total = (int64_t)B * 192 * 96;
+    hipLaunchKernelGGL(im2col_patch_split3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, reinterpret_cast<char*>(A_split), B);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
