@@ -614,11 +614,26 @@ def main():
                 if gw["on"]:
                     gw["host_s"] += time.perf_counter() - t_w
 
+    def in_turns(fn):
+        """--single-device only: the ranks share ONE GPU, and the engine's persistent kernels (decoder grid barrier, split3 hand-over) need all
+        their workgroups resident together — two processes launching them at once can starve each other until the bounded waits time out
+        (the in-process turnstile cannot see another process).  So each rank runs its forward alone, in rank order, between barriers.  On
+        real multi-GPU runs every rank has its own device and this is a plain call."""
+        if not a.single_device:
+            return fn()
+        res = None
+        for r in range(world):
+            if r == rank:
+                res = fn()
+                sync()
+            dist.barrier()
+        return res
+
     def step():
         if a.workload == "vit":
-            eng.vit_forward(img, out=feats)
+            in_turns(lambda: eng.vit_forward(img, out=feats))
             return
-        o = eng.forward(img, outputs=outs)
+        o = in_turns(lambda: eng.forward(img, outputs=outs))
         last["out"] = o
         if gather:
             # packed per-crop records of this step go out over xGMI while the next step's ViT runs; the previous step's

@@ -221,14 +221,17 @@ def test_head_regimes_agree_and_persistent_decoders_coexist(built_lib, cuda_dev)
             assert torch.equal(a[k], small[k]) and torch.equal(b[k], small[k]), k
 
 
-def test_fused_head_equals_chain_head_across_batch_sizes(built_lib, cuda_dev, monkeypatch):
+@pytest.mark.parametrize("mode", ["split3", "f32"])
+def test_fused_head_equals_chain_head_across_batch_sizes(built_lib, cuda_dev, monkeypatch, mode):
     """The persistent decoder kernel picks its grid from the batch (64 workgroups up to 16 crops, 128 / 192 / 256 above) and
     deals (column tile x 16-row sub-tile) items over it; the mixer stack runs inside that kernel, ten workgroups per crop, up to 25
     crops and as its own kernel, one workgroup per crop, above (bit-identical by construction: both call mixer_device.h).  For
     batch sizes on both sides of every boundary — 1, 2, 6, 7, 15, 16, 17, 25, 26, 33, 48, 49, 64, 100, 128 (ragged last sub-tiles
     included) — the fused head must
     agree with the chain-of-GEMMs head (THMR_LEGACY_HEAD=1: same maths as separate tiled launches, the round-1 path) to fp32
-    summation-order differences, be deterministic, and give a crop the same bits whatever batch it rides in."""
+    summation-order differences, be deterministic, and give a crop the same bits whatever batch it rides in.
+    Both modes of the engine: in the default "split3" mode the decoder's stacked to_kv GEMM runs on the bf16 pipe from 3 crops on, so one and two
+    crops (exact-fp32 to_kv) are a regime of their own there; "f32" is the round-2 regime structure."""
     from tokenhmr_amd.config import HMRConfig
     from tokenhmr_amd import weights as W
     from tokenhmr_amd.smpl_assets import make_synthetic_smpl
@@ -248,10 +251,18 @@ def test_fused_head_equals_chain_head_across_batch_sizes(built_lib, cuda_dev, mo
     plain = Engine(cfg, max_batch=128, device=cuda_dev, weight_arena=fused.weight_arena, experiments=True)
     plain.finalize(assume_all_loaded=True)
     monkeypatch.delenv("THMR_MIXER_CLUSTER")
+    for e in (fused, chain, plain):
+        assert e.vit_gemm() == "split3"                                   # the creation default (ABI 4)
+        e.set_vit_gemm(mode)
     ctx = torch.randn(128, 192, 1280, generator=torch.Generator().manual_seed(12)).to(cuda_dev)
     keys = ("token_out", "cls_logits", "pose6d", "pred_vertices", "pred_cam")
     ref128 = {k: v.clone() for k, v in fused.head_forward(ctx, taps=True).items()}
     ref6 = {k: v.clone() for k, v in fused.head_forward(ctx[:6], taps=True).items()}
+    ref2 = {k: v.clone() for k, v in fused.head_forward(ctx[:2], taps=True).items()}
+    if mode == "split3":      # one and two crops: exact-fp32 to_kv, fp32-rounding-close to the bf16-pipe product of the larger batches
+        assert (ref2["token_out"] - ref6["token_out"][:2]).abs().max() < 1e-4 and not torch.equal(ref2["token_out"], ref6["token_out"][:2])
+    else:
+        assert torch.equal(ref2["token_out"], ref6["token_out"][:2])
     # up to six crops the VQ decoder's GEMMs run on the tiny-M kernel (another association of the K sum): its own regime.  What comes
     # BEFORE the VQ decoder (decoder, mixers, logits) is the same arithmetic in both regimes.
     for k in ("token_out", "cls_logits"):
@@ -262,7 +273,7 @@ def test_fused_head_equals_chain_head_across_batch_sizes(built_lib, cuda_dev, mo
         a = {k: v.clone() for k, v in fused.head_forward(ctx[:B], taps=True).items()}
         b = fused.head_forward(ctx[:B], taps=True)
         c = chain.head_forward(ctx[:B], taps=True)
-        ref = ref6 if B <= 6 else ref128
+        ref = (ref2 if (B <= 2 and mode == "split3") else ref6) if B <= 6 else ref128
         for k in keys:
             assert torch.equal(a[k], b[k]), (B, k)                                   # deterministic
             assert torch.equal(a[k], ref[k][:B]), (B, k)                             # batch-invariant within a regime of the fused head

@@ -218,21 +218,25 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 
     // ---- fragments: lane (l15, g) reads chunk (k-group g, piece pc) of row l15 of a 16-row tile.  Row-major stage image: physical slot
     // (3 g + pc + rot16(row)) % 12, rot16(row) = rot16(l15) for every tile (tile offsets are multiples of 16).
+    // Each operand has ONE per-lane LDS address per piece with the stage base and the wave's tile offset folded in, so that every fragment read
+    // of the K loop is {that register} + {immediate below 64 KB}: A: buf * 24 KB + tile offset <= 33,792; W: buf * 48 KB + ni * 3 KB <=
+    // 58,368.  (With the wave-uniform parts left to the compiler it kept three registers and re-added the part that exceeds the 16-bit
+    // offset field inside the loop — three VALU instructions per trip in the persistent instantiations, round 5.)
+    typedef const __attribute__((address_space(3))) bf16x8* lds_frag_ptr;
     uint32_t fow[3], foa[3];
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) {
-        fow[pc] = (uint32_t)l15 * ROWB + (uint32_t)((3 * g + pc + rot16(l15)) % SLOTS) * 16u;
-        foa[pc] = ABLK ? (uint32_t)((3 * g + pc) * 512 + l15 * 16) : fow[pc];
+        const uint32_t rowmaj = (uint32_t)l15 * ROWB + (uint32_t)((3 * g + pc + rot16(l15)) % SLOTS) * 16u;
+        fow[pc] = lds_addr_b(Bs) + (uint32_t)(wn0 * ROWB) + rowmaj;
+        foa[pc] = lds_addr_b(As) + (uint32_t)(wm0 * ROWB) + (ABLK ? (uint32_t)((3 * g + pc) * 512 + l15 * 16) : rowmaj);      // (row-blocked A: wm0 / 32 blocks of 12 x 512 bytes — the same offset)
     }
-    const char* Afr = As + wm0 * ROWB;                                 // (row-blocked A: wm0 / 32 blocks of 12 x 512 bytes — the same offset)
-    const char* Bfr = Bs + wn0 * ROWB;
     bf16x8 af[4][3], wf[2][4][3];                                      // activation fragments (rolling), weight fragments of this / the next K tile
     auto read_a = [&](int buf, int mi, int pc) {
         const int off = ABLK ? (mi >> 1) * (SLOTS * 512) + (mi & 1) * 256 : mi * 16 * ROWB;
-        af[mi][pc] = *reinterpret_cast<const bf16x8*>(Afr + buf * A_STAGE + off + foa[pc]);
+        af[mi][pc] = *reinterpret_cast<lds_frag_ptr>((uintptr_t)(foa[pc] + (uint32_t)(buf * A_STAGE + off)));
     };
     auto read_w = [&](int buf, int set, int ni, int pc) {
-        wf[set][ni][pc] = *reinterpret_cast<const bf16x8*>(Bfr + buf * B_STAGE + ni * 16 * ROWB + fow[pc]);
+        wf[set][ni][pc] = *reinterpret_cast<lds_frag_ptr>((uintptr_t)(fow[pc] + (uint32_t)(buf * B_STAGE + ni * 16 * ROWB)));
     };
     f32x4 acc[4][4];
 
@@ -296,20 +300,13 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ws.part, 0, Q_NWG * Q_SLAB * 4, 0x00020000);
     const uint32_t slab_lane = (uint32_t)(wave * 16 * 1024 + lane * 16);       // a wave's 16 accumulators of 1 KiB each
-    int pub_pending = 0;         // the slab's stores are issued; the flag goes out after the next K tile's barrier (every wave drained)
     int par = 0;                 // buffer of the next K tile
-    unsigned ep = 1u;            // this launch's epoch (see Ws16)
-    if constexpr (PERSIST) {
-        ep = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ws.flag + W_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u;
-        if (ep == 0u) ep = 1u;
-    }
-    auto after_tile = [&]() {
-        if constexpr (PERSIST) {
-            if (pub_pending) {
-                if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pub_pending = 0;
-            }
-        }
+    // this launch's epoch (see Ws16), read from the workspace at each of its three uses instead of kept in a register across the K loops:
+    // the word only changes when the LAST workgroup of the launch has arrived at the end of the kernel.  (One more scalar register live
+    // across the loops made hipcc spill scalars into a vector register and re-derive three LDS fragment addresses inside the K loop.)
+    auto epoch = [&]() -> unsigned {
+        const unsigned e = __hip_atomic_load(ws.flag + W_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        return e == 0u ? 1u : e;
     };
 
     {
@@ -328,6 +325,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
             if (tid == 0) {
                 unsigned spins = 0;
                 unsigned* f = ws.flag + (xcd - 1) * QG + ln;
+                const unsigned ep = epoch();
                 while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) {
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > (1u << 22)) {                        // ~0.5 s: report (device word + host-mapped word), never hang
@@ -355,18 +353,20 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
         }
 
         int cnt = ke - kb;
-        if (cnt > 0 && par) { ktile(IntC<1>{}); after_tile(); --cnt; par = 0; }
+        if (cnt > 0 && par) { ktile(IntC<1>{}); --cnt; par = 0; }
         for (; cnt >= 2; cnt -= 2) {
             ktile(IntC<0>{});
-            after_tile();
             ktile(IntC<1>{});
-            after_tile();
         }
-        if (cnt) { ktile(IntC<0>{}); after_tile(); par = 1; }
+        if (cnt) { ktile(IntC<0>{}); par = 1; }
 
         const int m0 = bm0 + wm0, n0 = bn0 + wn0;
         if (PERSIST && kind == 1) {
-            // raw accumulators -> slab (xcd, ln), write-through; published after the next K tile's barrier
+            // raw accumulators -> slab (xcd, ln), write-through; published once every wave's stores have drained: a first part is the FIRST
+            // segment of a workgroup's list, so this wait + barrier happens once per workgroup and launch.  (Round 4 published from inside
+            // the K loop, after the next K tile's barrier; with the epoch a register value instead of the literal 1 that kept the flag's
+            // address live across the loop, and with all 256 registers taken hipcc reloaded it from scratch in every trip — a
+            // vmcnt(0) in front of the LDS-DMA pipeline: fc2 715 -> 638 us per launch became 715, profiles/r5a_ab_r4_vs_r5_b64.json.)
             const uint32_t base = (uint32_t)(xcd * QG + ln) * (uint32_t)(Q_SLAB * 4) + slab_lane;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -376,7 +376,8 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                                      __float_as_uint(acc[mi][ni][3])};
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, base + (uint32_t)((mi * 4 + ni) * 1024), 0, 16);
                 }
-            pub_pending = 1;
+            dma_wait_barrier();
+            if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, epoch(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (a.c_split != nullptr) {
             // the result as a split3 operand: bias + activation, then lanes (g, g + 1) complete each other's 8-column chunks
             // (v_permlane16_swap of accumulator pair (ni, ni + 1): even g ends with a chunk of tile ni, odd g with one of tile ni + 1).
@@ -463,15 +464,14 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no LDS-DMA write may outlive the workgroup's LDS allocation
-    if (pub_pending) {                                                 // (a first part is never a range's last segment; kept for safety)
-        __syncthreads();
-        after_tile();
-    }
     if constexpr (PERSIST) {
         // arrival: the last of the launch's workgroups closes the epoch (every workgroup read the epoch word before it arrived here)
-        if (tid == 0 && __hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nwg - 1)) {
-            __hip_atomic_store(ws.flag + W_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ws.flag + W_EPOCH, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            const unsigned ep = epoch();           // read BEFORE arriving: after the last arrival the word may already be the next epoch
+            if (__hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(Q_NWG - 1)) {
+                __hip_atomic_store(ws.flag + W_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ws.flag + W_EPOCH, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
