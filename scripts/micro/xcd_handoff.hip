@@ -1,5 +1,5 @@
 // Micro-benchmark 8 (round 3): what does it cost to hand MEGABYTES from one stage to the next INSIDE a persistent kernel on this
-// 8-XCD part — the open question behind a persistent whole-ViT-layer kernel for B <= 6.
+// 8-XCD part — the open question behind a persistent whole-ViT-layer kernel for B <= 6 (HISTORY.md §9).
 //   hipcc --offload-arch=gfx950 -O3 -o build_ab/xcd_handoff scripts/micro/xcd_handoff.hip && build_ab/xcd_handoff
 // The decoder's persistent kernel moves a few KB per step with device-scope dword atomics; a ViT stage at one crop hands over
 // 192 x 1280 floats (0.98 MB: x / h / attention output) up to 192 x 5120 (3.9 MB: the MLP hidden), and the consumer is a GEMM whose

@@ -504,7 +504,7 @@ def test_attention_b16_images_are_conflict_free_under_gfx950_lane_groups():
     old = dict(k_read=sum(k_read(208, kt, s) for kt in range(4) for s in range(3)), v_read=sum(v_read(144, dt, st, False) for dt in range(5) for st in range(2)),
                k_write=sum(k_write(208, w, m) for w in range(4) for m in range(5)), v_write=sum(v_write(144, w, m, False) for w in range(4) for m in range(5)))
     assert old["k_read"] == 48 and old["v_read"] == 40 and old["k_write"] > 0 and old["v_write"] > 0, old      # one extra cycle in each group of each read
-    # the padded V^T stride alone (DESIGN round 4, 11.13) fixes the reads but would have made round 4's writes 4-way: hence the swizzle + thread map
+    # the padded V^T stride alone (HISTORY.md 11.13) fixes the reads but would have made round 4's writes 4-way: hence the swizzle + thread map
     assert sum(v_read(160, dt, st, False) for dt in range(5) for st in range(2)) == 0
     assert sum(v_write(160, w, m, False) for w in range(4) for m in range(5)) > old["v_write"]
     assert 2 * (3 * 64 * 224 + 3 * 80 * 160) <= 160 * 1024                      # two workgroups per CU

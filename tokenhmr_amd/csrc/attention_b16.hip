@@ -1,5 +1,5 @@
 // ViT global self-attention on the bf16 matrix pipe: softmax(q k^T) v for one (crop, head) with every fp32 operand multiplied as three
-// bf16 pieces, six products per pair, fp32 accumulate ("split3") — what the ViT GEMMs of the split3 mode do, applied to
+// bf16 pieces, six products per pair, fp32 accumulate ("split3"; HISTORY.md 10.6) — what the ViT GEMMs of the split3 mode do, applied to
 // vit.py:113-122 (Attention.forward between the qkv and proj Linears).  Input / output as attention.hip: qkv (B,192,3840) fp32 with q
 // pre-scaled, out (B,192,1280) fp32 or the split3 operand of the proj GEMM.
 //

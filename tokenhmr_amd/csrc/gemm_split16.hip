@@ -4,7 +4,7 @@
 // LDS-DMA staging as gemm_split.hip (vit.py:82-87,104-126 are the products it serves).
 //
 // Why another MFMA shape (scripts/micro/mfma_bf16_sustained.hip, profiles/r4j_mfma_bf16_16x16x32_vs_32x32x16_sustained.log).  The split3
-// GEMMs run at the clock the part grants under 256 CUs of back-to-back bf16 MFMAs (1.4-1.5 GHz), so what counts is
+// GEMMs run at the clock the part grants under 256 CUs of back-to-back bf16 MFMAs (1.4-1.5 GHz, HISTORY.md 11.2), so what counts is
 // flops per joule — and on random operand bits the part SUSTAINS 2.09-2.12 PFLOP/s with 16x16x32 against 1.83 with 32x32x16 (register
 // operands), 1.81 against 1.67 with this kernel's 24 fragment reads and 9 LDS-DMA copies per K tile beside them.
 //
@@ -301,12 +301,19 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ws.part, 0, Q_NWG * Q_SLAB * 4, 0x00020000);
     const uint32_t slab_lane = (uint32_t)(wave * 16 * 1024 + lane * 16);       // a wave's 16 accumulators of 1 KiB each
     int par = 0;                 // buffer of the next K tile
-    // this launch's epoch (see Ws16), read from the workspace at each of its three uses instead of kept in a register across the K loops:
-    // the word only changes when the LAST workgroup of the launch has arrived at the end of the kernel.  (One more scalar register live
-    // across the loops made hipcc spill scalars into a vector register and re-derive three LDS fragment addresses inside the K loop.)
-    auto epoch = [&]() -> unsigned {
-        const unsigned e = __hip_atomic_load(ws.flag + W_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        return e == 0u ? 1u : e;
+    // this launch's epoch (see Ws16): read once; every workgroup reads it before any workgroup can have arrived
+    unsigned ep = 1u;
+    if constexpr (PERSIST) {
+        ep = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ws.flag + W_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u;
+        if (ep == 0u) ep = 1u;
+    }
+    // arrival (thread 0): a workgroup arrives once it no longer needs the epoch — after its consumer wait, or at its end if it has none; the
+    // last of the launch's Q_NWG arrivals closes the epoch.  `arrived_old` = the counter value this workgroup's arrival returned.
+    auto close_epoch_if_last = [&](unsigned arrived_old) {
+        if (arrived_old == (unsigned)(Q_NWG - 1)) {
+            __hip_atomic_store(ws.flag + W_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ws.flag + W_EPOCH, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     };
 
     {
@@ -322,10 +329,10 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
         tile_of(j, bm0, bn0);
         if (PERSIST && kind == 2) {
             // the accumulators of K tiles [0, kb) from lane ln of the previous XCD: one thread polls one word, then sc1 loads
+            unsigned arrived_old = 0u;
             if (tid == 0) {
                 unsigned spins = 0;
                 unsigned* f = ws.flag + (xcd - 1) * QG + ln;
-                const unsigned ep = epoch();
                 while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) {
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > (1u << 22)) {                        // ~0.5 s: report (device word + host-mapped word), never hang
@@ -335,6 +342,8 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                         break;
                     }
                 }
+                // this workgroup's last use of the epoch: arrive now — the atomic's round trip runs under the slab loads below
+                arrived_old = __hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             asm volatile("s_barrier" ::: "memory");
             const uint32_t base = (uint32_t)((xcd - 1) * QG + ln) * (uint32_t)(Q_SLAB * 4) + slab_lane;
@@ -345,6 +354,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                     const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (uint32_t)((mi * 4 + ni) * 1024), 0, 16);
                     acc[mi][ni] = f32x4{__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])};
                 }
+            if (tid == 0) close_epoch_if_last(arrived_old);
         } else {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -377,7 +387,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, base + (uint32_t)((mi * 4 + ni) * 1024), 0, 16);
                 }
             dma_wait_barrier();
-            if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, epoch(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (a.c_split != nullptr) {
             // the result as a split3 operand: bias + activation, then lanes (g, g + 1) complete each other's 8-column chunks
             // (v_permlane16_swap of accumulator pair (ni, ni + 1): even g ends with a chunk of tile ni, odd g with one of tile ni + 1).
@@ -465,14 +475,8 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no LDS-DMA write may outlive the workgroup's LDS allocation
     if constexpr (PERSIST) {
-        // arrival: the last of the launch's workgroups closes the epoch (every workgroup read the epoch word before it arrived here)
-        if (tid == 0) {
-            const unsigned ep = epoch();           // read BEFORE arriving: after the last arrival the word may already be the next epoch
-            if (__hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(Q_NWG - 1)) {
-                __hip_atomic_store(ws.flag + W_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(ws.flag + W_EPOCH, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+        // a workgroup without a consumer segment (first XCD; ranges that start on a tile boundary) arrives here
+        if (!has_post && tid == 0) close_epoch_if_last(__hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
 }
 
