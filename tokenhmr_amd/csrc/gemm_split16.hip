@@ -50,6 +50,16 @@ struct Ws16 {
     float* part;        // [8 * QG] slabs: slab (x, i) = the accumulators of the first part of the tile shared by lane i of XCDs x and x + 1
     unsigned* flag;     // [8 * QG] epochs; then the control words below
 };
+// A/B of the hand-over's two free choices (scripts/build_ab_lib.py --define ...; the defaults are what ships):
+//   THMR_S16_PUBLISH  when a first part's slab flag goes out: 0 = wait for the stores right behind them; 1 = after the next segment's K loop;
+//                     2 = after the FIRST K tile of the next segment (one peeled K tile: the stores drain under its MFMAs, as in round 4)
+//   THMR_S16_ARRIVE   0 = every workgroup arrives at its end; 1 = a consumer arrives right after its wait, the atomic under its slab loads
+#ifndef THMR_S16_PUBLISH
+#define THMR_S16_PUBLISH 2
+#endif
+#ifndef THMR_S16_ARRIVE
+#define THMR_S16_ARRIVE 1
+#endif
 constexpr int W_ERR = Q_NWG, W_EPOCH = Q_NWG + 1, W_DONE = Q_NWG + 2, W_HOST = Q_NWG + 4;      // W_HOST: 8-byte aligned (the flag array is)
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
@@ -300,13 +310,12 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ws.part, 0, Q_NWG * Q_SLAB * 4, 0x00020000);
     const uint32_t slab_lane = (uint32_t)(wave * 16 * 1024 + lane * 16);       // a wave's 16 accumulators of 1 KiB each
+    int pub_pending = 0;         // the slab's stores are issued; the flag goes out after the next K tile (see `publish`)
     int par = 0;                 // buffer of the next K tile
-    // this launch's epoch (see Ws16): read once; every workgroup reads it before any workgroup can have arrived
-    unsigned ep = 1u;
-    if constexpr (PERSIST) {
-        ep = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ws.flag + W_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u;
-        if (ep == 0u) ep = 1u;
-    }
+    // this launch's epoch (see Ws16): read once (requested here, consumed after the first fill so that its round trip runs under the
+    // prologue's copies); every workgroup reads it before any workgroup can have arrived
+    unsigned ep_raw = 0u, ep = 1u;
+    if constexpr (PERSIST) ep_raw = __hip_atomic_load(ws.flag + W_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // arrival (thread 0): a workgroup arrives once it no longer needs the epoch — after its consumer wait, or at its end if it has none; the
     // last of the launch's Q_NWG arrivals closes the epoch.  `arrived_old` = the counter value this workgroup's arrival returned.
     auto close_epoch_if_last = [&](unsigned arrived_old) {
@@ -323,6 +332,10 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
         set_offsets(bm0, bn0);          // persistent: M % 128 == 0 and N % 256 == 0, the offsets are the same for every tile
     }
     fill(0);
+    if constexpr (PERSIST) {
+        ep = __builtin_amdgcn_readfirstlane(ep_raw) + 1u;
+        if (ep == 0u) ep = 1u;
+    }
     for (int n = 0; n < nseg; ++n) {
         int j, kb, ke, kind, bm0, bn0;
         seg_of(n, j, kb, ke, kind);
@@ -342,8 +355,10 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                         break;
                     }
                 }
+#if THMR_S16_ARRIVE == 1
                 // this workgroup's last use of the epoch: arrive now — the atomic's round trip runs under the slab loads below
                 arrived_old = __hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             }
             asm volatile("s_barrier" ::: "memory");
             const uint32_t base = (uint32_t)((xcd - 1) * QG + ln) * (uint32_t)(Q_SLAB * 4) + slab_lane;
@@ -354,7 +369,11 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                     const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (uint32_t)((mi * 4 + ni) * 1024), 0, 16);
                     acc[mi][ni] = f32x4{__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])};
                 }
+#if THMR_S16_ARRIVE == 1
             if (tid == 0) close_epoch_if_last(arrived_old);
+#else
+            (void)arrived_old;
+#endif
         } else {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -362,21 +381,44 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                 for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
+        // publish the slab written at the end of the PREVIOUS segment once a K tile has passed: that tile's wait + barrier made every wave
+        // drain its write-through slab stores (vmcnt counts stores), under the tile's own MFMAs.  The K tile is PEELED out of the loop below:
+        // inside the loop the publish — a cold branch — made hipcc spill two register pairs and reload them in every trip (+12 % on fc2).
+        auto publish = [&]() {
+            if constexpr (PERSIST) {
+                if (pub_pending) {
+                    if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pub_pending = 0;
+                }
+            }
+        };
         int cnt = ke - kb;
-        if (cnt > 0 && par) { ktile(IntC<1>{}); --cnt; par = 0; }
+        if (cnt > 0 && par) {
+            ktile(IntC<1>{});
+            --cnt; par = 0;
+#if THMR_S16_PUBLISH == 2
+            publish();
+#endif
+        }
+#if THMR_S16_PUBLISH == 2
+        if constexpr (PERSIST) {
+            if (pub_pending && cnt >= 2) { ktile(IntC<0>{}); publish(); ktile(IntC<1>{}); cnt -= 2; }
+            else if (pub_pending && cnt == 1) { ktile(IntC<0>{}); publish(); par = 1; cnt = 0; }
+        }
+#endif
         for (; cnt >= 2; cnt -= 2) {
             ktile(IntC<0>{});
             ktile(IntC<1>{});
         }
         if (cnt) { ktile(IntC<0>{}); par = 1; }
+#if THMR_S16_PUBLISH >= 1
+        publish();           // (1: the whole K loop of the next segment has passed; 2: only reached with a segment of no K tile)
+#endif
 
         const int m0 = bm0 + wm0, n0 = bn0 + wn0;
         if (PERSIST && kind == 1) {
-            // raw accumulators -> slab (xcd, ln), write-through; published once every wave's stores have drained: a first part is the FIRST
-            // segment of a workgroup's list, so this wait + barrier happens once per workgroup and launch.  (Round 4 published from inside
-            // the K loop, after the next K tile's barrier; with the epoch a register value instead of the literal 1 that kept the flag's
-            // address live across the loop, and with all 256 registers taken hipcc reloaded it from scratch in every trip — a
-            // vmcnt(0) in front of the LDS-DMA pipeline: fc2 715 -> 638 us per launch became 715, profiles/r5a_ab_r4_vs_r5_b64.json.)
+            // raw accumulators -> slab (xcd, ln), write-through; a first part is the FIRST segment of a workgroup's list, its flag goes out
+            // after the first K tile of the next segment (`publish` above)
             const uint32_t base = (uint32_t)(xcd * QG + ln) * (uint32_t)(Q_SLAB * 4) + slab_lane;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -386,8 +428,12 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                                      __float_as_uint(acc[mi][ni][3])};
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, base + (uint32_t)((mi * 4 + ni) * 1024), 0, 16);
                 }
+#if THMR_S16_PUBLISH == 0
             dma_wait_barrier();
             if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+            pub_pending = 1;
+#endif
         } else if (a.c_split != nullptr) {
             // the result as a split3 operand: bias + activation, then lanes (g, g + 1) complete each other's 8-column chunks
             // (v_permlane16_swap of accumulator pair (ni, ni + 1): even g ends with a chunk of tile ni, odd g with one of tile ni + 1).
@@ -475,8 +521,18 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no LDS-DMA write may outlive the workgroup's LDS allocation
     if constexpr (PERSIST) {
+        if (pub_pending) {                                             // (a first part is never a range's last segment: >= 8 tiles per range; kept for safety)
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if constexpr (PERSIST) {
         // a workgroup without a consumer segment (first XCD; ranges that start on a tile boundary) arrives here
+#if THMR_S16_ARRIVE == 1
         if (!has_post && tid == 0) close_epoch_if_last(__hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#else
+        if (tid == 0) close_epoch_if_last(__hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#endif
     }
 }
 
