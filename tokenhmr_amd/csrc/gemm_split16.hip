@@ -55,10 +55,19 @@ struct Ws16 {
 //                     2 = after the FIRST K tile of the next segment (one peeled K tile: the stores drain under its MFMAs, as in round 4)
 //   THMR_S16_ARRIVE   0 = every workgroup arrives at its end; 1 = a consumer arrives right after its wait, the atomic under its slab loads
 #ifndef THMR_S16_PUBLISH
-#define THMR_S16_PUBLISH 2
+#define THMR_S16_PUBLISH 0
 #endif
 #ifndef THMR_S16_ARRIVE
 #define THMR_S16_ARRIVE 1
+#endif
+//   THMR_S16_EPOCH    1 = the epoch protocol; 0 = round 4's 0 / 1 flags (set by the producer from inside the K loop, cleared by the consumer; no
+//                     arrival): NOT robust against a late producer — exists only to price the protocol
+#ifndef THMR_S16_EPOCH
+#define THMR_S16_EPOCH 1
+#endif
+//   THMR_S16_FOLD     1 = per-lane LDS bases with the stage / wave offsets folded in; 0 = round 4's form (offsets left to the compiler)
+#ifndef THMR_S16_FOLD
+#define THMR_S16_FOLD 1
 #endif
 constexpr int W_ERR = Q_NWG, W_EPOCH = Q_NWG + 1, W_DONE = Q_NWG + 2, W_HOST = Q_NWG + 4;      // W_HOST: 8-byte aligned (the flag array is)
 
@@ -237,10 +246,16 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) {
         const uint32_t rowmaj = (uint32_t)l15 * ROWB + (uint32_t)((3 * g + pc + rot16(l15)) % SLOTS) * 16u;
+#if THMR_S16_FOLD
         fow[pc] = lds_addr_b(Bs) + (uint32_t)(wn0 * ROWB) + rowmaj;
         foa[pc] = lds_addr_b(As) + (uint32_t)(wm0 * ROWB) + (ABLK ? (uint32_t)((3 * g + pc) * 512 + l15 * 16) : rowmaj);      // (row-blocked A: wm0 / 32 blocks of 12 x 512 bytes — the same offset)
+#else
+        fow[pc] = rowmaj;
+        foa[pc] = ABLK ? (uint32_t)((3 * g + pc) * 512 + l15 * 16) : rowmaj;
+#endif
     }
     bf16x8 af[4][3], wf[2][4][3];                                      // activation fragments (rolling), weight fragments of this / the next K tile
+#if THMR_S16_FOLD
     auto read_a = [&](int buf, int mi, int pc) {
         const int off = ABLK ? (mi >> 1) * (SLOTS * 512) + (mi & 1) * 256 : mi * 16 * ROWB;
         af[mi][pc] = *reinterpret_cast<lds_frag_ptr>((uintptr_t)(foa[pc] + (uint32_t)(buf * A_STAGE + off)));
@@ -248,6 +263,17 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     auto read_w = [&](int buf, int set, int ni, int pc) {
         wf[set][ni][pc] = *reinterpret_cast<lds_frag_ptr>((uintptr_t)(fow[pc] + (uint32_t)(buf * B_STAGE + ni * 16 * ROWB)));
     };
+#else
+    const char* Afr = As + wm0 * ROWB;
+    const char* Bfr = Bs + wn0 * ROWB;
+    auto read_a = [&](int buf, int mi, int pc) {
+        const int off = ABLK ? (mi >> 1) * (SLOTS * 512) + (mi & 1) * 256 : mi * 16 * ROWB;
+        af[mi][pc] = *reinterpret_cast<const bf16x8*>(Afr + buf * A_STAGE + off + foa[pc]);
+    };
+    auto read_w = [&](int buf, int set, int ni, int pc) {
+        wf[set][ni][pc] = *reinterpret_cast<const bf16x8*>(Bfr + buf * B_STAGE + ni * 16 * ROWB + fow[pc]);
+    };
+#endif
     f32x4 acc[4][4];
 
     // one K tile out of buffer `buf` (weight fragment set `buf`)
@@ -346,7 +372,11 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
             if (tid == 0) {
                 unsigned spins = 0;
                 unsigned* f = ws.flag + (xcd - 1) * QG + ln;
+#if THMR_S16_EPOCH
                 while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) {
+#else
+                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+#endif
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > (1u << 22)) {                        // ~0.5 s: report (device word + host-mapped word), never hang
                         __hip_atomic_store(ws.flag + W_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -355,7 +385,9 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                         break;
                     }
                 }
-#if THMR_S16_ARRIVE == 1
+#if !THMR_S16_EPOCH
+                __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif THMR_S16_ARRIVE == 1
                 // this workgroup's last use of the epoch: arrive now — the atomic's round trip runs under the slab loads below
                 arrived_old = __hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
@@ -369,7 +401,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                     const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (uint32_t)((mi * 4 + ni) * 1024), 0, 16);
                     acc[mi][ni] = f32x4{__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])};
                 }
-#if THMR_S16_ARRIVE == 1
+#if THMR_S16_ARRIVE == 1 && THMR_S16_EPOCH
             if (tid == 0) close_epoch_if_last(arrived_old);
 #else
             (void)arrived_old;
@@ -393,6 +425,25 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
             }
         };
         int cnt = ke - kb;
+#if !THMR_S16_EPOCH
+        auto after_tile4 = [&]() {
+            if constexpr (PERSIST) {
+                if (pub_pending) {
+                    if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pub_pending = 0;
+                }
+            }
+        };
+        if (cnt > 0 && par) { ktile(IntC<1>{}); after_tile4(); --cnt; par = 0; }
+        for (; cnt >= 2; cnt -= 2) {
+            ktile(IntC<0>{});
+            after_tile4();
+            ktile(IntC<1>{});
+            after_tile4();
+        }
+        if (cnt) { ktile(IntC<0>{}); after_tile4(); par = 1; }
+        cnt = 0;
+#endif
         if (cnt > 0 && par) {
             ktile(IntC<1>{});
             --cnt; par = 0;
@@ -428,7 +479,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                                      __float_as_uint(acc[mi][ni][3])};
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, base + (uint32_t)((mi * 4 + ni) * 1024), 0, 16);
                 }
-#if THMR_S16_PUBLISH == 0
+#if THMR_S16_PUBLISH == 0 && THMR_S16_EPOCH
             dma_wait_barrier();
             if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
@@ -528,7 +579,9 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     }
     if constexpr (PERSIST) {
         // a workgroup without a consumer segment (first XCD; ranges that start on a tile boundary) arrives here
-#if THMR_S16_ARRIVE == 1
+#if !THMR_S16_EPOCH
+        (void)0;
+#elif THMR_S16_ARRIVE == 1
         if (!has_post && tid == 0) close_epoch_if_last(__hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #else
         if (tid == 0) close_epoch_if_last(__hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));

@@ -25,7 +25,9 @@ class Engine:
         """weight_arena: share another engine's (already loaded) packed weights — a second engine on the same GPU then only
         adds its own scratch arena (finalize it with assume_all_loaded=True)."""
         # experiments: None = the shipped library (or THMR_LIB=exp for a whole process); True = the -DTHMR_EXPERIMENTS build, which reads the
-        # THMR_* A/B knobs and carries the debug hooks — tests and scripts only
+        # THMR_* A/B knobs and carries the debug hooks — tests and scripts only; a path = another build of the library (scripts/ab_same_box.py).
+        # Each shared object has its OWN per-device turnstile for the persistent kernels (decoder grid barrier, split3 hand-over), so engines
+        # of two different libraries must not run CONCURRENTLY (two streams / threads) on one device; one after the other is fine.
         self.lib = _cabi.load(exp=experiments)
         self.cfg = cfg
         self._abi = self.lib.thmr_abi_version()          # (3 only for a previous round's build loaded by path: scripts/ab_same_box.py)

@@ -7,6 +7,8 @@ produced, so only 3 floats per crop are copied to the host instead of (B,6890,3)
 """
 import ctypes as C
 
+from collections.abc import Mapping
+
 import numpy as np
 import torch
 
@@ -68,27 +70,33 @@ def regress_joints_gpu(J, verts):
     return out
 
 
-class _BatchMetrics(dict):
+class _BatchMetrics(Mapping):
     """What `Evaluator.__call__` returns: the reference's {'mode_mpjpe': (B,) array, ...} — filled from the device on first access
-    (eval.py:149 ignores the return value, so a batch normally never pays a device synchronisation for it)."""
+    (eval.py:149 ignores the return value, so a batch normally never pays a device synchronisation for it).  A read-only Mapping, not a
+    dict subclass (CPython's fast paths for dict subclasses — `dict(res)`, `res.copy()`, `{**res}`, `==` — bypass an overridden
+    `__getitem__` and would hand out the placeholder values): every access goes through `__getitem__`, which returns a COPY of this
+    batch's slice as the reference does (`pose_utils.py:246` returns fresh arrays), so a caller can neither rewrite the evaluator's
+    stored metrics through it nor see them change after `merge_evaluator`."""
 
     def __init__(self, ev, lo, hi, keys):
-        dict.__init__(self, {k: None for k in keys})
-        self._ev, self._lo, self._hi = ev, lo, hi
+        self._ev, self._lo, self._hi, self._keys = ev, lo, hi, tuple(keys)
+        self._cache = {}
 
     def __getitem__(self, k):
-        if k not in self:
+        if k not in self._keys:
             raise KeyError(k)
-        return getattr(self._ev, k)[self._lo:self._hi]
+        if k not in self._cache:                     # the values of THIS batch, frozen at first access
+            self._cache[k] = np.array(getattr(self._ev, k)[self._lo:self._hi], copy=True)
+        return self._cache[k].copy()
 
-    def get(self, k, default=None):
-        return self[k] if k in self else default
+    def __iter__(self):
+        return iter(self._keys)
 
-    def values(self):
-        return [self[k] for k in self]
+    def __len__(self):
+        return len(self._keys)
 
-    def items(self):
-        return [(k, self[k]) for k in self]
+    def __repr__(self):
+        return "{" + ", ".join(f"{k!r}: {self[k]!r}" for k in self._keys) + "}"
 
 
 class Evaluator:
