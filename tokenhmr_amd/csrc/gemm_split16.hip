@@ -50,25 +50,16 @@ struct Ws16 {
     float* part;        // [8 * QG] slabs: slab (x, i) = the accumulators of the first part of the tile shared by lane i of XCDs x and x + 1
     unsigned* flag;     // [8 * QG] epochs; then the control words below
 };
-// A/B of the hand-over's two free choices (scripts/build_ab_lib.py --define ...; the defaults are what ships):
-//   THMR_S16_PUBLISH  when a first part's slab flag goes out: 0 = wait for the stores right behind them; 1 = after the next segment's K loop;
-//                     2 = after the FIRST K tile of the next segment (one peeled K tile: the stores drain under its MFMAs, as in round 4)
-//   THMR_S16_ARRIVE   0 = every workgroup arrives at its end; 1 = a consumer arrives right after its wait, the atomic under its slab loads
-#ifndef THMR_S16_PUBLISH
-#define THMR_S16_PUBLISH 0
-#endif
-#ifndef THMR_S16_ARRIVE
-#define THMR_S16_ARRIVE 1
-#endif
-//   THMR_S16_EPOCH    1 = the epoch protocol; 0 = round 4's 0 / 1 flags (set by the producer from inside the K loop, cleared by the consumer; no
-//                     arrival): NOT robust against a late producer — exists only to price the protocol
-#ifndef THMR_S16_EPOCH
-#define THMR_S16_EPOCH 1
-#endif
-//   THMR_S16_FOLD     1 = per-lane LDS bases with the stage / wave offsets folded in; 0 = round 4's form (offsets left to the compiler)
-#ifndef THMR_S16_FOLD
-#define THMR_S16_FOLD 1
-#endif
+// Measured alternatives of this hand-over (round 5, same-box interleaved against the round-4 library, fc2 class of a 64-crop step, 32 launches;
+// profiles/r5d_ab_r4_vs_*.json, r5e_ab_r4_vs_*.json; round 4 = 20.5-20.7 ms):
+//   the flag right behind the slab stores + one wait for them (what ships)                                21.1-21.2 ms
+//   the flag after the FIRST K tile of the next segment (peeled out of the loop)                          22.1
+//   the flag after the next segment's whole K loop (no wait at all; consumers of 1.9-tile ranges starve)  21.8
+//   the flag from inside the K loop, as in round 4 (a cold branch per K tile)                             22.9-24.0: with this file's kernel body as a
+//       function of (smem, tile, half) hipcc keeps two register pairs in scratch and reloads them in every trip — a vmcnt(0) in front
+//       of the LDS-DMA pipeline; round 4's source compiled without that by luck of its register allocation, which is also why the
+//       epoch protocol as a whole prices at +0.5 ms (2.6 % of fc2) against round 4 and not at zero
+//   arrival at the workgroup's end instead of under the consumer's slab loads: the same (22.06 vs 22.09)
 constexpr int W_ERR = Q_NWG, W_EPOCH = Q_NWG + 1, W_DONE = Q_NWG + 2, W_HOST = Q_NWG + 4;      // W_HOST: 8-byte aligned (the flag array is)
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
@@ -246,16 +237,10 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) {
         const uint32_t rowmaj = (uint32_t)l15 * ROWB + (uint32_t)((3 * g + pc + rot16(l15)) % SLOTS) * 16u;
-#if THMR_S16_FOLD
         fow[pc] = lds_addr_b(Bs) + (uint32_t)(wn0 * ROWB) + rowmaj;
         foa[pc] = lds_addr_b(As) + (uint32_t)(wm0 * ROWB) + (ABLK ? (uint32_t)((3 * g + pc) * 512 + l15 * 16) : rowmaj);      // (row-blocked A: wm0 / 32 blocks of 12 x 512 bytes — the same offset)
-#else
-        fow[pc] = rowmaj;
-        foa[pc] = ABLK ? (uint32_t)((3 * g + pc) * 512 + l15 * 16) : rowmaj;
-#endif
     }
     bf16x8 af[4][3], wf[2][4][3];                                      // activation fragments (rolling), weight fragments of this / the next K tile
-#if THMR_S16_FOLD
     auto read_a = [&](int buf, int mi, int pc) {
         const int off = ABLK ? (mi >> 1) * (SLOTS * 512) + (mi & 1) * 256 : mi * 16 * ROWB;
         af[mi][pc] = *reinterpret_cast<lds_frag_ptr>((uintptr_t)(foa[pc] + (uint32_t)(buf * A_STAGE + off)));
@@ -263,17 +248,6 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     auto read_w = [&](int buf, int set, int ni, int pc) {
         wf[set][ni][pc] = *reinterpret_cast<lds_frag_ptr>((uintptr_t)(fow[pc] + (uint32_t)(buf * B_STAGE + ni * 16 * ROWB)));
     };
-#else
-    const char* Afr = As + wm0 * ROWB;
-    const char* Bfr = Bs + wn0 * ROWB;
-    auto read_a = [&](int buf, int mi, int pc) {
-        const int off = ABLK ? (mi >> 1) * (SLOTS * 512) + (mi & 1) * 256 : mi * 16 * ROWB;
-        af[mi][pc] = *reinterpret_cast<const bf16x8*>(Afr + buf * A_STAGE + off + foa[pc]);
-    };
-    auto read_w = [&](int buf, int set, int ni, int pc) {
-        wf[set][ni][pc] = *reinterpret_cast<const bf16x8*>(Bfr + buf * B_STAGE + ni * 16 * ROWB + fow[pc]);
-    };
-#endif
     f32x4 acc[4][4];
 
     // one K tile out of buffer `buf` (weight fragment set `buf`)
@@ -336,7 +310,6 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ws.part, 0, Q_NWG * Q_SLAB * 4, 0x00020000);
     const uint32_t slab_lane = (uint32_t)(wave * 16 * 1024 + lane * 16);       // a wave's 16 accumulators of 1 KiB each
-    int pub_pending = 0;         // the slab's stores are issued; the flag goes out after the next K tile (see `publish`)
     int par = 0;                 // buffer of the next K tile
     // this launch's epoch (see Ws16): read once (requested here, consumed after the first fill so that its round trip runs under the
     // prologue's copies); every workgroup reads it before any workgroup can have arrived
@@ -372,11 +345,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
             if (tid == 0) {
                 unsigned spins = 0;
                 unsigned* f = ws.flag + (xcd - 1) * QG + ln;
-#if THMR_S16_EPOCH
                 while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ep) {
-#else
-                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-#endif
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > (1u << 22)) {                        // ~0.5 s: report (device word + host-mapped word), never hang
                         __hip_atomic_store(ws.flag + W_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -385,12 +354,8 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                         break;
                     }
                 }
-#if !THMR_S16_EPOCH
-                __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#elif THMR_S16_ARRIVE == 1
                 // this workgroup's last use of the epoch: arrive now — the atomic's round trip runs under the slab loads below
                 arrived_old = __hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
             }
             asm volatile("s_barrier" ::: "memory");
             const uint32_t base = (uint32_t)((xcd - 1) * QG + ln) * (uint32_t)(Q_SLAB * 4) + slab_lane;
@@ -401,11 +366,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                     const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (uint32_t)((mi * 4 + ni) * 1024), 0, 16);
                     acc[mi][ni] = f32x4{__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])};
                 }
-#if THMR_S16_ARRIVE == 1 && THMR_S16_EPOCH
             if (tid == 0) close_epoch_if_last(arrived_old);
-#else
-            (void)arrived_old;
-#endif
         } else {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -413,63 +374,21 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                 for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
-        // publish the slab written at the end of the PREVIOUS segment once a K tile has passed: that tile's wait + barrier made every wave
-        // drain its write-through slab stores (vmcnt counts stores), under the tile's own MFMAs.  The K tile is PEELED out of the loop below:
-        // inside the loop the publish — a cold branch — made hipcc spill two register pairs and reload them in every trip (+12 % on fc2).
-        auto publish = [&]() {
-            if constexpr (PERSIST) {
-                if (pub_pending) {
-                    if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    pub_pending = 0;
-                }
-            }
-        };
         int cnt = ke - kb;
-#if !THMR_S16_EPOCH
-        auto after_tile4 = [&]() {
-            if constexpr (PERSIST) {
-                if (pub_pending) {
-                    if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    pub_pending = 0;
-                }
-            }
-        };
-        if (cnt > 0 && par) { ktile(IntC<1>{}); after_tile4(); --cnt; par = 0; }
-        for (; cnt >= 2; cnt -= 2) {
-            ktile(IntC<0>{});
-            after_tile4();
-            ktile(IntC<1>{});
-            after_tile4();
-        }
-        if (cnt) { ktile(IntC<0>{}); after_tile4(); par = 1; }
-        cnt = 0;
-#endif
         if (cnt > 0 && par) {
             ktile(IntC<1>{});
             --cnt; par = 0;
-#if THMR_S16_PUBLISH == 2
-            publish();
-#endif
         }
-#if THMR_S16_PUBLISH == 2
-        if constexpr (PERSIST) {
-            if (pub_pending && cnt >= 2) { ktile(IntC<0>{}); publish(); ktile(IntC<1>{}); cnt -= 2; }
-            else if (pub_pending && cnt == 1) { ktile(IntC<0>{}); publish(); par = 1; cnt = 0; }
-        }
-#endif
         for (; cnt >= 2; cnt -= 2) {
             ktile(IntC<0>{});
             ktile(IntC<1>{});
         }
         if (cnt) { ktile(IntC<0>{}); par = 1; }
-#if THMR_S16_PUBLISH >= 1
-        publish();           // (1: the whole K loop of the next segment has passed; 2: only reached with a segment of no K tile)
-#endif
 
         const int m0 = bm0 + wm0, n0 = bn0 + wn0;
         if (PERSIST && kind == 1) {
-            // raw accumulators -> slab (xcd, ln), write-through; a first part is the FIRST segment of a workgroup's list, its flag goes out
-            // after the first K tile of the next segment (`publish` above)
+            // raw accumulators -> slab (xcd, ln), write-through; then ONE wait for every wave's stores (vmcnt counts stores) + barrier, and
+            // the flag.  A first part is the FIRST segment of a workgroup's list: once per workgroup and launch.
             const uint32_t base = (uint32_t)(xcd * QG + ln) * (uint32_t)(Q_SLAB * 4) + slab_lane;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -479,12 +398,8 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                                      __float_as_uint(acc[mi][ni][3])};
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, base + (uint32_t)((mi * 4 + ni) * 1024), 0, 16);
                 }
-#if THMR_S16_PUBLISH == 0 && THMR_S16_EPOCH
             dma_wait_barrier();
             if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-            pub_pending = 1;
-#endif
         } else if (a.c_split != nullptr) {
             // the result as a split3 operand: bias + activation, then lanes (g, g + 1) complete each other's 8-column chunks
             // (v_permlane16_swap of accumulator pair (ni, ni + 1): even g ends with a chunk of tile ni, odd g with one of tile ni + 1).
@@ -572,20 +487,8 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no LDS-DMA write may outlive the workgroup's LDS allocation
     if constexpr (PERSIST) {
-        if (pub_pending) {                                             // (a first part is never a range's last segment: >= 8 tiles per range; kept for safety)
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if constexpr (PERSIST) {
         // a workgroup without a consumer segment (first XCD; ranges that start on a tile boundary) arrives here
-#if !THMR_S16_EPOCH
-        (void)0;
-#elif THMR_S16_ARRIVE == 1
         if (!has_post && tid == 0) close_epoch_if_last(__hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-#else
-        if (tid == 0) close_epoch_if_last(__hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-#endif
     }
 }
 
