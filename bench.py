@@ -200,7 +200,10 @@ def cpu_baseline(cfg, sd, tok, smpl, workload, budget_s=150.0):
                     break
             ts.sort()
             res[B] = (B / ts[len(ts) // 2], len(ts))
-    return {"value": round(res[8][0], 3), "unit": "crops/s", "cores": threads, "kind": "port", "host_cpus": ncpu,
+    return {"value": round(res[8][0], 3), "unit": "crops/s", "cores": threads, "kind": "port",
+            "kind_note": ("port = oracle/tokenhmr_oracle.py, the CPU restatement pinned bit-exact to the reference's modules — NOT the reference's own "
+                          "modules: /root/reference does not exist on the GPU box"),
+            "host_cpus": ncpu,
             "usable_cpus": usable, "sweep": sweep,
             "value_b1": round(res[1][0], 3), "value_b8": round(res[8][0], 3),
             "sample": (f"oracle (torch CPU fp32, restatement pinned bit-exact to the reference modules), {workload} path, "
@@ -743,7 +746,7 @@ def main():
             # split3: the dominant kernel is gemm_split16_kernel on the bf16 matrix pipe, which executes SIX bf16 MFMA flops per
             # fp32-equivalent flop: achieved / peak are bf16 MFMA TFLOP/s there (the fp32-equivalent rate beside them)
             pk, mul = (PEAK_BF16_MFMA_TFLOPS, 6.0) if split_mode else (PEAK_F32_MFMA_TFLOPS, 1.0)
-            kern = ("gemm_split16_kernel<GELU, split3 output> on v_mfma_f32_16x16x32_bf16" if split_mode else "gemm_f32_kernel")
+            kern = ("gemm_split16_tail_kernel / gemm_split16_kernel<GELU, split3 output> on v_mfma_f32_16x16x32_bf16" if split_mode else "gemm_f32_kernel")
             roof = {"bound": "mfma", "kernel": f"{kern} ({dom})", "achieved": round(tf * mul, 2),
                     "peak": pk, "unit": "TFLOP/s",
                     "frac": round(tf * mul / pk, 4),
@@ -758,18 +761,19 @@ def main():
             # profiles/; FETCH_SIZE doubled per the gfx950 correction) — cannot be collected live inside this process, so it is a
             # RECORDED number and labelled as such
             alg = {"gemm_fc1": (6.0 if split_mode else 4.0) * (12288 * 1280 + 5120 * 1280 + 12288 * 5120)}
-            for pmc_file in ("r4_final_pmc.json", "r4p_pmc_split3_persistent.json"):
+            for pmc_file in ("r5_final_pmc.json", "r4_final_pmc.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                         pj = json.load(f)
                 except (OSError, ValueError):
                     continue
-                key = ("gemm_split16_kernel<4, 2, false, false>" if split_mode else "gemm_f32_kernel") if dom == "gemm_fc1" else None
-                pmc = pj.get(key) if key else None
+                # fc1 of a 64-crop batch runs the mixed grid (half-tile tail) since round 5; the round-4 file knows only the plain grid
+                keys = (["gemm_split16_tail_kernel<2, false>", "gemm_split16_kernel<4, 2, false, false>"] if split_mode else ["gemm_f32_kernel"]) if dom == "gemm_fc1" else []
+                pmc = next((pj[k] for k in keys if k in pj), None)
                 if pmc and a.batch == 64 and a.workload in ("full", "vit"):
                     roof["traffic"] = round(pmc["traffic_bytes"])
                     roof["traffic_source"] = (f"profiles/{pmc_file} (rocprofv3 --pmc pass of this kernel at B = 64: FETCH_SIZE*2 + WRITE_SIZE, "
-                                              "bytes/launch; recorded, not live)")
+                                              f"bytes/launch; recorded, not live; build {pj.get('_build', 'n/a')})")
                     roof["algorithmic_bytes_per_launch"] = alg[dom]
                     if "mfma_util_profiled" in pmc:
                         roof["pmc_mfma_util"] = pmc["mfma_util_profiled"]
@@ -799,7 +803,9 @@ def main():
                 if lbs and lbs["launches"]:
                     gbs = lbs["bytes"] / (lbs["ms"] * 1e-3) / 1e9
                     roof["lbs_hbm"] = {"batch": B, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                       "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_ms": round(lbs["ms"] / lbs["launches"], 4)}
+                                       "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_ms": round(lbs["ms"] / lbs["launches"], 4),
+                                       "bound": ("NOT hbm: three dependent launches, latency + LDS-bound (DESIGN.md 3.5); the rate is reported because "
+                                                 "north_star asks for it, it is not a fraction of a roof that binds this stage")}
                     if world == 1:
                         roof["lbs_hbm_b512"] = lbs_at_b512(dev, smpl)
         par, facade = None, None

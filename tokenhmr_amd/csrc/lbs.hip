@@ -6,7 +6,10 @@
 // algorithm), and tokenhmr/lib/utils/geometry.py:86-124 perspective_projection as called
 // at tokenhmr/lib/models/tokenhmr.py:183-187.
 //
-// HBM-bound stage (83 KB written per crop; 19.8 MB of constants).  Layout decisions:
+// SURVEY classes this stage as HBM-bound (83 KB written per crop; 19.8 MB of constants per batch).  Measured it is NOT: 25 MB in 55 us at 64
+// crops = 0.057 of the HBM peak — three dependent launches (9 + 13 + 29 us) whose time is per-workgroup set-up, the 72 broadcast LDS reads of
+// bone matrices per thread and crop, and the serial joint finish (five restructurings measured and not kept, HISTORY.md 10.4,
+// 11.8).  Layout decisions:
 //   * J = J_regressor . v_shaped is linear in betas, so J_template (24x3) and J_shapedirs (24x3x10) are
 //     precomputed once in fp64 at load time: no per-crop reduction over 6890 vertices before the chain.
 //   * blend shapes + pose correctives are ONE matrix product: v_posed (B x 20670) = [betas | pose_feature] (B x 217, zero-
