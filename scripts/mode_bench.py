@@ -1,5 +1,5 @@
-"""Full path at B crops with the ViT GEMMs in both modes of thmr_set_vit_gemm: "f32" (exact-fp32 MFMA, the default and the headline) and
-"split3" (fp32 operands as three bf16 pieces on the bf16 matrix pipe).  Per mode: ms per call (best of 3 windows of `iters` calls),
+"""Full path at B crops with the ViT GEMMs in both modes of thmr_set_vit_gemm: "split3" (fp32 operands as three bf16 pieces on the bf16 matrix pipe: the engine default since round 5) and
+"f32" (exact-fp32 MFMA, the opt-out).  Per mode: ms per call (best of 3 windows of `iters` calls),
 crops/s, the per-class profile of one profiled call, and the difference of the outputs between the modes.
 
     python scripts/mode_bench.py [B=64] [iters=10]

@@ -1,4 +1,4 @@
-"""CPU (-m "not gpu"): the arithmetic claim behind the opt-in "split3" GEMM mode (tokenhmr_amd/csrc/gemm_split.hip), checked in numpy:
+"""CPU (-m "not gpu"): the arithmetic claim behind the "split3" GEMM mode (the engine default since round 5; tokenhmr_amd/csrc/gemm_split16.hip), checked in numpy:
 an fp32 number is the sum of three bf16 pieces to 2^-24, products of pieces are exact in fp32, and keeping the six piece pairs down to
 2^-16 leaves an error below one fp32 rounding of the product — so a dot product accumulated in fp32 from them is as accurate as the
 fp32 dot product itself."""

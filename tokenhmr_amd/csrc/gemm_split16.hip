@@ -60,6 +60,9 @@ struct Ws16 {
 //       of the LDS-DMA pipeline; round 4's source compiled without that by luck of its register allocation, which is also why the
 //       epoch protocol as a whole prices at +0.5 ms (2.6 % of fc2) against round 4 and not at zero
 //   arrival at the workgroup's end instead of under the consumer's slab loads: the same (22.06 vs 22.09)
+//   the shipped publish point WITHOUT any epoch (0 / 1 flags, consumer clears, no arrival) 21.30, the epoch advanced by workgroup 0 alone
+//       (no arrival atomics) 21.42, shipped 21.46 on that box (r4 20.8-20.9; profiles/r5g_*): the epoch protocol itself is free — the
+//       0.5 ms is what publishing behind an explicit wait costs against round 4's in-loop publish when that compiles without spills
 constexpr int W_ERR = Q_NWG, W_EPOCH = Q_NWG + 1, W_DONE = Q_NWG + 2, W_HOST = Q_NWG + 4;      // W_HOST: 8-byte aligned (the flag array is)
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));

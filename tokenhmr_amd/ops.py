@@ -125,7 +125,7 @@ def gemm_split3(a_s, w_s, bias=None, resid=None, epi="none", qscale=1.0, qcols=0
     """C = epilogue(a @ w.T) for split3 operands (`split3(a)`, `split3(w)`) on the bf16 matrix pipe with fp32-grade results: six
     bf16 products per element pair, fp32 accumulation.  `out_split`: the result as a split3 operand (what the engine's fc1 hands fc2);
     `out_blocked`: that operand in the row-blocked form (`split3_block`).  `a_blocked_rows=M`: `a_s` IS in the row-blocked form and has M rows.
-    The engine runs it only in its opt-in mode `Engine.set_vit_gemm("split3")`."""
+    What the engine runs for its ViT GEMMs in the default mode (`Engine.set_vit_gemm("split3")`, the creation default since ABI 4)."""
     _req(bias, resid)
     if a_blocked_rows is not None:
         if not (a_s.is_cuda and a_s.dtype == torch.int16 and a_s.is_contiguous() and a_s.dim() == 5 and a_s.shape[2:] == (3, 32, 8)):
