@@ -50,19 +50,18 @@ struct Ws16 {
     float* part;        // [8 * QG] slabs: slab (x, i) = the accumulators of the first part of the tile shared by lane i of XCDs x and x + 1
     unsigned* flag;     // [8 * QG] epochs; then the control words below
 };
-// Measured alternatives of this hand-over (round 5, same-box interleaved against the round-4 library, fc2 class of a 64-crop step, 32 launches;
-// profiles/r5d_ab_r4_vs_*.json, r5e_ab_r4_vs_*.json; round 4 = 20.5-20.7 ms):
-//   the flag right behind the slab stores + one wait for them (what ships)                                21.1-21.2 ms
-//   the flag after the FIRST K tile of the next segment (peeled out of the loop)                          22.1
-//   the flag after the next segment's whole K loop (no wait at all; consumers of 1.9-tile ranges starve)  21.8
-//   the flag from inside the K loop, as in round 4 (a cold branch per K tile)                             22.9-24.0: with this file's kernel body as a
-//       function of (smem, tile, half) hipcc keeps two register pairs in scratch and reloads them in every trip — a vmcnt(0) in front
-//       of the LDS-DMA pipeline; round 4's source compiled without that by luck of its register allocation, which is also why the
-//       epoch protocol as a whole prices at +0.5 ms (2.6 % of fc2) against round 4 and not at zero
-//   arrival at the workgroup's end instead of under the consumer's slab loads: the same (22.06 vs 22.09)
-//   the shipped publish point WITHOUT any epoch (0 / 1 flags, consumer clears, no arrival) 21.30, the epoch advanced by workgroup 0 alone
-//       (no arrival atomics) 21.42, shipped 21.46 on that box (r4 20.8-20.9; profiles/r5g_*): the epoch protocol itself is free — the
-//       0.5 ms is what publishing behind an explicit wait costs against round 4's in-loop publish when that compiles without spills
+// When the flag goes out — measured (round 5, same-box interleaved against the round-4 library, fc2 class of a 64-crop step = 32 launches;
+// profiles/r5d_*, r5e_*, r5g_*, r5h_*; round 4 = 20.5-20.9 ms box to box):
+//   from inside the K loop, after the K tile that follows the slab stores — that tile's wait + barrier drains every wave's write-through
+//       stores under its MFMAs — with the cold branch's operands (flag address, epoch) PARKED IN LDS: what ships, r4 + 0.14 ms
+//   the same branch with its operands in registers (round 4's form): 22.9-24.0 ms in this code base — hipcc keeps them in scratch and
+//       reloads two register pairs in every trip, a vmcnt(0) in front of the LDS-DMA pipeline (round 4's own source compiled without
+//       that by luck of its register allocation; the first build of round 5 did not: fc2 +12 %, found by the first same-box A/B)
+//   the flag right behind the slab stores + one explicit wait for them, nothing in the loop          r4 + 0.5 ms
+//   the flag after the first K tile of the next segment, peeled out of the loop                      r4 + 1.5
+//   the flag after the next segment's whole K loop (consumers of 1.9-tile ranges starve)             r4 + 1.2
+//   the epoch protocol itself: free (0 / 1 flags without any arrival 21.30 ms, epoch advanced by one workgroup without arrival atomics
+//       21.42, full protocol 21.46 at the same publish point); arrival at the workgroup's end instead of under the slab loads: the same
 constexpr int W_ERR = Q_NWG, W_EPOCH = Q_NWG + 1, W_DONE = Q_NWG + 2, W_HOST = Q_NWG + 4;      // W_HOST: 8-byte aligned (the flag array is)
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
@@ -314,6 +313,9 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ws.part, 0, Q_NWG * Q_SLAB * 4, 0x00020000);
     const uint32_t slab_lane = (uint32_t)(wave * 16 * 1024 + lane * 16);       // a wave's 16 accumulators of 1 KiB each
     int par = 0;                 // buffer of the next K tile
+    int pub_pending = 0;         // the slab's stores are issued; the flag goes out after the next K tile's barrier (every wave has drained them)
+    __shared__ uint32_t pub_slot[4];          // {flag address lo, hi, epoch}: what the cold publish branch needs, parked in LDS so that NOTHING
+                                              // but `pub_pending` is live across the K loop on its behalf (see the measurements above)
     // this launch's epoch (see Ws16): read once (requested here, consumed after the first fill so that its round trip runs under the
     // prologue's copies); every workgroup reads it before any workgroup can have arrived
     unsigned ep_raw = 0u, ep = 1u;
@@ -337,6 +339,10 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     if constexpr (PERSIST) {
         ep = __builtin_amdgcn_readfirstlane(ep_raw) + 1u;
         if (ep == 0u) ep = 1u;
+        if (tid == 0) {
+            const uint64_t fa = (uint64_t)(uintptr_t)(ws.flag + xcd * QG + ln);
+            pub_slot[0] = (uint32_t)fa; pub_slot[1] = (uint32_t)(fa >> 32); pub_slot[2] = ep;
+        }
     }
     for (int n = 0; n < nseg; ++n) {
         int j, kb, ke, kind, bm0, bn0;
@@ -377,21 +383,35 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                 for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
+        // the publish: a scalar test per K tile; the cold branch reads its operands from LDS (thread 0 wrote them, thread 0 reads them)
+        auto after_tile = [&]() {
+            if constexpr (PERSIST) {
+                if (pub_pending) {
+                    if (tid == 0) {
+                        const uint32_t lo = pub_slot[0], hi = pub_slot[1], e = pub_slot[2];
+                        __hip_atomic_store(reinterpret_cast<unsigned*>((uintptr_t)(((uint64_t)hi << 32) | lo)), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    pub_pending = 0;
+                }
+            }
+        };
         int cnt = ke - kb;
         if (cnt > 0 && par) {
             ktile(IntC<1>{});
+            after_tile();
             --cnt; par = 0;
         }
         for (; cnt >= 2; cnt -= 2) {
             ktile(IntC<0>{});
+            after_tile();
             ktile(IntC<1>{});
+            after_tile();
         }
-        if (cnt) { ktile(IntC<0>{}); par = 1; }
+        if (cnt) { ktile(IntC<0>{}); after_tile(); par = 1; }
 
         const int m0 = bm0 + wm0, n0 = bn0 + wn0;
         if (PERSIST && kind == 1) {
-            // raw accumulators -> slab (xcd, ln), write-through; then ONE wait for every wave's stores (vmcnt counts stores) + barrier, and
-            // the flag.  A first part is the FIRST segment of a workgroup's list: once per workgroup and launch.
+            // raw accumulators -> slab (xcd, ln), write-through; published by `after_tile` once the next K tile's wait + barrier has passed
             const uint32_t base = (uint32_t)(xcd * QG + ln) * (uint32_t)(Q_SLAB * 4) + slab_lane;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -401,8 +421,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                                      __float_as_uint(acc[mi][ni][3])};
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, base + (uint32_t)((mi * 4 + ni) * 1024), 0, 16);
                 }
-            dma_wait_barrier();
-            if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pub_pending = 1;
         } else if (a.c_split != nullptr) {
             // the result as a split3 operand: bias + activation, then lanes (g, g + 1) complete each other's 8-column chunks
             // (v_permlane16_swap of accumulator pair (ni, ni + 1): even g ends with a chunk of tile ni, odd g with one of tile ni + 1).
@@ -490,6 +509,10 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no LDS-DMA write may outlive the workgroup's LDS allocation
     if constexpr (PERSIST) {
+        if (pub_pending) {                                             // (a first part is never a range's last segment: >= 8 tiles per lane; kept for safety)
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(ws.flag + xcd * QG + ln, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // a workgroup without a consumer segment (first XCD; ranges that start on a tile boundary) arrives here
         if (!has_post && tid == 0) close_epoch_if_last(__hip_atomic_fetch_add(ws.flag + W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
