@@ -132,7 +132,9 @@ struct thmr_engine {
     // (hand-over slabs, segment bookkeeping, register spills around its epilogue) and wins the ragged last round: with the 16x16x32
     // kernel it is the faster one for fc2 (K = 5120: 671 vs 715 us) and ties or loses at K = 1280 (qkv 518 vs 515, proj 199 vs 187,
     // fc1 with split3 output 728 vs 702; profiles/r4k_split3_gemm_b64_mfma16.jsonl; whole path 834 vs 822 crops/s with all four,
-    // profiles/r4l_engine_b64_persist_min_k_ab.log).  Same bits either way.  THMR_SPLIT3_PERSIST_MASK (experiments build) for the A/B.
+    // profiles/r4l_engine_b64_persist_min_k_ab.log).  Round 5, same-box interleaved, the whole path at 64 crops (profiles/r5j_ab_mask8_vs_*):
+    // + proj +0.33 ms per step (a build whose proj instantiation had NO scratch access in its K loop), + qkv +0.96 ms: at 40 K tiles per
+    // tile the hand-over costs more than the ragged round's 6 %.  Same bits either way.  THMR_SPLIT3_PERSIST_MASK (experiments build).
     int s3_persist_mask = 8;
     bool s3_forced_once = false;      // experiments build: THMR_SPLIT3_FORCE_TIMEOUT=1 was honoured already
     struct SplitW { const char *qkv, *proj, *fc1, *fc2; };
