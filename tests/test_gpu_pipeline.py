@@ -439,38 +439,3 @@ def test_forward_is_captured_into_a_hip_graph_and_replays_bit_identically(built_
                 for k in keys:
                     assert torch.equal(outs[k], w[k]), (mode, B, rep, k)
         eng.status()
-
-
-@pytest.mark.gpu
-def test_attention_q_pieces_from_the_qkv_epilogue_are_bit_identical(built_lib, cuda_dev, monkeypatch):
-    """Default mode, 3 crops and more: the qkv GEMM writes its scaled q columns as a split3 operand (GemmArgs::cs_cols) and the bf16-pipe
-    attention kernel takes those pieces instead of re-splitting fp32 q for every key block (attention_b16.hip QSP).  The pieces are the ones
-    the kernel would make itself — same function, same fp32 value — so the ViT features must be bit-identical to the fp32-q path
-    (THMR_ATTN_QSP=0, experiments build), for batch sizes on both sides of the GEMM tile rules (128 x 128 tiles, 128 x 256, the half-tile
-    tail) and of the attention kernel's 64- / 192-query workgroups."""
-    from tokenhmr_amd.config import HMRConfig
-    from tokenhmr_amd import weights as W
-    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
-    from tokenhmr_amd.engine import Engine
-    cfg = HMRConfig(vit_depth=2, dec_depth=6)
-    sd, tok, smpl = W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0), make_synthetic_smpl(cfg, 0)
-    new = Engine(cfg, max_batch=64, device=cuda_dev)
-    new.load_state(sd, tok)
-    new.load_smpl(smpl)
-    new.finalize()
-    monkeypatch.setenv("THMR_ATTN_QSP", "0")              # read once, at thmr_create
-    old = Engine(cfg, max_batch=64, device=cuda_dev, weight_arena=new.weight_arena, experiments=True)
-    old.finalize(assume_all_loaded=True)
-    monkeypatch.delenv("THMR_ATTN_QSP")
-    assert new.vit_gemm() == "split3" and old.vit_gemm() == "split3"
-    img = torch.randn(64, 3, 256, 256, generator=torch.Generator().manual_seed(77)).to(cuda_dev)
-    for B in (3, 5, 8, 16, 21, 32, 48, 64):
-        a = new.vit_forward(img[:B]).clone()
-        b = old.vit_forward(img[:B]).clone()
-        assert torch.isfinite(a).all()
-        assert torch.equal(a, b), (B, int((a != b).sum()), float((a - b).abs().max()))
-    oa, ob = new.forward(img[:64]), old.forward(img[:64])
-    for k in ("token_idx", "pred_vertices", "pred_cam"):
-        assert torch.equal(oa[k], ob[k]), k
-    new.status()
-    old.status()

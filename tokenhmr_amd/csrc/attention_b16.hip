@@ -62,11 +62,8 @@ __device__ __forceinline__ bf16x8 pieces8(uint32_t a, uint32_t b, uint32_t c, ui
 // items; at most 512 workgroups (two per CU) walk them (workgroup (xcd, i) takes items i, i + grid / 8, ... of its XCD's contiguous share),
 // and the block pipeline does not drain between items: the next item's first K block and Q step are requested under the current item's
 // last P.V, exactly as block n + 1's are under block n's.
-// QSP: q arrives as a split3 operand `qs` [B * 192][1280 / 8][3][8] (the qkv GEMM's epilogue wrote the scaled q columns as pieces instead of
-// fp32: GemmArgs::cs_cols) — the same pieces split_q() makes, without the 324 of ~960 vector instructions per key block that re-make them
-// for every block.  The q columns of `qkv` are then never read.
-template <int QT, bool SPLIT, bool QSP>
-__global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* __restrict__ qkv, const char* __restrict__ qs, float* __restrict__ out, int nitems) {
+template <int QT, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* __restrict__ qkv, float* __restrict__ out, int nitems) {
     constexpr int QB = 3 / QT;
     static_assert(QT == 1 || QT == 3, "192 queries = QB workgroups x 4 waves x QT tiles of 16");
     __shared__ __attribute__((aligned(16))) char smem[K_IMG + V_IMG];
@@ -149,25 +146,10 @@ __global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* 
     };
 
     // ---- Q pieces of k step s: B operand of S^T = K Q^T, lane (query l15, g) holds d = 32 s + 8 g ... + 7 (nothing past d = 79) ----
-    f32x4 qraw[QSP ? 1 : QT][2];
-    bf16x8 qn[QSP ? QT : 1][3];             // QSP: the next step's pieces, in flight
-    constexpr int QS_ROW = DIM * 6;          // bytes of a split3 row of 1280 columns
-    auto rsrc_q = [&](int crop) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qs + (int64_t)crop * NTOK * QS_ROW), 0, NTOK * QS_ROW, 0x00020000); };
-    const uint32_t qsoff = (uint32_t)(l15 * QS_ROW + g * 48);
+    f32x4 qraw[QT][2];
     auto load_q = [&](const Item& im, int s) {
-        if constexpr (QSP) {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                const int ub = (im.q0 + qt * 16) * QS_ROW + (im.hcol / 8 + 4 * s) * 48;          // k-group (hcol + 32 s + 8 g) / 8, pieces 16 bytes apart
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    qn[qt][pc] = (s < 2 || g < 2) ? __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q(im.crop), qsoff + pc * 16, ub, 0))
-                                                  : pieces8(0u, 0u, 0u, 0u);
-            }
-            return;
-        }
-#pragma unroll
-        for (int qt = 0; qt < (QSP ? 0 : QT); ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             const int ub = im.hcol + (im.q0 + qt * 16) * QKV_LD + s * 32;
             if (s < 2 || g < 2) {
                 qraw[qt][0] = ld4(im, ub, qoff);
@@ -180,15 +162,8 @@ __global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* 
     };
     bf16x8 qf[QT][3];
     auto split_q = [&]() {
-        if constexpr (QSP) {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) qf[qt][pc] = qn[qt][pc];
-            return;
-        }
-#pragma unroll
-        for (int qt = 0; qt < (QSP ? 0 : QT); ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             uint32_t H[4], M[4], L[4];
             split3_pair(qraw[qt][0][0], qraw[qt][0][1], H[0], M[0], L[0]);
             split3_pair(qraw[qt][0][2], qraw[qt][0][3], H[1], M[1], L[1]);
@@ -426,22 +401,19 @@ __global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* 
 
 // out_split == true: `out` is the split3 operand [B*192][1280/8][3][8] bf16.  qt = 0: the batch-size rule (64-query workgroups up to 20 crops);
 // 1 / 3 force a shape (bit-identical).
-int launch_vit_attention_b16(const float* qkv, void* out, int B, bool out_split, int qt, hipStream_t s, const char* q_split) {
+int launch_vit_attention_b16(const float* qkv, void* out, int B, bool out_split, int qt, hipStream_t s) {
     if (B <= 0 || (qt != 0 && qt != 1 && qt != 3)) return -1;
-    if (q_split != nullptr && !out_split) return -1;             // (the engine's form only)
     if (qt == 0) qt = B <= 20 ? 1 : 3;        // stand-alone, us per launch qt = 1 / 3: 20.2 / 25.7 at 8 crops, 28.3 / 31.6 at 16, 53.1 / 50.0 at 32 (profiles/r4q_, r4r_attention_b16_*.jsonl)
     float* o = reinterpret_cast<float*>(out);
     const int nitems = B * NH * (3 / qt);                        // a multiple of 16: the kernel splits items and grid by the 8 XCDs
     static_assert(NH % 8 == 0, "items per crop must divide by the XCD count");
     const dim3 grid(nitems < 512 ? nitems : 512);
     if (qt == 1) {
-        if (q_split) hipLaunchKernelGGL((vit_attention_b16_kernel<1, true, true>), grid, dim3(256), 0, s, qkv, q_split, o, nitems);
-        else if (out_split) hipLaunchKernelGGL((vit_attention_b16_kernel<1, true, false>), grid, dim3(256), 0, s, qkv, nullptr, o, nitems);
-        else hipLaunchKernelGGL((vit_attention_b16_kernel<1, false, false>), grid, dim3(256), 0, s, qkv, nullptr, o, nitems);
+        if (out_split) hipLaunchKernelGGL((vit_attention_b16_kernel<1, true>), grid, dim3(256), 0, s, qkv, o, nitems);
+        else hipLaunchKernelGGL((vit_attention_b16_kernel<1, false>), grid, dim3(256), 0, s, qkv, o, nitems);
     } else {
-        if (q_split) hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, true>), grid, dim3(256), 0, s, qkv, q_split, o, nitems);
-        else if (out_split) hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, false>), grid, dim3(256), 0, s, qkv, nullptr, o, nitems);
-        else hipLaunchKernelGGL((vit_attention_b16_kernel<3, false, false>), grid, dim3(256), 0, s, qkv, nullptr, o, nitems);
+        if (out_split) hipLaunchKernelGGL((vit_attention_b16_kernel<3, true>), grid, dim3(256), 0, s, qkv, o, nitems);
+        else hipLaunchKernelGGL((vit_attention_b16_kernel<3, false>), grid, dim3(256), 0, s, qkv, o, nitems);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

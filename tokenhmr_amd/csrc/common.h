@@ -72,10 +72,6 @@ struct GemmArgs {
     //           fp32 tile: 7.5 of the 9.9 us fc1's epilogue costs per tile, profiles/r4e_split3_gemm_b64.jsonl); here 32 lanes write 512
     //           contiguous bytes.  Used for the one operand that only GEMM kernels touch: fc1's GELU output = fc2's A (vit.py:84-87).
     int a_blk, cs_blk;
-    // split3 GEMM only, with c_split: cs_cols > 0 = only columns [0, cs_cols) go out as the split3 operand (row length ldcs >= cs_cols), the
-    // rest as fp32 C; cs_cols % 256 == 0 so that a workgroup's tile is wholly one or the other.  The qkv GEMM's scaled q columns for the
-    // bf16-pipe attention kernel (attention_b16.hip QSP), k and v staying fp32.  0 = every column (fc1's GELU output).
-    int cs_cols;
 };
 
 // byte offset of chunk (row m, k-group n8, piece pc) of a split3 operand with row length ld (fp32-equivalents), row-major or row-blocked
@@ -402,7 +398,7 @@ int launch_vit_attention_keysplit(const float* qkv, float* out, int B, hipStream
 int launch_vit_attention_variant(const float* qkv, float* out, int B, int variant, hipStream_t s);   // 0 = rule; 1 / 3 / 5 / 12 / 6
 // attention_b16.hip: the same attention with every product as 3 x 3 bf16 pieces on v_mfma_f32_16x16x32_bf16 (six products, fp32 accumulate);
 // out = fp32 (B,192,1280) or the split3 operand; qt = 0 (batch-size rule), 1 (64-query workgroups), 3 (one workgroup per (crop, head))
-int launch_vit_attention_b16(const float* qkv, void* out, int B, bool out_split, int qt, hipStream_t s, const char* q_split = nullptr);     // q_split: q as a split3 operand [B * 192][1280] (attention_b16.hip QSP)
+int launch_vit_attention_b16(const float* qkv, void* out, int B, bool out_split, int qt, hipStream_t s);
 // rowops.hip
 int launch_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int D, float eps, int relu,
                      hipStream_t s);

@@ -108,7 +108,6 @@ struct thmr_engine {
     bool tiny_gemm = true;            // THMR_TINY_GEMM=0: the VQ decoder's GEMMs stay on the ring kernel in the small-batch regime (A/B only)
     bool qkv_ring16 = true;           // THMR_QKV_RING16=0: one and two crops keep the 64x64 ring kernel for qkv (A/B only)
     bool attn_keysplit = true;        // THMR_ATTN_KEYSPLIT=0: one and two crops keep the 64-query attention workgroups (A/B only)
-    bool attn_qsp = true;             // ... and takes its q as split3 pieces from the qkv GEMM's epilogue (GemmArgs::cs_cols); THMR_ATTN_QSP=0: A/B only
     bool attn_b16 = kAttnB16;         // split3 mode: the attention on the bf16 matrix pipe too (csrc/attention_b16.hip); THMR_ATTN_B16=0 / 1: A/B only
     int mid_split_force[2] = {-1, -1};   // THMR_MID_SPLIT=<p><f> (digits 0|2|4): force the split factors of proj and fc2 above 6 crops where the partial-sum buffer allows (A/B only)
     bool smpl_loaded = false, finalized = false;
@@ -554,20 +553,15 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             static const bool no_blk = [] { const char* k = thmr_knob("THMR_SPLIT3_BS_BLK"); return k && k[0] == '0'; }();      // A/B (experiments build)
             if (no_blk) bs_blk = 0;
         }
-        // q_pieces: the qkv GEMM writes its (scaled) q columns as a split3 operand into the idle GELU buffer instead of fp32, for the bf16-pipe
-        // attention kernel (GemmArgs::cs_cols; attention_b16.hip QSP)
-        auto gemm_s = [&](int cls, const char* A, int K, const char* Wt, const float* bias, const float* resid, float* C, int N, int epi, int a_blk = 0,
-                          char* q_pieces = nullptr) -> int {
+        auto gemm_s = [&](int cls, const char* A, int K, const char* Wt, const float* bias, const float* resid, float* C, int N, int epi, int a_blk = 0) -> int {
             ProfScope ps(e, st, cls, 2.0 * M * (double)N * K, 6.0 * ((double)M * K + (double)N * K) + 4.0 * M * N * (resid ? 2.0 : 1.0));
             GemmArgs a = mk(reinterpret_cast<const float*>(A), K, reinterpret_cast<const float*>(Wt), K, bias, resid, N, C, N, M, N, K);
             a.qscale = qscale; a.qcols = DIM;
             a.a_blk = a_blk;
-            if (q_pieces) { a.c_split = q_pieces; a.ldcs = DIM; a.cs_cols = DIM; }
             const int bit = cls == THMR_PROF_GEMM_QKV ? 1 : cls == THMR_PROF_GEMM_PROJ ? 2 : cls == THMR_PROF_GEMM_FC2 ? 8 : 0;
-            if (!q_pieces && e->s3_ws && e->s3_persist && (e->s3_persist_mask & bit) && gemm_split3_persist_ok(a)) return launch_split3_persist_serialised(e, a, epi, 0, st);
+            if (e->s3_ws && e->s3_persist && (e->s3_persist_mask & bit) && gemm_split3_persist_ok(a)) return launch_split3_persist_serialised(e, a, epi, 0, st);
             return launch_gemm_split3(a, epi, -1, st);
         };
-        char* const qs = (e->attn_b16 && e->attn_qsp) ? bs : nullptr;       // (bs is idle between a block's fc2 and the next block's fc1)
         {
             ProfScope ps(e, st, THMR_PROF_LN, 0, 10.0 * M * DIM);
             LAUNCH_OK(launch_layernorm_split3(x, e->vitw[0].n1w, e->vitw[0].n1b, hs, M, DIM, VIT_EPS, st));
@@ -576,10 +570,10 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             const VitBlockW& w = e->vitw[i];
             const thmr_engine::SplitW& ws = e->vitw_s[i];
             const bool last = i + 1 == e->vit_depth;
-            LAUNCH_OK(gemm_s(THMR_PROF_GEMM_QKV, hs, DIM, ws.qkv, w.qkvb, nullptr, big, 3 * DIM, EPI_BIAS_QSCALE, 0, qs));
+            LAUNCH_OK(gemm_s(THMR_PROF_GEMM_QKV, hs, DIM, ws.qkv, w.qkvb, nullptr, big, 3 * DIM, EPI_BIAS_QSCALE));
             {   // attention, its output written directly as proj's split3 operand
                 ProfScope ps(e, st, THMR_PROF_ATTN, 4.0 * B * HEADS * 192.0 * 192.0 * 80.0, 4.0 * (3.0 * M * DIM) + 6.0 * M * DIM);
-                if (e->attn_b16) LAUNCH_OK(launch_vit_attention_b16(big, hs, B, true, 0, st, qs));
+                if (e->attn_b16) LAUNCH_OK(launch_vit_attention_b16(big, hs, B, true, 0, st));
                 else LAUNCH_OK(launch_vit_attention_split3(big, hs, B, st));
             }
             if (s3_split > 1) {
@@ -1225,7 +1219,6 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* qr = thmr_knob("THMR_QKV_RING16"); e->qkv_ring16 = !(qr && qr[0] == '0'); }
     { const char* ak = thmr_knob("THMR_ATTN_KEYSPLIT"); e->attn_keysplit = !(ak && ak[0] == '0'); }
     { const char* ab = thmr_knob("THMR_ATTN_B16"); if (ab && (ab[0] == '0' || ab[0] == '1')) e->attn_b16 = ab[0] == '1'; }
-    { const char* ab = thmr_knob("THMR_ATTN_QSP"); if (ab && (ab[0] == '0' || ab[0] == '1')) e->attn_qsp = ab[0] == '1'; }
     { const char* ss = thmr_knob("THMR_SPLIT3_SMALL"); e->split3_small = ss && ss[0] == '1'; }
     { const char* fs = thmr_knob("THMR_SPLIT3_FC2_SPLIT"); e->split3_fc2_split = (fs && fs[0] == '1') ? 1 : kSplit3Fc2Split; }
     { const char* sm = thmr_knob("THMR_SPLIT3_MIN_B"); e->split3_min_b = sm ? atoi(sm) : 0; }

@@ -635,8 +635,7 @@ int launch_gemm_split3(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % SBK) != 0 || (a.lda % 8) != 0 || (a.ldw % 8) != 0) return -1;
     if (a.lda * 6 * 256 >= (int64_t(1) << 32) || a.ldw * 6 * 256 >= (int64_t(1) << 32)) return -1;     // 32-bit lane offsets within a tile
     if (a.cs_out != nullptr || a.ksplit > 1) return -1;
-    if (a.c_split != nullptr && ((a.N % 8) != 0 || (a.ldcs % 8) != 0 || a.ldcs < (a.cs_cols > 0 ? a.cs_cols : a.N) || epi == EPI_BIAS_RESID)) return -1;
-    if (a.cs_cols != 0 && (a.c_split == nullptr || a.C == nullptr || a.cs_cols < 0 || (a.cs_cols % 256) != 0 || a.cs_cols > a.N)) return -1;
+    if (a.c_split != nullptr && ((a.N % 8) != 0 || (a.ldcs % 8) != 0 || a.ldcs < a.N || epi == EPI_BIAS_RESID)) return -1;
     return launch_split3_tiles(a, epi, variant, s);
 }
 
@@ -696,7 +695,6 @@ static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStrea
         }
         if (variant == 5) return -1;
     }
-    if (a.cs_cols > 0 && variant != 0 && variant != 2) return -1;      // the split column range is the product kernels' (gemm_split16.hip)
     switch (variant) {
         // round 4: the product kernels multiply on v_mfma_f32_16x16x32_bf16 (gemm_split16.hip); the 32x32x16 kernels of this file are the
         // experiments build's variants 20 / 22 (and 1, 4, 3x below) — another grouping of k inside the MFMA, so equal to rounding only

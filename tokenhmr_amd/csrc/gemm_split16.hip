@@ -422,7 +422,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, base + (uint32_t)((mi * 4 + ni) * 1024), 0, 16);
                 }
             pub_pending = 1;
-        } else if (a.c_split != nullptr && (a.cs_cols <= 0 || bn0 < a.cs_cols)) {
+        } else if (a.c_split != nullptr) {
             // the result as a split3 operand: bias + activation, then lanes (g, g + 1) complete each other's 8-column chunks
             // (v_permlane16_swap of accumulator pair (ni, ni + 1): even g ends with a chunk of tile ni, odd g with one of tile ni + 1).
             // One address per lane; the 24 stores sit at offsets that are the same for every lane (row step, row-block step, chunk step).
