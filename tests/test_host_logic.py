@@ -536,3 +536,53 @@ def test_batch_metrics_is_a_faithful_read_only_mapping():
         res["nope"]
     with pytest.raises(TypeError):
         res["mode_re"] = np.zeros(3)                           # read-only
+
+
+def test_split3_handover_epoch_protocol_model():
+    """A model of the persistent split3 GEMM's slab hand-over (csrc/gemm_split16.hip: flag[xcd][lane] holds the EPOCH of the launch that
+    published the slab; every workgroup reads the workspace's epoch word at its start; a consumer accepts a slab iff its flag equals this
+    launch's epoch; the last of the launch's arrivals advances the epoch word) against the failure ADVICE r4 described for round 4's 0 / 1
+    flags: a producer that publishes AFTER its consumer's bounded wait ran out must not be able to feed a LATER launch a stale slab.
+    Launches on a stream are serialised by the kernel boundary and the (producer, consumer) pairs of a launch are independent, so a launch
+    is, per pair, either publish -> consume (on time) or timed-out consume -> late publish."""
+    import random
+
+    def run(protocol, seed):
+        rng = random.Random(seed)
+        lanes = 8
+        flag = [0] * lanes
+        slab = [None] * lanes               # (launch, lane) that wrote it
+        epoch_word = 0
+        stale_accepts = 0
+        for launch in range(1, 40):
+            ep = epoch_word + 1             # read once by every workgroup at its start
+            want = ep if protocol == "epoch" else 1
+
+            def publish(l):
+                slab[l] = (launch, l)
+                flag[l] = want
+
+            def consume(l, timed_out):
+                nonlocal stale_accepts
+                if flag[l] == want:         # the spin loop's exit condition
+                    if slab[l] != (launch, l):
+                        stale_accepts += 1
+                    if protocol == "flags01":
+                        flag[l] = 0         # round 4: the consumer re-arms the flag
+                else:
+                    assert timed_out        # an on-time pair always finds its flag
+                    if protocol == "flags01":
+                        flag[l] = 0         # round 4's time-out path stored 0 — and the late producer's 1 then survives the launch
+
+            for l in range(lanes):
+                if rng.random() < 0.2:      # this producer misses its consumer's bounded wait
+                    consume(l, True)
+                    publish(l)
+                else:
+                    publish(l)
+                    consume(l, False)
+            epoch_word = ep                 # the last arrival closes the epoch
+        return stale_accepts
+
+    assert sum(run("flags01", s) for s in range(20)) > 0          # the model reproduces round 4's hazard ...
+    assert all(run("epoch", s) == 0 for s in range(200))          # ... and an epoch flag cannot admit a slab of another launch
