@@ -224,6 +224,23 @@ def parity_vs_golden(o, B, cfg, workload):
     return _parity_block(o, g, "tests/golden/full_d32_b64.npz (reference modules, B = 64, depth 32)")
 
 
+def parity_golden_file(cfg, workload):
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "full_d32_b64.npz")
+    return np.load(path) if (workload == "full" and cfg.vit_depth == 32 and os.path.exists(path)) else None
+
+
+class GoldenRows:
+    """The first b crops of a 64-crop golden file (crops are independent on this path: no batch statistic, tokenhmr.py:146-188)."""
+    PER_CROP = ("token_idx", "top2_gap", "joints", "verts_sample", "joints_f64", "verts_sample_f64")
+
+    def __init__(self, g, b):
+        self.g, self.b, self.files = g, b, [f for f in g.files if f not in ("joints_f64", "verts_sample_f64")]
+
+    def __getitem__(self, k):
+        return self.g[k][:self.b] if k in self.PER_CROP else self.g[k]
+
+
 def _parity_block(o, g, against):
     import numpy as np
     idx = o["token_idx"].cpu().numpy()
@@ -837,6 +854,47 @@ def main():
                 pipeline = {a.vit_gemm: pipeline_bench(eng, dev, B, max(5, min(a.steps, 20)), 2, elapsed / a.steps * 1e3)}
             except Exception as ex:      # an extra must never cost the headline line
                 pipeline = {"error": f"{type(ex).__name__}: {ex}"}
+        sweep = None
+        if world == 1 and not a.no_extras and not cpu_dry and a.workload == "full" and B >= 32:
+            # The reference's OWN batch sizes through the same engine in the timed mode (untimed extra): 1 crop (BASELINE configs[0], a
+            # single detection), 8 (demo.py:70 DataLoader batch_size), 32 (README.md:316 eval batch) — and the timed batch again, by the
+            # same method, so the ratios are same-process, same-box.  HIP events on the launch stream, pre-allocated outputs.
+            try:
+                rows = []
+                gold = parity_golden_file(cfg, a.workload) if B == 64 else None      # rank 0's batch IS the fixture's input: rows [:b] are its first b crops
+                for b in (1, 2, 4, 8, 16, 32, B):
+                    ob = eng._alloc_outputs(b, taps=False, want_probs=True)
+                    xb = img[:b].contiguous()
+                    n_it = 30 if b <= 8 else max(5, min(a.steps, 20))
+                    for _ in range(3):
+                        eng.forward(xb, outputs=ob)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(n_it):
+                        eng.forward(xb, outputs=ob)
+                    e1.record()
+                    sync()
+                    ms = e0.elapsed_time(e1) / n_it
+                    row = {"batch": b, "ms_per_call": round(ms, 3), "crops_per_s": round(b / (ms * 1e-3), 2), "calls": n_it}
+                    if gold is not None:
+                        # depth-32 parity of THIS batch size against the reference's own modules (crops are independent: the fixture's
+                        # first b rows are the reference's answer for b crops alone) — every regime of the K sums, not only 64 crops
+                        blk = _parity_block(ob, GoldenRows(gold, b), f"tests/golden/full_d32_b64.npz rows [:{b}]")
+                        row["parity"] = {k: blk[k] for k in ("tokens", "mismatches", "mismatches_where_gap_gt_1e-3", "max_joint_err_m", "max_vertex_err_m")}
+                    rows.append(row)
+                eng.status()
+                ref_row = rows[-1]["crops_per_s"]
+                for r in rows:
+                    r["vs_timed_batch"] = round(r["crops_per_s"] / ref_row, 4)
+                sweep = {"vit_gemm": eng.vit_gemm(), "rows": rows,
+                         "timed_batch_row_vs_value": round(ref_row / value, 4),
+                         "what": ("untimed extra, run right after the timed region (before the other mode's pass): the reference's own batch sizes "
+                                  "(1 = one detection; 8 = demo.py:70; 32 = README.md:316), the sizes between them and the timed batch again by the "
+                                  "same method (`timed_batch_row_vs_value` = that row over `value`), same engine and mode, back-to-back calls on "
+                                  "resident crops; `parity` per row = token indices / joints / vertices of those b crops against the reference "
+                                  "modules' depth-32 golden; one and two crops run the exact-fp32 small-batch kernels in either mode")}
+            except Exception as ex:      # an extra must never cost the headline line
+                sweep = {"error": f"{type(ex).__name__}: {ex}"}
         other, other_name = None, ("exact_f32_mode" if split_mode else "split3_mode")
         if world == 1 and not a.no_extras and not cpu_dry and B >= 3:
             # SECOND measurement, not `value`: the same K steps with the ViT GEMMs in the engine's OTHER mode (thmr_set_vit_gemm), so one
@@ -893,37 +951,6 @@ def main():
                     eng.set_vit_gemm(a.vit_gemm)
                 except Exception:
                     pass
-        sweep = None
-        if world == 1 and not a.no_extras and not cpu_dry and a.workload == "full" and B >= 32:
-            # The reference's OWN batch sizes through the same engine in the timed mode (untimed extra): 1 crop (BASELINE configs[0], a
-            # single detection), 8 (demo.py:70 DataLoader batch_size), 32 (README.md:316 eval batch) — and the timed batch again, by the
-            # same method, so the ratios are same-process, same-box.  HIP events on the launch stream, pre-allocated outputs.
-            try:
-                rows = []
-                for b in (1, 8, 32, B):
-                    ob = eng._alloc_outputs(b, taps=False, want_probs=True)
-                    xb = img[:b].contiguous()
-                    n_it = 30 if b <= 8 else max(5, min(a.steps, 20))
-                    for _ in range(3):
-                        eng.forward(xb, outputs=ob)
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(n_it):
-                        eng.forward(xb, outputs=ob)
-                    e1.record()
-                    sync()
-                    ms = e0.elapsed_time(e1) / n_it
-                    rows.append({"batch": b, "ms_per_call": round(ms, 3), "crops_per_s": round(b / (ms * 1e-3), 2), "calls": n_it})
-                eng.status()
-                ref_row = rows[-1]["crops_per_s"]
-                for r in rows:
-                    r["vs_timed_batch"] = round(r["crops_per_s"] / ref_row, 4)
-                sweep = {"vit_gemm": eng.vit_gemm(), "rows": rows,
-                         "what": ("untimed extra: the reference's own batch sizes (1 = one detection; 8 = demo.py:70; 32 = README.md:316) and the timed "
-                                  "batch, same engine and mode, back-to-back calls on resident crops; one and two crops run the exact-fp32 "
-                                  "small-batch kernels in either mode")}
-            except Exception as ex:      # an extra must never cost the headline line
-                sweep = {"error": f"{type(ex).__name__}: {ex}"}
         if par is not None and world == 1 and not a.no_extras and not cpu_dry and a.workload == "full" and B == 64 and cfg.vit_depth == 32:
             try:
                 par["set"] = parity_set(cfg, dev, a.vit_gemm, par)

@@ -34,8 +34,10 @@ extern "C" {
  * 3 (round 3): thmr_set_vit_gemm / thmr_get_vit_gemm and the split3 operators added (no struct changed).
  * 4 (round 5): an engine is CREATED in mode 1 ("split3") — thmr_finalize_weights builds the split3 weight copies, thmr_forward runs the bf16
  *   matrix pipe from 3 crops on — and thmr_set_vit_gemm(0) is the opt-out to exact-fp32 MFMA (up to ABI 3 it was the other way round); no
- *   struct or signature changed. */
-#define THMR_ABI_VERSION 4
+ *   struct or signature changed.
+ * 5 (round 6): thmr_config.reserved[0] became `flags` (THMR_CFG_*: create in the opt-out mode, create without co-residency-dependent kernels;
+ *   a zeroed field = ABI 4's behaviour), thmr_mode_bytes added; the split3 weight copies are shared among the engines of one weight arena. */
+#define THMR_ABI_VERSION 5
 
 typedef enum {
     THMR_OK = 0,
@@ -55,8 +57,23 @@ typedef struct {
     int32_t dec_depth;          /* 6 (tokenhmr_release.yaml:74) */
     int32_t max_batch;          /* crops per thmr_forward call the scratch arena is sized for */
     int32_t device;             /* HIP device ordinal */
-    int32_t reserved[3];
+    int32_t flags;              /* THMR_CFG_* below, 0 = defaults */
+    int32_t reserved[2];        /* must be 0 */
 } thmr_config;
+
+/* thmr_config.flags */
+enum {
+    /* Create the engine in the exact-fp32 mode (as if thmr_set_vit_gemm(0) had been called before thmr_finalize_weights): finalize then
+     * builds NO split3 weight copies and allocates no split3 activation buffers (3.8 GB + 0.5 GB at release depth and 64 crops, outside the
+     * caller's arenas: thmr_mode_bytes).  thmr_set_vit_gemm(1) later builds them on demand. */
+    THMR_CFG_VIT_GEMM_F32 = 1,
+    /* No kernel that needs ALL its workgroups resident at once: the head runs as the launch chain instead of the persistent decoder kernel
+     * (grid barrier) and the split3 GEMMs one workgroup per tile instead of the 256-workgroup stream with slab hand-over (the ViT bit-identical,
+     * the head to fp32 summation order; a few per cent slower).  For a GPU SHARED WITH ANOTHER PROCESS: there the persistent kernels can starve each other until their bounded
+     * waits (~0.5 s) run out — one batch of invalid outputs, an error from the next call, then this mode anyway (thmr_engine_status).  Engines
+     * of ONE process are ordered by the library itself (one turn per forward-type call) and do not need the flag. */
+    THMR_CFG_NO_PERSISTENT = 2
+};
 
 /* One named tensor of the reference checkpoint contract:
  *   'backbone.*' / 'smpl_head.*'   tokenhmr/lib/utils/misc.py:242-256 (load_pretrained)
@@ -124,6 +141,11 @@ const char* thmr_build_info(void);
 /* Bytes the engine needs; lets the caller allocate the arenas itself (e.g. as torch tensors so
  * that torch.distributed/RCCL can broadcast the weight arena). */
 int thmr_arena_bytes(const thmr_config* cfg, size_t* weight_bytes, size_t* scratch_bytes);
+
+/* Device memory the engine allocates ITSELF, outside the two arenas, for `vit_gemm_mode` (0 / 1, see thmr_set_vit_gemm): the split3 copies
+ * of the ViT weights (shared by all engines of this process that were created on the same weight_arena_dev), the split3 activation operands
+ * of max_batch crops, the hand-over workspace of the persistent GEMM.  All 0 for mode 0 and for max_batch < 3.  No GPU needed. */
+int thmr_mode_bytes(const thmr_config* cfg, int32_t vit_gemm_mode, size_t* split_weight_bytes, size_t* split_act_bytes, size_t* workspace_bytes);
 
 /* Enumerate the checkpoint contract the engine expects (name + element count), index = 0..count-1.
  * Returns the number of tensors; name/numel may be NULL.  No GPU needed. */

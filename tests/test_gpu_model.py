@@ -235,6 +235,57 @@ def test_b64_tokens_vs_reference_golden(built_lib, cuda_dev, golden):
     torch.cuda.empty_cache()
 
 
+class _GoldenRows:
+    """The first B crops of a 64-crop golden file: crops are independent (no batch statistic anywhere on the path, tokenhmr.py:146-188),
+    so rows [:B] of the reference's 64-crop outputs ARE the reference's outputs for those B crops alone."""
+    _PER_CROP = ("token_idx", "top2_gap", "joints", "verts_sample", "rotmat", "betas", "cam", "kp2d", "probs_max", "joints_f64", "verts_sample_f64")
+
+    def __init__(self, g, B):
+        self._g, self._B, self.files = g, B, list(g.files)
+
+    def __getitem__(self, k):
+        v = self._g[k]
+        return v[:self._B] if k in self._PER_CROP else v
+
+
+# Every regime of the batch size (csrc/engine.hip: the association of the proj / fc2 K sums, the head's kernels) on both sides of each
+# boundary — split3: 1-2 | 3-4 | 5-15 | 16-31 | >= 32 (head: 6 | 7); f32: 1-2 | 3-6 | 7-16 | >= 17 — incl. demo.py:70's batch of 8 and
+# README.md:316's 32.
+REGIME_BATCHES = (1, 2, 3, 4, 5, 6, 7, 8, 15, 16, 17, 31, 32)
+
+
+@pytest.mark.parametrize("golden", B64_GOLDENS)
+def test_full_depth_tokens_every_batch_regime(built_lib, cuda_dev, golden):
+    """"bit-identical pose-token indices" 32 blocks deep at EVERY batch regime, not only at 2 and >= 32 crops.  The first
+    B crops of each 64-crop depth-32 fixture (the reference's own modules, oracle/gen_golden.py) run alone, for B on both sides of every
+    regime boundary, in both ViT GEMM modes: token indices equal to the reference's (0 mismatches — the same bound as at 64 crops), joints /
+    vertices / rotations / camera inside _check_b64_golden's bounds.  4 fixtures x 13 sizes x 2 modes; 160 B tokens each."""
+    from tokenhmr_amd.config import RELEASE
+    from tokenhmr_amd.model import TokenHMR
+    from tokenhmr_amd import weights as W
+    g = np.load(os.path.join(GOLDEN_DIR, golden + ".npz"))
+    vd, dd, B64, seed = [int(v) for v in g["meta"]]
+    style = str(g["style"]) if "style" in g.files else "init"
+    assert (vd, dd, B64) == (32, 6, 64)
+    sd, tok, smpl = _assets(RELEASE, seed, style)
+    assert abs(W.checksum(sd) - g["weights_checksum"][0]) < 1e-6 * max(1.0, abs(g["weights_checksum"][0]))
+    img = _inputs(B64, seed).to(cuda_dev)
+    model = TokenHMR.from_state(RELEASE, sd, tok, smpl, max_batch=max(REGIME_BATCHES), device=cuda_dev)
+    failures = []
+    for vit_gemm in ("split3", "f32"):
+        model.engine.set_vit_gemm(vit_gemm)
+        for B in REGIME_BATCHES:
+            out = _to_cpu(model({"img": img[:B]}))
+            model.engine.status()
+            try:
+                _check_b64_golden(out, _GoldenRows(g, B), f"{golden}[:{B}], ViT GEMMs {vit_gemm}")
+            except AssertionError as ex:        # report every (size, mode) that fails, not just the first
+                failures.append(f"B={B} {vit_gemm}: {ex}")
+    del model
+    torch.cuda.empty_cache()
+    assert not failures, "\n".join(failures)
+
+
 def _check_b64_golden(out, g, tag):
     idx, ref, gap = out["token_idx"].numpy(), g["token_idx"], g["top2_gap"]
     mism = idx != ref

@@ -127,6 +127,87 @@ def test_second_engine_shares_the_weight_arena(built_lib, cuda_dev):
         Engine(HMRConfig(vit_depth=1, dec_depth=1), max_batch=4, device=cuda_dev, weight_arena=e1.weight_arena)
 
 
+def test_creation_flags_and_shared_split_weights(built_lib, cuda_dev):
+    """ABI 5.  (1) An engine CREATED in the opt-out mode (vit_gemm="f32" -> THMR_CFG_VIT_GEMM_F32) finalizes without building
+    any split3 copy: device memory grows by the arenas only, results = the default engine switched to "f32".  (2) Engines that share a
+    weight arena share ONE split3 weight copy: the second engine's finalize allocates its activation operands only.  (3) An engine
+    created without the co-residency-dependent kernels (persistent=False -> THMR_CFG_NO_PERSISTENT: launch-chain head, per-tile split3
+    GEMMs) gives the default engine's ViT features bit for bit and its outputs to fp32 summation-order differences (the launch-chain head
+    associates its sums differently from the persistent decoder kernel: test_head_regimes_agree_and_persistent_decoders_coexist)."""
+    from tokenhmr_amd.config import HMRConfig
+    from tokenhmr_amd import weights as W
+    from tokenhmr_amd.smpl_assets import make_synthetic_smpl
+    from tokenhmr_amd.engine import Engine
+    cfg = HMRConfig(vit_depth=2, dec_depth=2)
+    sd, tok, smpl = W.make_synthetic_state(cfg, 0), W.make_synthetic_tokenizer(cfg, 0), make_synthetic_smpl(cfg, 0)
+    img = torch.randn(40, 3, 256, 256, generator=torch.Generator().manual_seed(5)).to(cuda_dev)
+
+    def used():
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info(cuda_dev)
+        return total - free
+
+    def make(**kw):
+        e = Engine(cfg, max_batch=40, device=cuda_dev, **kw)
+        if "weight_arena" not in kw:
+            e.load_state(sd, tok)
+            e.load_smpl(smpl)
+        return e
+
+    keys = ("pred_vertices", "pred_keypoints_3d", "token_idx", "cls_logits_softmax")
+    # (1) created in the opt-out mode
+    f = make(vit_gemm="f32")
+    assert f.vit_gemm() == "f32" and f.mode_bytes() == {"split_weights": 0, "split_activations": 0, "workspace": 0}
+    before = used()
+    f.finalize()
+    grown = used() - before
+    assert grown < 8 * 2 ** 20, f"finalize of an engine created in the f32 mode allocated {grown} bytes"
+    out_f = {k: v.clone() for k, v in f.forward(img).items()}
+    # default engine: finalize builds the copies thmr_mode_bytes announces
+    d = make()
+    mb = d.mode_bytes()
+    assert d.vit_gemm() == "split3" and mb["split_weights"] > 0 and mb["split_activations"] > 0
+    before = used()
+    d.finalize()
+    grown = used() - before
+    want = mb["split_weights"] + mb["split_activations"] + mb["workspace"]
+    assert want <= grown <= want + 64 * 2 ** 20, (grown, mb)
+    out_d = {k: v.clone() for k, v in d.forward(img).items()}
+    d.set_vit_gemm("f32")
+    out_df = d.forward(img)
+    for k in keys:
+        assert torch.equal(out_df[k], out_f[k]), k
+    d.set_vit_gemm("split3")
+    # (2) a second engine on the same arena: activations (+ workspace) only
+    before = used()
+    d2 = make(weight_arena=d.weight_arena)
+    d2.finalize(assume_all_loaded=True)
+    grown = used() - before
+    own = d2.scratch_bytes + mb["split_activations"] + mb["workspace"]
+    assert grown <= own + 64 * 2 ** 20 and grown < own + mb["split_weights"] // 2, (grown, own, mb)
+    out_d2 = d2.forward(img)
+    for k in keys:
+        assert torch.equal(out_d2[k], out_d[k]), k
+    d2.close()                                                   # the shared copy outlives one of its holders
+    out_d3 = d.forward(img)
+    torch.cuda.synchronize()
+    assert torch.equal(out_d3["pred_vertices"], out_d["pred_vertices"])
+    # (3) no persistent kernels
+    n = make(persistent=False)
+    assert n.mode_bytes()["workspace"] == 0
+    n.finalize()
+    for b in (40, 8, 3):
+        o_n, o_d = n.forward(img[:b], taps=True), d.forward(img[:b], taps=True)
+        assert torch.equal(o_n["vit_features"], o_d["vit_features"]), b
+        assert (o_n["pred_vertices"] - o_d["pred_vertices"]).abs().max() < 1e-4, b
+        assert (o_n["cls_logits_softmax"] - o_d["cls_logits_softmax"]).abs().max() < 1e-5, b
+    n.status()
+    d.status()
+    for e in (f, d, n):
+        e.close()
+    torch.cuda.empty_cache()
+
+
 def test_run_eval_loop_matches_manual_loop(built_lib, cuda_dev):
     """tokenhmr_amd.eval_dp.run_eval (eval.py:116-158 as a shardable job) on one process = the hand-written loop, for any
     batch size (per-sample metrics, so batching cannot change the means beyond fp32 regime differences)."""

@@ -90,6 +90,28 @@ def test_bad_config_is_rejected(built_lib):
         assert built_lib.thmr_last_error(None)
 
 
+def test_mode_bytes_and_creation_flags(built_lib):
+    """ABI 5: what the engine allocates OUTSIDE the caller's arenas is a query (thmr_mode_bytes), and the mode / the
+    co-residency-free kernels are creation-time choices (thmr_config.flags)."""
+    a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    cc = _cabi.Config(abi_version=_cabi.ABI_VERSION, vit_depth=32, dec_depth=6, max_batch=64, device=0)
+    assert built_lib.thmr_mode_bytes(C.byref(cc), 1, C.byref(a), C.byref(b), C.byref(c)) == 0
+    per_block = 1280 * 3840 + 1280 * 1280 + 2 * 1280 * 5120
+    assert a.value == (per_block * 32 + 6 * 1024 * 1280 + 1280 * 768) * 6            # 3.8 GB: ViT weights + stacked to_kv + patch embed, 6 bytes each
+    assert b.value == 64 * 192 * (1280 + 5120) * 6 + 2 * 64 * 192 * 1280 * 4
+    assert c.value > 256 * 128 * 256 * 4                                               # 256 slabs of one raw accumulator tile + flags
+    assert built_lib.thmr_mode_bytes(C.byref(cc), 0, C.byref(a), C.byref(b), C.byref(c)) == 0 and (a.value, b.value, c.value) == (0, 0, 0)
+    cc.flags = _cabi.CFG_NO_PERSISTENT
+    assert built_lib.thmr_mode_bytes(C.byref(cc), 1, C.byref(a), C.byref(b), C.byref(c)) == 0 and a.value > 0 and c.value == 0
+    cc.flags, cc.max_batch = 0, 2                                                      # one and two crops never reach the mode
+    assert built_lib.thmr_mode_bytes(C.byref(cc), 1, C.byref(a), C.byref(b), C.byref(c)) == 0 and (a.value, b.value, c.value) == (0, 0, 0)
+    assert built_lib.thmr_mode_bytes(C.byref(cc), 2, C.byref(a), None, None) == -1
+    for bad in (dict(flags=4), dict(flags=-1), dict(reserved=(C.c_int32 * 2)(1, 0))):
+        kw = dict(abi_version=_cabi.ABI_VERSION, vit_depth=2, dec_depth=2, max_batch=4, device=0)
+        kw.update(bad)
+        assert built_lib.thmr_arena_bytes(C.byref(_cabi.Config(**kw)), C.byref(a), None) == -1
+
+
 def test_create_without_gpu_fails_loudly(built_lib):
     if torch.cuda.is_available():
         pytest.skip("GPU present")

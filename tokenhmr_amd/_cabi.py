@@ -15,14 +15,16 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtokenhmr_hip.so")
 LIB_PATH_EXP = os.path.join(_HERE, "lib", "libtokenhmr_hip_exp.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "tokenhmr_hip.h")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
+# thmr_config.flags (header: THMR_CFG_*)
+CFG_VIT_GEMM_F32, CFG_NO_PERSISTENT = 1, 2
 PROF_NAMES = ["gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "attention", "layernorm", "patch_embed",
               "dec_kv", "head", "lbs"]
 
 
 class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("vit_depth", C.c_int32), ("dec_depth", C.c_int32),
-                ("max_batch", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("max_batch", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class TensorDesc(C.Structure):
@@ -68,8 +70,9 @@ _libs = {}
 def load(exp=None):
     """The shipped library, or (exp=True, or exp=None with THMR_LIB=exp in the environment) the experiments build.
     exp = a PATH (str): that very file — another BUILD of this library, e.g. the previous round's, loaded beside the current one by
-    scripts/ab_same_box.py so that two builds are timed interleaved in one process on one box (A/B tooling only; ABI 3 builds accepted:
-    no struct or signature changed between 3 and 4, only the creation default of the ViT GEMM mode)."""
+    scripts/ab_same_box.py so that two builds are timed interleaved in one process on one box (A/B tooling only; ABI 3 and 4 builds
+    accepted: no struct layout or signature changed between 3 and 5 — 4 changed the creation default of the ViT GEMM mode, 5 gave
+    thmr_config.reserved[0] a meaning and added thmr_mode_bytes, which such a build simply lacks)."""
     if exp is None:
         exp = os.environ.get("THMR_LIB", "") == "exp"
     if isinstance(exp, str):
@@ -95,7 +98,8 @@ def load(exp=None):
     except ImportError:
         pass
     lib = C.CDLL(path)
-    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    older = isinstance(exp, str) and lib.thmr_abi_version() in (3, 4)          # a previous round's build, loaded by path (A/B tooling)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s) and not (older and s in ("thmr_mode_bytes",))]
     if missing:
         raise RuntimeError(f"libtokenhmr_hip.so lacks symbols declared in tokenhmr_hip.h: {missing}")
     vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -105,6 +109,8 @@ def load(exp=None):
     lib.thmr_last_error.argtypes = [vp]
     lib.thmr_arena_bytes.argtypes = [C.POINTER(Config), C.POINTER(sz), C.POINTER(sz)]
     lib.thmr_spec.argtypes = [C.POINTER(Config), i32, C.POINTER(C.c_char_p), C.POINTER(i64)]
+    if hasattr(lib, "thmr_mode_bytes"):
+        lib.thmr_mode_bytes.argtypes = [C.POINTER(Config), i32, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     lib.thmr_create.argtypes = [C.POINTER(Config), vp, vp, C.POINTER(vp)]
     lib.thmr_destroy.argtypes = [vp]
     lib.thmr_destroy.restype = None
@@ -153,11 +159,13 @@ def load(exp=None):
     lib.thmr_get_vit_gemm.argtypes = [vp]
     lib.thmr_prof_collect.argtypes = [vp, C.POINTER(ProfEntry), i32]
     for name in declared_symbols():
+        if not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         if name not in ("thmr_build_info", "thmr_last_error", "thmr_destroy", "thmr_smpl_destroy", "thmr_cropper_destroy",
                         "thmr_cropper_last_error", "thmr_collective_last_error"):
             fn.restype = C.c_int
-    if lib.thmr_abi_version() != ABI_VERSION and not (isinstance(exp, str) and lib.thmr_abi_version() == 3):
+    if lib.thmr_abi_version() != ABI_VERSION and not older:
         raise RuntimeError("libtokenhmr_hip.so ABI version mismatch")
     _libs[exp] = lib
     return lib

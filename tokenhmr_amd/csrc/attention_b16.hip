@@ -62,7 +62,14 @@ __device__ __forceinline__ bf16x8 pieces8(uint32_t a, uint32_t b, uint32_t c, ui
 // items; at most 512 workgroups (two per CU) walk them (workgroup (xcd, i) takes items i, i + grid / 8, ... of its XCD's contiguous share),
 // and the block pipeline does not drain between items: the next item's first K block and Q step are requested under the current item's
 // last P.V, exactly as block n + 1's are under block n's.
-template <int QT, bool SPLIT>
+// ABL (experiments build only, timing-only ablations with garbage results — DESIGN.md 3.2's diagnosis, round 6): bit 0 = q is loaded for an
+// item's FIRST key block only (blocks 1, 2 re-split stale registers: the q re-reads' memory traffic gone, the vector work kept); bit 1 = K / V
+// are loaded for the first block of a workgroup's first item only (later blocks stage score registers into the images: no K / V traffic at all,
+// the staging's vector + LDS work kept); bit 2 = q is re-SPLIT for the first block only (the conversion's vector work gone, its loads kept).
+// EARLY (experiments build, round 6): the block's V and the next block's K are requested at the START of the S^T phase's k step EARLY - 1
+// (1 = before step 0, 2 = before step 1, 3 = before step 2) instead of after it — a whole MFMA phase for the loads to land instead of the
+// softmax's ~270 vector instructions; 40 more registers live through the phase.
+template <int QT, bool SPLIT, int ABL = 0, int EARLY = 0>
 __global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* __restrict__ qkv, float* __restrict__ out, int nitems) {
     constexpr int QB = 3 / QT;
     static_assert(QT == 1 || QT == 3, "192 queries = QB workgroups x 4 waves x QT tiles of 16");
@@ -217,8 +224,15 @@ __global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* 
             for (int pc = 0; pc < 3; ++pc) kc[pc] = *reinterpret_cast<const bf16x8*>(kfr + pc * KPL);
 #pragma unroll
             for (int st = 0; st < 3; ++st) {
-                split_q();
-                if (st + 1 < 3) load_q(cur, st + 1);          // in flight under this step's MFMAs
+                if constexpr (EARLY > 0 && (ABL & 2) == 0) {
+                    if (st == EARLY - 1) {
+                        load_v(cur, blk);
+                        if (more) load_k(cur, blk + 1);
+                        else if (has_next) load_k(nxt, 0);
+                    }
+                }
+                if ((ABL & 4) == 0 || blk == 0) split_q();
+                if (st + 1 < 3 && ((ABL & 1) == 0 || blk == 0)) load_q(cur, st + 1);          // in flight under this step's MFMAs
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
                     const int nx = st * 4 + kt + 1;
@@ -239,9 +253,24 @@ __global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* 
                 }
             }
             // ---- this block's V and the next block's K (this item's, or the next item's first): in flight under the softmax ----
-            load_v(cur, blk);
-            if (more) load_k(cur, blk + 1);
-            else if (has_next) load_k(nxt, 0);
+            if constexpr ((ABL & 2) == 0) {
+                if constexpr (EARLY == 0) {
+                    load_v(cur, blk);
+                    if (more) load_k(cur, blk + 1);
+                    else if (has_next) load_k(nxt, 0);
+                }
+            } else {                                           // ablation: the staging registers filled from live score registers instead of memory
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    kr[m] = s[0][m & 3];
+                    asm volatile("" : "+v"(kr[m]));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        vr[m][r] = s[0][(m + r) & 3][r];
+                        asm volatile("" : "+v"(vr[m][r]));
+                    }
+                }
+            }
             __syncthreads();                                   // every wave is done with the K image (and with the V^T image: its P.V came first)
             // ---- running softmax: m = max(m, block max); e = 2^(s log2 e - m log2 e); earlier sums and outputs scaled by 2^((m_old - m) log2 e) ----
 #pragma unroll
@@ -277,8 +306,10 @@ __global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* 
             write_v();
             if (more || has_next) write_k();
             __syncthreads();
-            if (more) load_q(cur, 0);                          // the next block's first Q step, in flight under P.V
-            else if (has_next) load_q(nxt, 0);
+            if constexpr ((ABL & 1) == 0) {
+                if (more) load_q(cur, 0);                      // the next block's first Q step, in flight under P.V
+                else if (has_next) load_q(nxt, 0);
+            } else if (!more && has_next) load_q(nxt, 0);
             // ---- O^T += V^T P^T: 2 k steps of 32 keys x 5 d tiles x (6 products x QT) MFMAs ----
             bf16x8 vc[3], vn[3];
 #pragma unroll
@@ -408,6 +439,35 @@ int launch_vit_attention_b16(const float* qkv, void* out, int B, bool out_split,
     const int nitems = B * NH * (3 / qt);                        // a multiple of 16: the kernel splits items and grid by the 8 XCDs
     static_assert(NH % 8 == 0, "items per crop must divide by the XCD count");
     const dim3 grid(nitems < 512 ? nitems : 512);
+#ifdef THMR_EXPERIMENTS
+    {
+        const char* ek = thmr_knob("THMR_ATTN_EARLY");
+        const int early = ek ? atoi(ek) : 0;
+        if (early > 0 && qt == 3 && out_split) {
+            switch (early) {
+                case 1: hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, 0, 1>), grid, dim3(256), 0, s, qkv, o, nitems); break;
+                case 2: hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, 0, 2>), grid, dim3(256), 0, s, qkv, o, nitems); break;
+                case 3: hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, 0, 3>), grid, dim3(256), 0, s, qkv, o, nitems); break;
+                default: return -1;
+            }
+            return hipGetLastError() == hipSuccess ? 0 : -2;
+        }
+        const char* k = thmr_knob("THMR_ATTN_ABL");
+        const int abl = k ? atoi(k) : 0;
+        if (abl > 0 && qt == 3 && out_split) {
+            switch (abl) {
+                case 1: hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, 1>), grid, dim3(256), 0, s, qkv, o, nitems); break;
+                case 2: hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, 2>), grid, dim3(256), 0, s, qkv, o, nitems); break;
+                case 3: hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, 3>), grid, dim3(256), 0, s, qkv, o, nitems); break;
+                case 4: hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, 4>), grid, dim3(256), 0, s, qkv, o, nitems); break;
+                case 5: hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, 5>), grid, dim3(256), 0, s, qkv, o, nitems); break;
+                case 7: hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, 7>), grid, dim3(256), 0, s, qkv, o, nitems); break;
+                default: return -1;
+            }
+            return hipGetLastError() == hipSuccess ? 0 : -2;
+        }
+    }
+#endif
     if (qt == 1) {
         if (out_split) hipLaunchKernelGGL((vit_attention_b16_kernel<1, true>), grid, dim3(256), 0, s, qkv, o, nitems);
         else hipLaunchKernelGGL((vit_attention_b16_kernel<1, false>), grid, dim3(256), 0, s, qkv, o, nitems);

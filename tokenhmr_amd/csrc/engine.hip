@@ -103,6 +103,7 @@ struct thmr_engine {
         const float *res_w[2], *res_b[2];   // the two 1x1 convs of the ResConv blocks
     } hot{};
     bool counted = false;             // registered in the per-device engine count (decoder turnstile)
+    bool no_persistent = false;       // THMR_CFG_NO_PERSISTENT: launch-chain head, per-tile split3 GEMMs, no hand-over workspace
     bool legacy_head = false;         // THMR_LEGACY_HEAD=1: force the chain-of-GEMMs head at every batch size (A/B only)
     bool mixer_cluster = true;        // THMR_MIXER_CLUSTER=0: always run the mixer stack as its own one-workgroup-per-crop kernel (A/B only)
     bool tiny_gemm = true;            // THMR_TINY_GEMM=0: the VQ decoder's GEMMs stay on the ring kernel in the small-batch regime (A/B only)
@@ -120,7 +121,8 @@ struct thmr_engine {
     bool split3_small = false;        // THMR_SPLIT3_SMALL=1: the split3 mode also serves up to six crops (ring kernel on split3 operands) — measured SLOWER, A/B only
     int split3_fc2_split = 2;         // THMR_SPLIT3_FC2_SPLIT=1: fc2 of the split3 mode unsplit from 16 crops on (A/B only)
     int split3_min_b = 0;             // THMR_SPLIT3_MIN_B=<n>: A/B knob for the smallest batch the split3 mode serves (0 = kSplit3LowMinB)
-    char* split_w = nullptr;
+    char* split_w = nullptr;          // split3 weight copies: shared, reference-counted, among the engines of one weight arena (split_share())
+    bool split_w_counted = false;     // this engine holds a reference in split_share()
     char* split_act = nullptr;
     // persistent split3 GEMM (csrc/gemm_split_persist.hip; bit-identical to the one-workgroup-per-tile kernel, so purely a matter of time):
     // hand-over slabs + flags, allocated with the split3 weights on a 256-CU device.  s3_persist: 0 off / 1 on (THMR_SPLIT3_PERSIST);
@@ -459,7 +461,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
     float* x = e->S(e->so.x);
     float* h = e->S(e->so.h);
     float* big = e->S(e->so.big);
-    const bool s3_on = e->vit_gemm_mode == 1 && B >= (e->split3_min_b > 0 ? e->split3_min_b : kSplit3LowMinB) && e->split_w;
+    const bool s3_on = e->vit_gemm_mode == 1 && B >= (e->split3_min_b > 0 ? e->split3_min_b : kSplit3LowMinB) && e->split_w && e->split_act;
     {   // patch embed: crop + pad + im2col, then GEMM (+bias, +pos_embed)   vit.py:341,170-176,327
         ProfScope ps(e, st, THMR_PROF_PATCH, 2.0 * M * 768.0 * DIM,
                      4.0 * (B * 3.0 * 256 * 192 + (double)M * DIM + 768.0 * DIM));
@@ -1018,46 +1020,80 @@ int write_arena_constants(thmr_engine* e, hipStream_t st) {
 // The persistent kernels need ALL their workgroups resident at once: the decoder kernel has a grid barrier and, from 49 crops on, asks
 // for every CU; the persistent split3 GEMM's consumers wait for slabs their producers publish, one 147 KB workgroup per CU.  Two such
 // launches issued concurrently by two engines on two streams could each grab part of the chip and wait for the rest until the bounded
-// waits run out.  So when a process has more than one engine on a device, those launches are chained through one event per device:
-// each waits for the previous one (of any engine) to finish.  One engine (the normal case) never touches the event, and a capturing
-// stream does not either (an event from outside a capture cannot be waited on).  (Engines of the shipped and of the experiments
+// waits run out.  So when a process has more than one engine on a device, their forward-type calls are chained through one event per
+// device (struct Turn below: one wait + one record per CALL since round 6, not per launch): each call waits for the previous one (of any
+// engine) to finish.  One engine (the normal case) never touches the event, and a capturing stream does not either (an event from outside
+// a capture cannot be waited on).  ANOTHER PROCESS on the same GPU is outside this protection: see THMR_CFG_NO_PERSISTENT (header).  (Engines of the shipped and of the experiments
 // library in one process each have their own copy of this object: do not run them concurrently on one device — tests do not.)
 struct DecoderTurnstile {
     std::mutex mu;
     std::map<int, int> engines;          // device -> live engines
-    std::map<int, hipEvent_t> last;      // device -> event recorded after the most recent persistent launch
+    std::map<int, hipEvent_t> last;      // device -> event recorded at the end of the most recent forward-type call of any engine
 };
 DecoderTurnstile& turnstile() {
     static DecoderTurnstile t;
     return t;
 }
 
-template <class Launch>
-int launch_serialised(thmr_engine* e, hipStream_t st, Launch&& launch) {
-    DecoderTurnstile& t = turnstile();
-    std::unique_lock<std::mutex> lk(t.mu);
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (t.engines[e->cfg.device] <= 1 || hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-        lk.unlock();
-        return launch();
+// One TURN per forward-type call (round 6, ADVICE r5: round 5 took the mutex and waited / recorded the event around EVERY persistent launch,
+// 33 and more per forward).  With more than one engine of this library on the device and no capture in progress, the call's stream first
+// waits for the event the previous call (of any engine) recorded at its end, and records it again at its own end; the mutex is held for the
+// host-side enqueue of the whole call (~0.3 ms), so two threads cannot both wait on the same earlier record and then overlap.  Whole
+// forwards of different engines therefore run one after the other on the device — which is what kernels that need all 256 CUs resident
+// amount to anyway.  One engine per device (the normal case): no lock held, no event touched.
+struct Turn {
+    std::unique_lock<std::mutex> lk;
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    int rc = 0;
+    Turn(thmr_engine* e, hipStream_t s) : lk(turnstile().mu), st(s) {
+        DecoderTurnstile& t = turnstile();
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (t.engines[e->cfg.device] <= 1 || hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            lk.unlock();
+            return;
+        }
+        auto it = t.last.find(e->cfg.device);
+        if (it == t.last.end()) {
+            hipEvent_t nev;
+            if (hipEventCreateWithFlags(&nev, hipEventDisableTiming) != hipSuccess) { rc = -2; lk.unlock(); return; }
+            it = t.last.emplace(e->cfg.device, nev).first;
+        } else if (hipStreamWaitEvent(st, it->second, 0) != hipSuccess) { rc = -2; lk.unlock(); return; }
+        ev = it->second;
     }
-    auto it = t.last.find(e->cfg.device);
-    if (it == t.last.end()) {
-        hipEvent_t ev;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return -2;
-        it = t.last.emplace(e->cfg.device, ev).first;
-    } else if (hipStreamWaitEvent(st, it->second, 0) != hipSuccess) return -2;
-    const int r = launch();
-    if (hipEventRecord(it->second, st) != hipSuccess) return -2;
-    return r;
-}
+    // records the end of the turn; returns -2 if the record failed (the launches themselves were fine)
+    int end() {
+        int r = 0;
+        if (ev) {
+            if (hipEventRecord(ev, st) != hipSuccess) r = -2;
+            ev = nullptr;
+        }
+        if (lk.owns_lock()) lk.unlock();
+        return r;
+    }
+    ~Turn() { (void)end(); }
+};
 
 int launch_decoder_serialised(thmr_engine* e, const DecParams& d, hipStream_t st) {
-    return launch_serialised(e, st, [&] { return launch_decoder_fused(d, st); });
+    (void)e;
+    return launch_decoder_fused(d, st);                // the caller's Turn (thmr_forward / thmr_head_forward) orders engines
 }
 
 int launch_split3_persist_serialised(thmr_engine* e, const GemmArgs& a, int epi, int mode, hipStream_t st) {
-    return launch_serialised(e, st, [&] { return launch_gemm_split3_persist(a, epi, mode, e->s3_ws, st); });
+    return launch_gemm_split3_persist(a, epi, mode, e->s3_ws, st);
+}
+
+// split3 weight copies are a pure function of the weight arena's contents: engines that SHARE an arena (thmr_create with the same
+// weight_arena_dev, e.g. several engines of one process on one GPU) share ONE copy, reference-counted (round 6, ADVICE r5: eight engines on
+// one device held 30 GB of duplicates).  Every finalize still runs the conversion into it — idempotent, the same bytes.
+struct SplitShare {
+    std::mutex mu;
+    struct Ent { char* p; size_t bytes; int refs; };
+    std::map<std::pair<int, const void*>, Ent> m;
+};
+SplitShare& split_share() {
+    static SplitShare s;
+    return s;
 }
 
 // The persistent decoder kernel's bounded grid barrier timed out in an earlier call (its workgroups were not resident together:
@@ -1157,6 +1193,29 @@ static int validate_cfg(const thmr_config* cfg) {
     if (cfg->vit_depth < 1 || cfg->vit_depth > 64 || cfg->dec_depth < 1 || cfg->dec_depth > 6 || cfg->max_batch < 1 ||
         cfg->max_batch > 4096)
         return fail(nullptr, THMR_ERR_INVALID, "config out of range (vit_depth 1..64, dec_depth 1..6, max_batch 1..4096)");
+    if ((cfg->flags & ~(THMR_CFG_VIT_GEMM_F32 | THMR_CFG_NO_PERSISTENT)) != 0 || cfg->reserved[0] != 0 || cfg->reserved[1] != 0)
+        return fail(nullptr, THMR_ERR_INVALID, "unknown config flag / non-zero reserved field");
+    return 0;
+}
+
+// bytes of the engine-owned allocations of the split3 mode (build_split_weights): weight copies, activation operands + fc2's split-K planes
+static size_t split_w_bytes_of(int vit_depth, int dec_depth) {
+    const size_t per_block = (size_t)DIM * (3 * DIM) + (size_t)DIM * DIM + 2 * (size_t)DIM * MLP;      // weights of one block
+    const size_t kv_rows = (size_t)dec_depth * 2 * INNER;                                              // + the decoder's to_kv of all layers
+    return (per_block * vit_depth + kv_rows * DIM + (size_t)DIM * 768) * 6;                            // + the patch-embed matrix
+}
+static size_t split_act_bytes_of(int max_batch) {
+    const size_t M = (size_t)max_batch * TOK;
+    return M * (size_t)(DIM + MLP) * 6 + (size_t)kSplit3Fc2Split * M * DIM * 4;
+}
+
+int thmr_mode_bytes(const thmr_config* cfg, int32_t vit_gemm_mode, size_t* split_weight_bytes, size_t* split_act_bytes, size_t* workspace_bytes) {
+    if (int r = validate_cfg(cfg)) return r;
+    if (vit_gemm_mode != 0 && vit_gemm_mode != 1) return fail(nullptr, THMR_ERR_INVALID, "vit gemm mode must be 0 or 1");
+    const bool on = vit_gemm_mode == 1 && cfg->max_batch >= kSplit3LowMinB;
+    if (split_weight_bytes) *split_weight_bytes = on ? split_w_bytes_of(cfg->vit_depth, cfg->dec_depth) : 0;
+    if (split_act_bytes) *split_act_bytes = on ? split_act_bytes_of(cfg->max_batch) : 0;
+    if (workspace_bytes) *workspace_bytes = on && !(cfg->flags & THMR_CFG_NO_PERSISTENT) ? gemm_split3_persist_ws_bytes() : 0;
     return 0;
 }
 
@@ -1226,6 +1285,12 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* fm = thmr_knob("THMR_SPLIT3_FC1_MODE"); if (fm && fm[0] >= '0' && fm[0] <= '2') e->s3_fc1_mode = fm[0] - '0'; }
     { const char* mk_ = thmr_knob("THMR_SPLIT3_PERSIST_MASK"); if (mk_) e->s3_persist_mask = atoi(mk_); }
     { const char* ms = thmr_knob("THMR_MID_SPLIT"); if (ms && ms[0] && ms[1]) { e->mid_split_force[0] = ms[0] - '0'; e->mid_split_force[1] = ms[1] - '0'; } }
+    if (cfg->flags & THMR_CFG_VIT_GEMM_F32) e->vit_gemm_mode = 0;      // created in the opt-out mode: finalize builds nothing for split3
+    if (cfg->flags & THMR_CFG_NO_PERSISTENT) {                         // no kernel that needs all its workgroups resident at once
+        e->s3_persist = 0;
+        e->legacy_head = true;
+        e->no_persistent = true;
+    }
     { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[cfg->device] += 1; e->counted = true; }
     *out = e;
     return 0;
@@ -1233,10 +1298,22 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
 
 void thmr_destroy(thmr_engine* e) {
     if (!e) return;
-    if (e->counted) { DecoderTurnstile& t = turnstile(); std::lock_guard<std::mutex> lk(t.mu); t.engines[e->cfg.device] -= 1; }
+    if (e->counted) {
+        DecoderTurnstile& t = turnstile();
+        std::lock_guard<std::mutex> lk(t.mu);
+        if (--t.engines[e->cfg.device] <= 0) {              // the device's last engine: its turnstile event goes with it
+            auto it = t.last.find(e->cfg.device);
+            if (it != t.last.end()) { (void)hipEventDestroy(it->second); t.last.erase(it); }
+        }
+    }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->host_err) (void)hipHostFree(e->host_err);
-    if (e->split_w) (void)hipFree(e->split_w);
+    if (e->split_w_counted) {
+        SplitShare& sh = split_share();
+        std::lock_guard<std::mutex> lk(sh.mu);
+        auto it = sh.m.find({e->cfg.device, static_cast<const void*>(e->warena)});
+        if (it != sh.m.end() && --it->second.refs <= 0) { (void)hipFree(it->second.p); sh.m.erase(it); }
+    } else if (e->split_w) (void)hipFree(e->split_w);
     if (e->split_act) (void)hipFree(e->split_act);
     if (e->s3_ws) (void)hipFree(e->s3_ws);
     if (e->own_w && e->warena) (void)hipFree(e->warena);
@@ -1289,15 +1366,32 @@ int thmr_load_smpl(thmr_engine* e, const thmr_smpl_desc* s, void* stream) {
 // split3 copies of the four ViT GEMM weights of every block (6 bytes per weight) + the activation operand buffers, engine-owned
 static int build_split_weights(thmr_engine* e, hipStream_t st) {
     if (e->max_batch < kSplit3LowMinB) return 0;      // no call of this engine can reach the mode (one and two crops run the exact-fp32 kernels)
-    const size_t per_block = (size_t)DIM * (3 * DIM) + (size_t)DIM * DIM + 2 * (size_t)DIM * MLP;      // weights of one block
-    const size_t kv_rows = (size_t)e->dec_depth * 2 * INNER;                                           // + the decoder's to_kv of all layers
-    if (!e->split_w && hipMalloc(reinterpret_cast<void**>(&e->split_w), (per_block * e->vit_depth + kv_rows * DIM + (size_t)DIM * 768) * 6) != hipSuccess)
-        return fail(e, THMR_ERR_NOMEM, "hipMalloc(split3 ViT weights) failed");
-    const size_t M = (size_t)e->max_batch * TOK;
+    const size_t kv_rows = (size_t)e->dec_depth * 2 * INNER;                                           // the decoder's to_kv of all layers
+    if (!e->split_w) {
+        // one copy per (device, weight arena): engines that share an arena share it (split_share())
+        SplitShare& sh = split_share();
+        std::lock_guard<std::mutex> lk(sh.mu);
+        const size_t bytes = split_w_bytes_of(e->vit_depth, e->dec_depth);
+        auto key = std::make_pair(e->cfg.device, static_cast<const void*>(e->warena));
+        auto it = sh.m.find(key);
+        if (it != sh.m.end() && it->second.bytes == bytes) {
+            it->second.refs += 1;
+            e->split_w = it->second.p;
+        } else {
+            if (it != sh.m.end())
+                return fail(e, THMR_ERR_INVALID, "another engine with a different depth holds split3 copies of this weight arena");
+            char* p = nullptr;
+            if (hipMalloc(reinterpret_cast<void**>(&p), bytes) != hipSuccess)
+                return fail(e, THMR_ERR_NOMEM, "hipMalloc(split3 ViT weights) failed");
+            sh.m[key] = SplitShare::Ent{p, bytes, 1};
+            e->split_w = p;
+        }
+        e->split_w_counted = true;
+    }
     // activations: [M][1280] + [M][5120] split3 operands, then the two fp32 partial-sum planes of fc2's split-K ([2][M][1280])
-    if (!e->split_act && hipMalloc(reinterpret_cast<void**>(&e->split_act), M * (size_t)(DIM + MLP) * 6 + (size_t)kSplit3Fc2Split * M * DIM * 4) != hipSuccess)
+    if (!e->split_act && hipMalloc(reinterpret_cast<void**>(&e->split_act), split_act_bytes_of(e->max_batch)) != hipSuccess)
         return fail(e, THMR_ERR_NOMEM, "hipMalloc(split3 activations) failed");
-    if (!e->s3_ws) {
+    if (!e->s3_ws && !e->no_persistent) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, e->cfg.device) == hipSuccess && prop.multiProcessorCount == 256) {
             // the persistent kernel's decomposition is 8 XCDs x 32 CUs; elsewhere the per-tile kernel stays in charge (same results)
@@ -1444,11 +1538,11 @@ int thmr_finalize_weights(thmr_engine* e, int32_t assume_all_loaded, void* strea
             h.res_w[b] = e->W(p + "conv2.weight"); h.res_b[b] = e->W(p + "conv2.bias");
         }
     }
-    e->finalized = true;
     if (e->vit_gemm_mode == 1) {                                       // weights were (re)loaded with the split3 mode on
-        if (int r = build_split_weights(e, st)) return r;
+        if (int r = build_split_weights(e, st)) return r;              // (on failure the engine stays un-finalized: no forward can run on half-built operands)
         HIP_OK(hipStreamSynchronize(st));                              // as in thmr_set_vit_gemm: visible to forwards on any stream
     }
+    e->finalized = true;
     return 0;
 }
 
@@ -1577,16 +1671,24 @@ int thmr_debug_decoder_timeline(thmr_engine* e, uint64_t* stamps_host, int32_t m
     return 0;
 }
 
+// a forward-type call = one turn of the per-device turnstile (struct Turn): r = the call's own result, then the turn's end
+static int end_turn(thmr_engine* e, Turn& turn, int r) {
+    const int t = turn.end();
+    if (r) return r;
+    return t ? fail(e, THMR_ERR_HIP, "hipEventRecord failed at the end of the call (per-device engine turnstile)") : 0;
+}
+#define THMR_TURN(turn, e, st)                                                                                         \
+    Turn turn(e, st);                                                                                                  \
+    if (turn.rc) return fail(e, THMR_ERR_HIP, "the per-device engine turnstile could not create / wait for its event")
+
 int thmr_vit_forward(thmr_engine* e, const float* img_dev, int32_t B, float* feats_dev, void* stream) {
     if (int r = check_ready(e, B, static_cast<hipStream_t>(stream))) return r;
     if (!img_dev || !feats_dev) return fail(e, THMR_ERR_INVALID, "null buffer");
-    return vit_forward(e, img_dev, B, feats_dev, static_cast<hipStream_t>(stream));
+    THMR_TURN(turn, e, static_cast<hipStream_t>(stream));
+    return end_turn(e, turn, vit_forward(e, img_dev, B, feats_dev, static_cast<hipStream_t>(stream)));
 }
 
-int thmr_head_forward(thmr_engine* e, const float* ctx_dev, int32_t B, const thmr_outputs* out, void* stream) {
-    if (int r = check_ready(e, B, static_cast<hipStream_t>(stream))) return r;
-    if (!ctx_dev) return fail(e, THMR_ERR_INVALID, "null buffer");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+static int head_forward_call(thmr_engine* e, const float* ctx_dev, int32_t B, const thmr_outputs* out, hipStream_t st) {
     if (int r = head_forward(e, ctx_dev, B, out, st)) return r;
     if (out && (out->pred_vertices || out->pred_keypoints_3d || out->pred_keypoints_2d)) {
         const float* rot = out->rotmat ? out->rotmat : e->S(e->so.rot);
@@ -1597,10 +1699,15 @@ int thmr_head_forward(thmr_engine* e, const float* ctx_dev, int32_t B, const thm
     return 0;
 }
 
-int thmr_forward(thmr_engine* e, const float* img_dev, int32_t B, const thmr_outputs* out, void* stream) {
+int thmr_head_forward(thmr_engine* e, const float* ctx_dev, int32_t B, const thmr_outputs* out, void* stream) {
     if (int r = check_ready(e, B, static_cast<hipStream_t>(stream))) return r;
-    if (!img_dev || !out) return fail(e, THMR_ERR_INVALID, "null buffer");
+    if (!ctx_dev) return fail(e, THMR_ERR_INVALID, "null buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    THMR_TURN(turn, e, st);
+    return end_turn(e, turn, head_forward_call(e, ctx_dev, B, out, st));
+}
+
+static int forward_call(thmr_engine* e, const float* img_dev, int32_t B, const thmr_outputs* out, hipStream_t st) {
     float* ctx = e->S(e->so.h);
     if (int r = vit_forward(e, img_dev, B, nullptr, st)) return r;
     if (out->vit_features)
@@ -1618,6 +1725,14 @@ int thmr_forward(thmr_engine* e, const float* img_dev, int32_t B, const thmr_out
     }
 #endif
     return lbs(e, rot, betas, camt, B, out->pred_vertices, out->pred_keypoints_3d, out->pred_keypoints_2d, st);
+}
+
+int thmr_forward(thmr_engine* e, const float* img_dev, int32_t B, const thmr_outputs* out, void* stream) {
+    if (int r = check_ready(e, B, static_cast<hipStream_t>(stream))) return r;
+    if (!img_dev || !out) return fail(e, THMR_ERR_INVALID, "null buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    THMR_TURN(turn, e, st);
+    return end_turn(e, turn, forward_call(e, img_dev, B, out, st));
 }
 
 int thmr_lbs_forward(thmr_engine* e, const float* rotmat_dev, const float* betas_dev, const float* cam_dev, int32_t B,

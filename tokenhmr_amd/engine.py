@@ -21,9 +21,15 @@ class Engine:
     """One engine per GPU.  The weight arena is a torch uint8 tensor so that
     torch.distributed.broadcast (RCCL) can replicate it across ranks."""
 
-    def __init__(self, cfg: HMRConfig = RELEASE, max_batch: int = 64, device="cuda:0", weight_arena=None, experiments=None):
+    def __init__(self, cfg: HMRConfig = RELEASE, max_batch: int = 64, device="cuda:0", weight_arena=None, experiments=None,
+                 vit_gemm=None, persistent=True):
         """weight_arena: share another engine's (already loaded) packed weights — a second engine on the same GPU then only
-        adds its own scratch arena (finalize it with assume_all_loaded=True)."""
+        adds its own scratch arena and split3 activation operands (finalize it with assume_all_loaded=True); the split3 weight copies are
+        shared too (one per weight arena and process).
+        vit_gemm: None / "split3" = the library's creation default; "f32" = CREATE the engine in the exact-fp32 mode (thmr_config.flags
+        THMR_CFG_VIT_GEMM_F32), so that finalize never builds the 3.8 GB of split3 weight copies an opt-out caller does not want.
+        persistent=False (THMR_CFG_NO_PERSISTENT, or $THMR_SHARED_GPU=1): none of the kernels that need all their workgroups resident at
+        once — for a GPU shared with another PROCESS (header); same results, a few per cent slower."""
         # experiments: None = the shipped library (or THMR_LIB=exp for a whole process); True = the -DTHMR_EXPERIMENTS build, which reads the
         # THMR_* A/B knobs and carries the debug hooks — tests and scripts only; a path = another build of the library (scripts/ab_same_box.py).
         # Each shared object has its OWN per-device turnstile for the persistent kernels (decoder grid barrier, split3 hand-over), so engines
@@ -37,8 +43,17 @@ class Engine:
             raise _cabi.EngineError("tokenhmr_amd runs on a HIP device only (no CPU fallback)")
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device("cuda", idx)
+        import os
+        if vit_gemm not in (None, "f32", "split3"):
+            raise ValueError(f"vit_gemm must be None, 'f32' or 'split3', got {vit_gemm!r}")
+        if os.environ.get("THMR_SHARED_GPU", "") == "1":
+            persistent = False
+        flags = (_cabi.CFG_VIT_GEMM_F32 if vit_gemm == "f32" else 0) | (0 if persistent else _cabi.CFG_NO_PERSISTENT)
+        if flags and self._abi < 5:
+            raise _cabi.EngineError("this build of the library (ABI < 5) has no creation flags")
+        self.persistent = bool(persistent)
         self._ccfg = _cabi.Config(abi_version=self._abi, vit_depth=cfg.vit_depth, dec_depth=cfg.dec_depth,
-                                  max_batch=self.max_batch, device=idx)
+                                  max_batch=self.max_batch, device=idx, flags=flags)
         wb, sb = C.c_size_t(0), C.c_size_t(0)
         self._check(self.lib.thmr_arena_bytes(C.byref(self._ccfg), C.byref(wb), C.byref(sb)))
         self.weight_bytes, self.scratch_bytes = wb.value, sb.value
@@ -266,6 +281,14 @@ class Engine:
 
     def vit_gemm(self):
         return {v: k for k, v in self.VIT_GEMM.items()}[self.lib.thmr_get_vit_gemm(self.h)]
+
+    def mode_bytes(self, mode=None):
+        """Device memory the engine allocates itself, outside its two arenas, in `mode` (default: the current one): dict of the split3
+        weight copies (shared among the engines of one weight arena), the split3 activation operands, the hand-over workspace."""
+        m = self.VIT_GEMM[mode] if mode is not None else self.lib.thmr_get_vit_gemm(self.h)
+        a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self._check(self.lib.thmr_mode_bytes(C.byref(self._ccfg), m, C.byref(a), C.byref(b), C.byref(c)))
+        return {"split_weights": a.value, "split_activations": b.value, "workspace": c.value}
 
     # ------------------------------------------------------------------ profiler
     def prof_enable(self, on=True):

@@ -25,21 +25,23 @@ class _SmplHandle:
 
 
 class TokenHMR:
-    def __init__(self, cfg: HMRConfig = RELEASE, max_batch: int = 64, device="cuda:0", model_cfg=None):
+    def __init__(self, cfg: HMRConfig = RELEASE, max_batch: int = 64, device="cuda:0", model_cfg=None, vit_gemm=None, persistent=True):
         self.hmr_cfg = cfg
         self.cfg = model_cfg if model_cfg is not None else types.SimpleNamespace(**cfg.to_dict())
         self.max_batch = max_batch
         self.device = torch.device(device)
-        self.engine = Engine(cfg, max_batch=max_batch, device=device)
+        self.engine = Engine(cfg, max_batch=max_batch, device=device, vit_gemm=vit_gemm, persistent=persistent)
         self.smpl = _SmplHandle(torch.zeros(13776, 3, dtype=torch.int64))
         self.training = False
         self.return_taps = False
 
     # ---- construction -------------------------------------------------------------------
     @classmethod
-    def from_state(cls, cfg, state, tokenizer, smpl, max_batch=64, device="cuda:0", model_cfg=None):
+    def from_state(cls, cfg, state, tokenizer, smpl, max_batch=64, device="cuda:0", model_cfg=None, vit_gemm=None, persistent=True):
+        """vit_gemm / persistent: creation-time choices of the engine (Engine.__init__): "f32" creates it in the opt-out mode, so that
+        finalize builds no split3 copies at all; persistent=False for a GPU shared with another process."""
         W.validate_state(state, cfg, tokenizer)
-        m = cls(cfg, max_batch=max_batch, device=device, model_cfg=model_cfg)
+        m = cls(cfg, max_batch=max_batch, device=device, model_cfg=model_cfg, vit_gemm=vit_gemm, persistent=persistent)
         m.engine.load_state(state, tokenizer)
         m.engine.load_smpl(smpl)
         m.engine.finalize()
@@ -196,20 +198,27 @@ def _read_yaml_cfg(path, merge=True):
 
 
 def load_tokenhmr(checkpoint_path="", model_cfg="", dataset_dir="", is_train_state=False, is_demo=False,
-                  max_batch=64, device="cuda:0", strict=True, vit_gemm=None):
+                  max_batch=64, device="cuda:0", strict=True, vit_gemm=None, shared_gpu=None):
     """Drop-in for tokenhmr/lib/models/__init__.py:3-26: (model, cfg) from the reference's files.  See read_reference_files
     for what is read and how; `device` is where the engine is built (the reference builds on the CPU and the caller moves the
     module, eval.py:52-54 — an engine cannot be moved, so pass the target here; `.to()` of the same device is a no-op).
     `vit_gemm`: "split3" (the engine's default since round 5 — what bench.py's headline measures: the ViT GEMMs and attention of calls of 3
     crops and more on the bf16 matrix pipe with fp32 operands as three bf16 pieces, fp32 accumulation; fp32-grade) or "f32" (the opt-out:
     exact-fp32 MFMA everywhere, ~0.65x the rate); None reads $THMR_VIT_GEMM, so that an unmodified eval.py can be switched from the shell,
-    and leaves the engine's default alone when that is unset."""
+    and leaves the engine's default alone when that is unset.  The mode is chosen BEFORE the engine is created (round 6): the opt-out never
+    builds or holds the split3 weight copies (3.8 GB at release depth).
+    `shared_gpu=True` (or $THMR_SHARED_GPU=1): another PROCESS uses this GPU too — the engine then runs none of the kernels that need all
+    their workgroups resident at once (persistent decoder, persistent split3 GEMM), which two processes could starve each other on until
+    their bounded waits (~0.5 s) expire; same results, a few per cent slower (header: THMR_CFG_NO_PERSISTENT)."""
     hcfg, state, tok, smpl, cfg = read_reference_files(checkpoint_path, model_cfg, dataset_dir, is_train_state, strict)
     mode = vit_gemm if vit_gemm is not None else os.environ.get("THMR_VIT_GEMM")
     if mode not in (None, "f32", "split3"):
         raise ValueError(f"vit_gemm / $THMR_VIT_GEMM must be 'f32' or 'split3', got {mode!r}")
-    model = TokenHMR.from_state(hcfg, state, tok, smpl, max_batch=max_batch, device=device, model_cfg=cfg)
-    if mode is not None and mode != model.engine.vit_gemm():
+    if shared_gpu is None:
+        shared_gpu = os.environ.get("THMR_SHARED_GPU", "") == "1"
+    model = TokenHMR.from_state(hcfg, state, tok, smpl, max_batch=max_batch, device=device, model_cfg=cfg, vit_gemm=mode,
+                                persistent=not shared_gpu)
+    if mode is not None and mode != model.engine.vit_gemm():      # (only a build without creation flags gets here)
         model.engine.set_vit_gemm(mode)
     return model, cfg
 
