@@ -232,7 +232,7 @@ def test_gemm_split3(built_lib, cuda_dev, shape):
     bound = (a.double().abs() @ w.double().abs().t())                       # |a| . |w|: what a dot product's rounding error scales with
     e32 = ((ops.gemm(da, dw, variant="128x160").cpu().double() - ref64).abs() / bound).max().item()
     outs = {}
-    for variant in ("128x256/w8", "128x256/w4", "128x128/w4", "256x256/w4"):
+    for variant in ("128x256/w8", "128x256/w4", "128x128/w4", "128x128/w8", "128x128/w4/s3", "256x256/w4"):
         o = ops.gemm_split3(sa, sw, variant=variant)
         es = ((o.cpu().double() - ref64).abs() / bound).max().item()
         assert es <= max(2.0 * e32, 2.0 ** -22), (variant, es, e32)
@@ -244,6 +244,12 @@ def test_gemm_split3(built_lib, cuda_dev, shape):
             assert torch.allclose(o.cpu(), ref, atol=2e-4, rtol=1e-5), (variant, epi, (o.cpu() - ref).abs().max())
     # the product kernels (v_mfma_f32_16x16x32_bf16, csrc/gemm_split16.hip): both tiles and the rule give the same bits
     assert torch.equal(outs["128x128/w4"], outs["128x256/w8"]) and torch.equal(ops.gemm_split3(sa, sw, variant="auto"), outs["128x256/w8"])
+    # round 6: the 128 x 128 tile on eight waves of 64 x 32, and on four waves with a three-stage K ring
+    assert torch.equal(outs["128x128/w8"], outs["128x256/w8"]) and torch.equal(outs["128x128/w4/s3"], outs["128x256/w8"])
+    for epi, kw in (("bias_gelu", {}), ("bias_resid", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
+        rr = dr if epi == "bias_resid" else None
+        for v in ("128x128/w8", "128x128/w4/s3"):
+            assert torch.equal(ops.gemm_split3(sa, sw, db, rr, epi=epi, variant=v, **kw), ops.gemm_split3(sa, sw, db, rr, epi=epi, variant="128x256/w8", **kw)), (v, epi)
     # the round-3 / first round-4 kernels on 32x32x16 MFMAs (experiments build): bit-identical among themselves — 64x64 and 64x128 wave
     # tiles, the 256x256 tile, the small-M ring kernel without split-K — and equal to the product kernels to fp32 rounding (another
     # grouping of k inside the MFMA)
@@ -266,7 +272,7 @@ def test_gemm_split3(built_lib, cuda_dev, shape):
             half = ops.gemm_split3(ops.split3(da[:M // 2].contiguous()), sw, db, dr[:M // 2].contiguous(), epi="bias_resid", variant=name)
             assert torch.equal(half, o[:M // 2]), name
     if N % 8 == 0:      # the epilogue's result as the next GEMM's split3 operand: bit-identical to converting the fp32 result
-        for variant in ("128x256/w8", "128x256/w4", "128x128/w4", "256x256/w4", "ring", "old/128x256/w8"):
+        for variant in ("128x256/w8", "128x256/w4", "128x128/w4", "128x128/w8", "128x128/w4/s3", "256x256/w4", "ring", "old/128x256/w8"):
             for epi, kw in (("none", {}), ("bias", {}), ("bias_gelu", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
                 bb = None if epi == "none" else db
                 fused = ops.gemm_split3(sa, sw, bb, epi=epi, variant=variant, out_split=True, **kw)
@@ -353,8 +359,9 @@ def test_gemm_split3_half_tile_tail(built_lib, cuda_dev, shape):
     sa, sw = ops.split3(da), ops.split3(dw)
     base = ops.gemm_split3(sa, sw, variant="128x256/w8")
     for rep in range(2):
-        o = ops.gemm_split3(sa, sw, variant="tail")
-        assert torch.equal(o, base), (rep, int((o != base).sum()), (o - base).abs().max().item())
+        for tail in ("tail", "tail/w8"):               # the half tiles on four waves of 64 x 64 (round 5, the rule's form) / on eight waves of 64 x 32 (round 6)
+            o = ops.gemm_split3(sa, sw, variant=tail)
+            assert torch.equal(o, base), (tail, rep, int((o != base).sum()), (o - base).abs().max().item())
     assert torch.equal(ops.gemm_split3(sa, sw, variant="auto"), base)
     for epi, kw in (("bias", {}), ("bias_gelu", {}), ("bias_resid", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
         rr = dr if epi == "bias_resid" else None

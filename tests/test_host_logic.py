@@ -305,11 +305,17 @@ def test_gemm_k_loops_carry_no_valu_instruction(built_lib, tmp_path):
     # instantiations of the 128 x 256 tile with the GELU and the residual epilogue, and the 128 x 128 tile (the persistent instantiations
     # run the same K tile body; their loop also holds the cold branch that looks up the next tile of the stream)
     for name, sym, min_mfma in (("gemm_f32.o", r"gemm_f32_kernelILi4ELi1ELi1ELi5ELb1ELi2", 160), ("gemm_f32.o", r"gemm_ring_kernelILi4ELi5ELb0", 64),
-                                ("gemm_split16.o", r"gemm_split16_kernelILi4ELi2ELb0ELb0E", 192),
-                                ("gemm_split16.o", r"gemm_split16_kernelILi4ELi4ELb0ELb0E", 192),
-                                ("gemm_split16.o", r"gemm_split16_kernelILi2ELi0ELb0ELb0E", 192),
+                                # template <WN, NI, EPI, PERSIST, ABLK, NST>
+                                ("gemm_split16.o", r"gemm_split16_kernelILi4ELi4ELi2ELb0ELb0ELi2E", 192),
+                                ("gemm_split16.o", r"gemm_split16_kernelILi4ELi4ELi4ELb0ELb0ELi2E", 192),
+                                ("gemm_split16.o", r"gemm_split16_kernelILi2ELi4ELi0ELb0ELb0ELi2E", 192),
+                                # round 6: the 128 x 128 tile with a three-stage K ring (six K tiles per loop trip), GELU / raw partial sums
+                                ("gemm_split16.o", r"gemm_split16_kernelILi2ELi4ELi2ELb0ELb0ELi3E", 576),
+                                ("gemm_split16.o", r"gemm_split16_kernelILi2ELi4ELi0ELb0ELb0ELi3E", 576),
+                                # ... and on eight waves of 64 x 32 (48 MFMAs per K tile and wave)
+                                ("gemm_split16.o", r"gemm_split16_kernelILi4ELi2ELi0ELb0ELb0ELi2E", 96),
                                 # round 5: the mixed grid (8-wave body on wide tiles, 4-wave body on the half tiles of the last round): fc1's instantiation
-                                ("gemm_split16.o", r"gemm_split16_tail_kernelILi2ELb0E", 192)):
+                                ("gemm_split16.o", r"gemm_split16_tail_kernelILi2ELb0ELb0E", 192)):
         seg = k_loop(name, sym, min_mfma)
         valu = [op for _, op, _ in seg if op.startswith("v_") and not op.startswith("v_mfma")]
         dma = [(op, args) for _, op, args in seg if op.startswith("global_load_lds")]

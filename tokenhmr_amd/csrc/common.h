@@ -72,6 +72,10 @@ struct GemmArgs {
     //           fp32 tile: 7.5 of the 9.9 us fc1's epilogue costs per tile, profiles/r4e_split3_gemm_b64.jsonl); here 32 lanes write 512
     //           contiguous bytes.  Used for the one operand that only GEMM kernels touch: fc1's GELU output = fc2's A (vit.py:84-87).
     int a_blk, cs_blk;
+    // split3 GEMM, A/B only (experiments build: the engine sets it from THMR_SPLIT3_NARROW8=1 / THMR_SPLIT3_TAIL8=1 at thmr_create): bit 0 = the
+    // 128 x 128 tile on eight waves of 64 x 32 instead of four of 64 x 64, bit 1 = the half-tile tail likewise (round 6: measured slower /
+    // equal, gemm_split.hip); bit 2 = the 128 x 128 tile with round 5's TWO-stage K ring instead of three stages (THMR_SPLIT3_RING3=0).  Same bits either way.
+    int tile_opts;
 };
 
 // byte offset of chunk (row m, k-group n8, piece pc) of a split3 operand with row length ld (fp32-equivalents), row-major or row-blocked
@@ -382,10 +386,10 @@ int gemm_split3_persist_bind_host_err(void* ws, unsigned* const* host_err_slot, 
 void* gemm_split3_persist_op_ws(hipStream_t s);        // zeroed workspace per (device, stream) for the stateless operators
 // gemm_split16.hip: the split3 GEMM on v_mfma_f32_16x16x32_bf16 (what launch_gemm_split3 / _splitk / _persist run since round 4):
 // one workgroup per tile (wide = 128 x 256 on 8 waves, else 128 x 128 on 4; a.ksplit copies of the grid) or 256 persistent workgroups
-int launch_split16_tiles(const GemmArgs& a, int epi, bool wide, hipStream_t s);
+int launch_split16_tiles(const GemmArgs& a, int epi, int shape, hipStream_t s);      // shape 0: 128 x 256 / 8 waves, 1: 128 x 128 / 4 waves, 2: 128 x 128 / 8 waves
 int launch_split16_persist(const GemmArgs& a, int epi, void* ws, hipStream_t s);
 // the wide grid with its ragged last round as 128 x 128 half tiles; 0 launched, 1 = does not apply to this shape (nothing launched), < 0 error
-int launch_split16_tiles_tail(const GemmArgs& a, int epi, int cus, hipStream_t s);
+int launch_split16_tiles_tail(const GemmArgs& a, int epi, int cus, bool tail8, hipStream_t s);
 // small-M split3 GEMM (64x64 tiles, LDS-DMA ring, optional split-K into part[ksplit][M][N] without epilogue)
 int launch_gemm_split3_ring(const GemmArgs& a, int epi, int ksplit, float* part, hipStream_t s);
 // LayerNorm (D = 1280) whose result is written as a split3 operand [rows][D/8][3][8] instead of fp32 (same arithmetic as launch_layernorm)

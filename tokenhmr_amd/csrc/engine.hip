@@ -120,6 +120,7 @@ struct thmr_engine {
     int vit_gemm_mode = 1;
     bool split3_small = false;        // THMR_SPLIT3_SMALL=1: the split3 mode also serves up to six crops (ring kernel on split3 operands) — measured SLOWER, A/B only
     int split3_fc2_split = 2;         // THMR_SPLIT3_FC2_SPLIT=1: fc2 of the split3 mode unsplit from 16 crops on (A/B only)
+    int s3_tile_opts = 0;             // GemmArgs::tile_opts of the split3 GEMMs (THMR_SPLIT3_NARROW8=1 -> 1, THMR_SPLIT3_TAIL8=1 -> 2; A/B only)
     int split3_min_b = 0;             // THMR_SPLIT3_MIN_B=<n>: A/B knob for the smallest batch the split3 mode serves (0 = kSplit3LowMinB)
     char* split_w = nullptr;          // split3 weight copies: shared, reference-counted, among the engines of one weight arena (split_share())
     bool split_w_counted = false;     // this engine holds a reference in split_share()
@@ -471,6 +472,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             char* ims = e->split_act + (size_t)M * DIM * 6;
             LAUNCH_OK(launch_im2col_patch_split3(img, ims, B, st));
             GemmArgs a = mk(reinterpret_cast<const float*>(ims), 768, reinterpret_cast<const float*>(e->pe_s), 768, e->hot.pe_b, e->hot.pos, 0, x, DIM, M, DIM, 768);
+            a.tile_opts = e->s3_tile_opts;
             LAUNCH_OK(launch_gemm_split3(a, EPI_BIAS_POS, -1, st));
         } else {
             LAUNCH_OK(launch_im2col_patch(img, big, B, st));
@@ -560,6 +562,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             GemmArgs a = mk(reinterpret_cast<const float*>(A), K, reinterpret_cast<const float*>(Wt), K, bias, resid, N, C, N, M, N, K);
             a.qscale = qscale; a.qcols = DIM;
             a.a_blk = a_blk;
+            a.tile_opts = e->s3_tile_opts;
             const int bit = cls == THMR_PROF_GEMM_QKV ? 1 : cls == THMR_PROF_GEMM_PROJ ? 2 : cls == THMR_PROF_GEMM_FC2 ? 8 : 0;
             if (e->s3_ws && e->s3_persist && (e->s3_persist_mask & bit) && gemm_split3_persist_ok(a)) return launch_split3_persist_serialised(e, a, epi, 0, st);
             return launch_gemm_split3(a, epi, -1, st);
@@ -582,6 +585,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 {
                     ProfScope ps(e, st, THMR_PROF_GEMM_PROJ, 2.0 * M * DIM * (double)DIM, 6.0 * ((double)M * DIM + (double)DIM * DIM) + 4.0 * s3_split * M * DIM);
                     GemmArgs a = mk(reinterpret_cast<const float*>(hs), DIM, reinterpret_cast<const float*>(ws.proj), DIM, nullptr, nullptr, 0, x, DIM, M, DIM, DIM);
+                    a.tile_opts = e->s3_tile_opts;
                     LAUNCH_OK(launch_gemm_split3_splitk(a, s3_split, part, st));
                 }
                 ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (s3_split + 2.0) * M * DIM + 6.0 * M * DIM);
@@ -596,6 +600,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 GemmArgs a = mk(reinterpret_cast<const float*>(hs), DIM, reinterpret_cast<const float*>(ws.fc1), DIM, w.f1b, nullptr, 0, nullptr, 0, M, MLP, DIM);
                 a.c_split = bs; a.ldcs = MLP;
                 a.cs_blk = bs_blk;
+                a.tile_opts = e->s3_tile_opts;
                 if (e->s3_ws && e->s3_persist && e->s3_fc1_mode && (e->s3_persist_mask & 4) && gemm_split3_persist_ok(a))
                     LAUNCH_OK(launch_split3_persist_serialised(e, a, EPI_BIAS_GELU, 2, st));
                 else
@@ -606,6 +611,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                     ProfScope ps(e, st, THMR_PROF_GEMM_FC2, 2.0 * M * DIM * (double)MLP, 6.0 * ((double)M * MLP + (double)DIM * MLP) + 4.0 * s3_fc2 * M * DIM);
                     GemmArgs a = mk(reinterpret_cast<const float*>(bs), MLP, reinterpret_cast<const float*>(ws.fc2), MLP, nullptr, nullptr, 0, x, DIM, M, DIM, MLP);
                     a.a_blk = bs_blk;
+                    a.tile_opts = e->s3_tile_opts;
                     LAUNCH_OK(launch_gemm_split3_splitk(a, s3_fc2, part2, st));
                 }
                 ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (s3_fc2 + 3.0) * M * DIM);
@@ -812,6 +818,7 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
             // on the bf16 matrix pipe (1.5 -> 1.0 ms at 64 crops)
             LAUNCH_OK(launch_split3(ctx, DIM, e->split_act, DIM, M, DIM, st));
             GemmArgs a = mk(reinterpret_cast<const float*>(e->split_act), DIM, reinterpret_cast<const float*>(e->kv_s), DIM, nullptr, nullptr, 0, big, ldkv, M, ldkv, DIM);
+            a.tile_opts = e->s3_tile_opts;
             if (e->s3_ws && e->s3_persist && (e->s3_persist_mask & 16) && gemm_split3_persist_ok(a)) LAUNCH_OK(launch_split3_persist_serialised(e, a, EPI_NONE, 0, st));
             else LAUNCH_OK(launch_gemm_split3(a, EPI_NONE, -1, st));
         } else {
@@ -1281,6 +1288,9 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* ss = thmr_knob("THMR_SPLIT3_SMALL"); e->split3_small = ss && ss[0] == '1'; }
     { const char* fs = thmr_knob("THMR_SPLIT3_FC2_SPLIT"); e->split3_fc2_split = (fs && fs[0] == '1') ? 1 : kSplit3Fc2Split; }
     { const char* sm = thmr_knob("THMR_SPLIT3_MIN_B"); e->split3_min_b = sm ? atoi(sm) : 0; }
+    { const char* n8 = thmr_knob("THMR_SPLIT3_NARROW8"); if (n8 && n8[0] == '1') e->s3_tile_opts |= 1; }
+    { const char* t8 = thmr_knob("THMR_SPLIT3_TAIL8"); if (t8 && t8[0] == '1') e->s3_tile_opts |= 2; }
+    { const char* r3 = thmr_knob("THMR_SPLIT3_RING3"); if (r3 && r3[0] == '0') e->s3_tile_opts |= 4; }
     { const char* sp = thmr_knob("THMR_SPLIT3_PERSIST"); if (sp && sp[0] >= '0' && sp[0] <= '1') e->s3_persist = sp[0] - '0'; }
     { const char* fm = thmr_knob("THMR_SPLIT3_FC1_MODE"); if (fm && fm[0] >= '0' && fm[0] <= '2') e->s3_fc1_mode = fm[0] - '0'; }
     { const char* mk_ = thmr_knob("THMR_SPLIT3_PERSIST_MASK"); if (mk_) e->s3_persist_mask = atoi(mk_); }
@@ -1849,7 +1859,7 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: epilogue must be 0, 1, 2, 4, 5 or 6");
     if (epi != EPI_NONE && !bias) return fail(e, THMR_ERR_INVALID, "epilogue needs bias");
     if ((epi == EPI_BIAS_RESID || epi == EPI_BIAS_POS) && !resid) return fail(e, THMR_ERR_INVALID, "epilogue needs resid");
-    if (epi == EPI_BIAS_POS && ((N % 4) != 0 || (variant != -1 && variant != 0 && variant != 2))) return fail(e, THMR_ERR_INVALID, "split3 GEMM: the pos-embed epilogue needs N % 4 == 0 and a per-tile variant (-1, 0, 2)");
+    if (epi == EPI_BIAS_POS && ((N % 4) != 0 || (variant != -1 && variant != 0 && variant != 2 && variant != 6 && variant != 8))) return fail(e, THMR_ERR_INVALID, "split3 GEMM: the pos-embed epilogue needs N % 4 == 0 and a per-tile variant (-1, 0, 2, 6, 8)");
     if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || ldc < N)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: K % 32 == 0, lda / ldw multiples of 8 and >= K, ldc >= N");
     // + 1000: A is a ROW-BLOCKED split3 operand ([M / 32][K / 8][3][32][8], rows padded to 32; GemmArgs::a_blk) — tiles 0 / 2, split-K 202 / 204
@@ -1858,12 +1868,12 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
     if (variant >= 1000) {
         a_blk = 1;
         variant -= 1000;
-        if ((variant != 0 && variant != 2 && variant != 202 && variant != 204 && variant != 300) || (epi != EPI_NONE && epi != EPI_BIAS_RESID))
-            return fail(e, THMR_ERR_INVALID, "split3 GEMM with a row-blocked A: variants 1000, 1002, 1202, 1204, 1300 and epilogues 0 / 4 only");
+        if ((variant != 0 && variant != 2 && variant != 6 && variant != 8 && variant != 202 && variant != 204 && variant != 300) || (epi != EPI_NONE && epi != EPI_BIAS_RESID))
+            return fail(e, THMR_ERR_INVALID, "split3 GEMM with a row-blocked A: variants 1000, 1002, 1006, 1008, 1202, 1204, 1300 and epilogues 0 / 4 only");
     }
-    if (!(variant >= -1 && variant <= 5) && variant != 31 && variant != 32 && variant != 34 && variant != 37 && !(variant >= 100 && variant <= 102) &&
+    if (!(variant >= -1 && variant <= 8) && variant != 31 && variant != 32 && variant != 34 && variant != 37 && !(variant >= 100 && variant <= 102) &&
         variant != 202 && variant != 204 && variant != 300 && variant != 20 && variant != 22 && variant != 310)
-        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 2, 5 (half-tile tail), 202, 204, 300; experiments build: 1, 4, 20, 22, 100-102, 310 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
+        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 2, 6 (128 x 128 on 8 waves), 8 (128 x 128, three-stage ring), 5 / 7 (half-tile tail on 4 / 8 waves), 202, 204, 300; experiments build: 1, 4, 20, 22, 100-102, 310 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, resid, ldc, C, ldc, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
     a.a_blk = a_blk;
@@ -1928,7 +1938,7 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
         return 0;
     }
 #else
-    if (variant >= 100 || variant == 1 || variant == 3 || variant == 4 || variant > 5)
+    if (variant >= 100 || variant == 1 || variant == 3 || variant == 4 || variant > 8)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: this variant exists only in the experiments build (libtokenhmr_hip_exp.so)");
 #endif
     LAUNCH_OK(launch_gemm_split3(a, epi, variant, st));
@@ -1951,8 +1961,8 @@ int thmr_op_gemm_split3_out_split3(const void* A, int64_t lda, const void* W, in
         cs_blk = 1;
         variant -= 1000;
     }
-    if ((variant < -1 || variant > 2) && variant != 4 && variant != 5 && variant != 100 && variant != 20 && variant != 22 && variant != 302 && variant != 311 && variant != 312)
-        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 2, 302 (persistent workgroups); experiments build: 1, 4, 20, 22, 100 (ring kernel), 311 / 312 (32x32x16 persistent kernel: LDS / swapped-role epilogue)");
+    if ((variant < -1 || variant > 2) && variant != 4 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 100 && variant != 20 && variant != 22 && variant != 302 && variant != 311 && variant != 312)
+        return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 2, 6, 5 / 7 (half-tile tail), 302 (persistent workgroups); experiments build: 1, 4, 20, 22, 100 (ring kernel), 311 / 312 (32x32x16 persistent kernel: LDS / swapped-role epilogue)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, nullptr, 0, nullptr, 0, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
     a.c_split = Cs; a.ldcs = ldcs;

@@ -630,7 +630,8 @@ int launch_layernorm_split3(const float* x, const float* g, const float* b, void
 static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStream_t s);
 
 // a.A / a.W point at split3 operands (lda / ldw = their row strides in fp32-equivalents, i.e. 6 lda bytes); C, bias, resid are fp32.
-// variant: -1 = rule below   0 = 8 waves of 64x64 on 128x256   1 = 4 waves of 64x128 on 128x256   2 = 4 waves of 64x64 on 128x128
+// variant: -1 = rule below   0 = 8 waves of 64x64 on 128x256   2 = 4 waves of 64x64 on 128x128   6 = 8 waves of 64x32 on 128x128   8 = 4 waves on 128x128, three-stage K ring   5 / 7 = 128x256 with the
+// ragged last round as half tiles on 4 / 8 waves   (experiments build: 1 = 4 waves of 64x128 on 128x256, ...)
 int launch_gemm_split3(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % SBK) != 0 || (a.lda % 8) != 0 || (a.ldw % 8) != 0) return -1;
     if (a.lda * 6 * 256 >= (int64_t(1) << 32) || a.ldw * 6 * 256 >= (int64_t(1) << 32)) return -1;     // 32-bit lane offsets within a tile
@@ -680,26 +681,41 @@ static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStrea
         // 707 at 48: a partly filled last round of big tiles costs less than a full round (profiles/r3ae_split3_tile_rule_ab.log)
         const long ks = a.ksplit > 1 ? a.ksplit : 1;
         const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * ks;
-        variant = t128 <= 256 ? 2 : 0;
+        // round 6: the 128 x 128 tile on EIGHT waves of 64 x 32 (variant 6; gemm_split16.hip) was built to put two waves on every SIMD where
+        // that tile is what runs (few crops) and measured SLOWER than the four-wave form, same box, interleaved, whole path
+        // (profiles/r6d_ab_narrow8_*): +5.9 % per call at 4 crops (fc2 +0.19 ms, fc1 +0.14, qkv +0.12 of 8.1), +3.7 % at 8 (fc2 +0.42), +2.9 % at 3,
+        // +3.2 % at 5, +0.6 % at 16.  The few-crop K loop is not short of waves: it waits for its LDS-DMA copies (one 48 KB stage in flight per
+        // CU against a 1.5 us loaded round trip = the 1.55 us per K tile measured), and eight waves add barrier cost without adding bytes
+        // in flight.  Kept as variant 6 / THMR_SPLIT3_NARROW8=1 (bit-identical, tested).
+        static const bool narrow8 = [] { const char* e = thmr_knob("THMR_SPLIT3_NARROW8"); return e && e[0] == '1'; }();
+        // round 6: the four-wave 128 x 128 tile with a THREE-stage K ring (variant 8: two stages of copies in flight per CU)
+        static const int ring3 = [] { const char* e = thmr_knob("THMR_SPLIT3_RING3"); return e ? atoi(e) : -1; }();
+        const bool r3 = ring3 >= 0 ? ring3 != 0 : !(a.tile_opts & 4);
+        variant = t128 <= 256 ? ((narrow8 || (a.tile_opts & 1)) ? 6 : r3 ? 8 : 2) : 0;
         by_rule = true;
     }
-    if ((by_rule && variant == 0) || variant == 5) {
+    if ((by_rule && variant == 0) || variant == 5 || variant == 7) {
         // round 5: the 128 x 256 grid with its ragged last round as 128 x 128 half tiles, where that applies (fc1 of a 64-crop batch: 1920
         // tiles = 7.5 rounds of 256 CUs; gemm_split16.hip gemm_split16_tail_kernel).  Bit-identical to the plain grid.  THMR_SPLIT3_TAIL=0
         // (experiments build) switches it off for the A/B; variant 5 asks for it explicitly and fails if the shape does not qualify.
         static const bool tail_off = [] { const char* e = thmr_knob("THMR_SPLIT3_TAIL"); return e && e[0] == '0'; }();
-        if (variant == 5 || !tail_off) {
-            const int r = launch_split16_tiles_tail(a, epi, device_cus(), s);
+        // round 6: the half tiles on all eight waves (64 x 32 wave tiles) instead of four = variant 7 / THMR_SPLIT3_TAIL8=1: measured equal
+        // (fc1 +0.09 ms of 22.1 per 64-crop step, whole step +0.1 %: profiles/r6d_ab_narrow8_or_tail8_b64.json); round 5's form stays
+        static const bool tail8 = [] { const char* e = thmr_knob("THMR_SPLIT3_TAIL8"); return e && e[0] == '1'; }();
+        if (variant == 5 || variant == 7 || !tail_off) {
+            const int r = launch_split16_tiles_tail(a, epi, device_cus(), variant == 7 ? true : (tail8 || (a.tile_opts & 2)), s);
             if (r <= 0) return r;                 // launched, or failed
-            if (variant == 5) return -1;          // does not apply to this shape
+            if (variant == 5 || variant == 7) return -1;          // does not apply to this shape
         }
-        if (variant == 5) return -1;
+        if (variant == 5 || variant == 7) return -1;
     }
     switch (variant) {
         // round 4: the product kernels multiply on v_mfma_f32_16x16x32_bf16 (gemm_split16.hip); the 32x32x16 kernels of this file are the
         // experiments build's variants 20 / 22 (and 1, 4, 3x below) — another grouping of k inside the MFMA, so equal to rounding only
-        case 0: return launch_split16_tiles(a, epi, true, s);
-        case 2: return launch_split16_tiles(a, epi, false, s);
+        case 0: return launch_split16_tiles(a, epi, 0, s);
+        case 2: return launch_split16_tiles(a, epi, 1, s);
+        case 6: return launch_split16_tiles(a, epi, 2, s);
+        case 8: return launch_split16_tiles(a, epi, 3, s);
 #ifdef THMR_EXPERIMENTS
         case 20: return launch_split3_cfg<2, 4, 2, 2>(a, epi, s);
         case 22: return launch_split3_cfg<2, 2, 2, 2>(a, epi, s);

@@ -8,7 +8,7 @@
 // flops per joule — and on random operand bits the part SUSTAINS 2.09-2.12 PFLOP/s with 16x16x32 against 1.83 with 32x32x16 (register
 // operands), 1.81 against 1.67 with this kernel's 24 fragment reads and 9 LDS-DMA copies per K tile beside them.
 //
-// Wave tile 64 x 64 = 4 x 4 MFMA tiles of 16 x 16; one MFMA consumes a whole 32-deep K tile: lane (l & 15, g = l >> 4) of an operand
+// Wave tile 64 x 64 = 4 x 4 MFMA tiles of 16 x 16 (NI = 4; NI = 2: 64 x 32, the 128 x 128 tile on eight waves — round 6, below); one MFMA consumes a whole 32-deep K tile: lane (l & 15, g = l >> 4) of an operand
 // fragment holds the 16-byte chunk of row l & 15, k-group g — exactly one chunk of the split3 format.  Operand ROLES are swapped for every
 // product (the MFMA's "A" is the weight fragment): an accumulator then holds, per lane, 4 CONSECUTIVE output columns n = 4 g ... 4 g + 3 of
 // output row m = l & 15 — one 16-byte store per accumulator for an fp32 result (a 16-byte load for the residual, the bias), and for a
@@ -114,30 +114,49 @@ __device__ __forceinline__ f32x4 epi4(const GemmArgs& a, f32x4 v, f32x4 b, int m
 // SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE, 8 instead of 4 LDS cycles per read, profiles/r4ah_pmc_lds.json.)
 __device__ __forceinline__ constexpr int rot16(int row) { return ((row >> 2) & 1) * 2; }
 
-template <int WN>
-constexpr int split16_lds_bytes() { return 2 * (QBM * ROWB + WN * 64 * ROWB); }      // two stages of (A tile + W tile): 147,456 / 98,304 bytes
+template <int WN, int NI = 4, int NST = 2>
+constexpr int split16_lds_bytes() { return NST * (QBM * ROWB + WN * NI * 16 * ROWB); }    // NST stages of (A tile + W tile): 147,456 / 98,304 bytes at two, 147,456 for three 128 x 128 stages
 
 // The kernel body (one workgroup of 2 WN waves; `smem` = its split16_lds_bytes<WN>() of LDS).  given_tile / half: -1 / -1 = the tile comes
 // from the block index (the plain kernels below); the tail kernel passes the tile — and, for its 128 x 128 half tiles, which half of the
 // 128 x 256 tile `given_tile` of the WIDE grid (tiles_n = that grid's) this workgroup computes.
-template <int WN, int EPI, bool PERSIST, bool ABLK>
+// NI = 16-column MFMA tiles per wave along N.  (WN, NI) = (4, 4): 128 x 256 on 8 waves; (2, 4): 128 x 128 on 4 waves; (4, 2): 128 x 128 on
+// EIGHT waves of 64 x 32 (round 6: 18 fragment reads per 48 MFMAs and wave; bit-identical, same K order per element).  Built on the
+// hypothesis that the four-wave form (one wave per SIMD, matrix pipe ~45 % busy at few crops: fc1 at 4 crops = 240 workgroups x 40 K tiles
+// in 62 us = 1.55 us per K tile against 0.7 us of MFMA issue, profiles/r6a_class_profile_small_batches.log) lacks a second wave per SIMD.
+// Measured, it does not: the eight-wave form is 3-6 % SLOWER per call at 3-8 crops and equal as the half-tile tail at 64
+// (profiles/r6d_ab_narrow8_or_tail8_*.json; launch_split3_tiles in gemm_split.hip keeps the four-wave form).  What the few-crop K loop
+// waits for is its LDS-DMA copies — bytes in flight per CU, not waves (see the NST = 3 ring below).
+// NST = LDS stages of the K ring (round 6).  Two (every instantiation up to round 5): the copies of K tile t + 1 are issued during tile t - 1 and
+// waited for at tile t's barrier — ONE stage (48 KB of a 128 x 128 tile pair, 72 KB of a 128 x 256 one) in flight per CU for about one K-tile
+// period.  With many tiles per CU that period is the MFMA time (2.2 us per wide K tile at 64 crops) and the round trip hides under it; at few
+// crops the weights come cold from HBM to 90-240 workgroups, the round trip (~1.5 us loaded) IS the period, and the matrix pipe idles for
+// half of it (1.55 us per 128 x 128 K tile against 0.7 us of MFMA issue at 4 crops).  Three stages (128 x 128 tile only: 3 x 48 KB = 144 KB)
+// put the copies of tile t + 2 in flight as well: tile t's barrier waits with vmcnt(NP) — everything but the newest tile's copies — so a
+// copy has two periods to land.  Fragment registers still alternate between two sets, so the K loop is unrolled by six (stage = t mod 3,
+// set = t mod 2, all LDS offsets immediates).  Same K order per element: bit-identical.
+template <int WN, int NI, int EPI, bool PERSIST, bool ABLK, int NST = 2>
 __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles_n, int nwg, const Ws16& ws, char* smem, int given_tile, int half) {
-    constexpr int NW = 2 * WN, BN = WN * 64;
+    constexpr int NW = 2 * WN, BN = WN * NI * 16;
+    static_assert(NST == 2 || (NST == 3 && !PERSIST), "two stages, or three for the one-workgroup-per-tile decomposition");
+    static_assert(NI == 4 || NI == 2, "wave tile 64 x 64 or 64 x 32");
+    static_assert(!PERSIST || NI == 4, "the persistent decomposition uses the 64 x 64 wave tile");
     constexpr int A_Q = QBM * SLOTS / 64, B_Q = BN * SLOTS / 64;
     static_assert(A_Q % NW == 0 && B_Q % NW == 0, "tile / waves mismatch");
     constexpr int A_P = A_Q / NW, B_P = B_Q / NW, NP = A_P + B_P;      // copies per wave and K tile: 3 + 6 (8 waves), 6 + 6 (4 waves)
     constexpr int A_STAGE = QBM * ROWB, B_STAGE = BN * ROWB;
     constexpr int A_KSTEP = ABLK ? SLOTS * 512 : ROWB;                 // bytes a K tile advances the A source by
-    static_assert(2 * (A_STAGE + B_STAGE) <= 160 * 1024 && 2 * (A_STAGE + B_STAGE) == split16_lds_bytes<WN>(), "LDS");
+    static_assert(NST * (A_STAGE + B_STAGE) <= 160 * 1024 && NST * (A_STAGE + B_STAGE) == split16_lds_bytes<WN, NI, NST>(), "LDS");
+    static_assert((NST - 1) * A_STAGE + 3 * 16 * ROWB < 65536 && (NST - 1) * B_STAGE + (NI - 1) * 16 * ROWB < 65536, "fragment offsets must stay 16-bit immediates");
     static_assert(!PERSIST || WN == 4, "the persistent decomposition uses the 128 x 256 tile");
 
     char* As = smem;
-    char* Bs = smem + 2 * A_STAGE;
+    char* Bs = smem + NST * A_STAGE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * 64;
+    const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * (NI * 16);
     const int l15 = lane & 15, g = lane >> 4;
     const int nk_all = a.K / SBK;
 
@@ -242,7 +261,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
         fow[pc] = lds_addr_b(Bs) + (uint32_t)(wn0 * ROWB) + rowmaj;
         foa[pc] = lds_addr_b(As) + (uint32_t)(wm0 * ROWB) + (ABLK ? (uint32_t)((3 * g + pc) * 512 + l15 * 16) : rowmaj);      // (row-blocked A: wm0 / 32 blocks of 12 x 512 bytes — the same offset)
     }
-    bf16x8 af[4][3], wf[2][4][3];                                      // activation fragments (rolling), weight fragments of this / the next K tile
+    bf16x8 af[4][3], wf[2][NI][3];                                     // activation fragments (rolling), weight fragments of this / the next K tile
     auto read_a = [&](int buf, int mi, int pc) {
         const int off = ABLK ? (mi >> 1) * (SLOTS * 512) + (mi & 1) * 256 : mi * 16 * ROWB;
         af[mi][pc] = *reinterpret_cast<lds_frag_ptr>((uintptr_t)(foa[pc] + (uint32_t)(buf * A_STAGE + off)));
@@ -250,33 +269,39 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     auto read_w = [&](int buf, int set, int ni, int pc) {
         wf[set][ni][pc] = *reinterpret_cast<lds_frag_ptr>((uintptr_t)(fow[pc] + (uint32_t)(buf * B_STAGE + ni * 16 * ROWB)));
     };
-    f32x4 acc[4][4];
+    f32x4 acc[4][NI];
 
     // one K tile out of buffer `buf` (weight fragment set `buf`)
-    constexpr int NRB = 3 + 4;                                         // reads per block 1-3: one activation tile (3 pieces) + 4 weight fragments
+    constexpr int NRB = 3 + NI;                                        // reads per block 1-3: one activation tile (3 pieces) + NI of the 3 NI weight fragments
     constexpr int DB = (NP + 2) / 3;                                   // copies per block 1-3
-    static_assert(NRB + DB <= 24, "block too small for the staging interleave");
-    auto ktile = [&](auto bufc) {
-        constexpr int buf = decltype(bufc){};
+    static_assert(NRB + DB <= NPROD * NI, "block too small for the staging interleave");
+    // wait for every copy of this wave but the newest `keep` tiles' (the compiler does not count LDS-DMA copies: explicit), + its LDS reads; barrier
+    auto ring_wait_barrier = [&](auto keepc) {
+        constexpr int keep = decltype(keepc){};
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(keep * NP) : "memory");
+    };
+    // K tile t out of LDS stage `buf` = t mod NST with weight fragment set `set` = t mod 2: reads tile t + 1 from stage buf + 1, copies tile t + NST into stage buf
+    auto ktile = [&](auto bufc, auto setc) {
+        constexpr int buf = decltype(bufc){}, set = decltype(setc){}, nbuf = (buf + 1) % NST;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
             for (int p = 0; p < NPROD; ++p)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const int idx = p * 4 + ni;
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[buf][ni][piece_w(p)], af[mi][piece_a(p)], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int idx = p * NI + ni;
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[set][ni][piece_w(p)], af[mi][piece_a(p)], acc[mi][ni], 0, 0, 0);
                     bool any = false;
                     if (mi == 0) {
                         if (idx < 3) { read_a(buf, 3, idx); any = true; }                       // this tile's last activation fragment
                     } else {
-                        if (idx < 3) { read_a(buf ^ 1, mi - 1, idx); any = true; }              // next tile: activation tile mi - 1 ...
-                        else if (idx < NRB) {                                                   // ... and 4 of its 12 weight fragments
-                            const int q = (mi - 1) * 4 + (idx - 3);
-                            read_w(buf ^ 1, buf ^ 1, q / 3, q % 3);
+                        if (idx < 3) { read_a(nbuf, mi - 1, idx); any = true; }                 // next tile: activation tile mi - 1 ...
+                        else if (idx < NRB) {                                                   // ... and NI of its 3 NI weight fragments
+                            const int q = (mi - 1) * NI + (idx - 3);
+                            read_w(nbuf, set ^ 1, q / 3, q % 3);
                             any = true;
                         } else if (idx - NRB < DB && (mi - 1) * DB + (idx - NRB) < NP) {
-                            dma_piece(buf, (mi - 1) * DB + (idx - NRB));                        // the K tile after next, into this buffer
+                            dma_piece(buf, (mi - 1) * DB + (idx - NRB));                        // K tile t + NST, into this stage
                             any = true;
                         }
                     }
@@ -284,7 +309,8 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                 }
             if (mi == 0) {
                 __builtin_amdgcn_sched_barrier(0);
-                dma_wait_barrier();
+                if constexpr (NST == 2) dma_wait_barrier();
+                else ring_wait_barrier(IntC<NST - 2>{});             // tile t + 1 has landed; the copies of t + 2 may still be in flight
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -300,13 +326,20 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 #pragma unroll
         for (int p = 0; p < NP; ++p) dma_piece(1, p);
         fetch_advance();
-        dma_wait_barrier();
+        if constexpr (NST == 3) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) dma_piece(2, p);
+            fetch_advance();
+            ring_wait_barrier(IntC<2>{});                            // tile 0 has landed
+        } else {
+            dma_wait_barrier();
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) {
                 read_a(0, t, pc);
-                read_w(0, 0, t, pc);
+                if (t < NI) read_w(0, 0, t, pc);
             }
     };
 
@@ -371,7 +404,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
+                for (int ni = 0; ni < NI; ++ni) {
                     const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (uint32_t)((mi * 4 + ni) * 1024), 0, 16);
                     acc[mi][ni] = f32x4{__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3])};
                 }
@@ -380,7 +413,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
         // the publish: a scalar test per K tile; the cold branch reads its operands from LDS (thread 0 wrote them, thread 0 reads them)
@@ -396,18 +429,35 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
             }
         };
         int cnt = ke - kb;
-        if (cnt > 0 && par) {
-            ktile(IntC<1>{});
-            after_tile();
-            --cnt; par = 0;
+        if constexpr (NST == 3) {
+            // one segment per workgroup: stage = t mod 3, fragment set = t mod 2
+            for (; cnt >= 6; cnt -= 6) {
+                ktile(IntC<0>{}, IntC<0>{});
+                ktile(IntC<1>{}, IntC<1>{});
+                ktile(IntC<2>{}, IntC<0>{});
+                ktile(IntC<0>{}, IntC<1>{});
+                ktile(IntC<1>{}, IntC<0>{});
+                ktile(IntC<2>{}, IntC<1>{});
+            }
+            if (cnt > 0) ktile(IntC<0>{}, IntC<0>{});
+            if (cnt > 1) ktile(IntC<1>{}, IntC<1>{});
+            if (cnt > 2) ktile(IntC<2>{}, IntC<0>{});
+            if (cnt > 3) ktile(IntC<0>{}, IntC<1>{});
+            if (cnt > 4) ktile(IntC<1>{}, IntC<0>{});
+        } else {
+            if (cnt > 0 && par) {
+                ktile(IntC<1>{}, IntC<1>{});
+                after_tile();
+                --cnt; par = 0;
+            }
+            for (; cnt >= 2; cnt -= 2) {
+                ktile(IntC<0>{}, IntC<0>{});
+                after_tile();
+                ktile(IntC<1>{}, IntC<1>{});
+                after_tile();
+            }
+            if (cnt) { ktile(IntC<0>{}, IntC<0>{}); after_tile(); par = 1; }
         }
-        for (; cnt >= 2; cnt -= 2) {
-            ktile(IntC<0>{});
-            after_tile();
-            ktile(IntC<1>{});
-            after_tile();
-        }
-        if (cnt) { ktile(IntC<0>{}); after_tile(); par = 1; }
 
         const int m0 = bm0 + wm0, n0 = bn0 + wn0;
         if (PERSIST && kind == 1) {
@@ -416,7 +466,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
+                for (int ni = 0; ni < NI; ++ni) {
                     const u32x4 v = {__float_as_uint(acc[mi][ni][0]), __float_as_uint(acc[mi][ni][1]), __float_as_uint(acc[mi][ni][2]),
                                      __float_as_uint(acc[mi][ni][3])};
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, base + (uint32_t)((mi * 4 + ni) * 1024), 0, 16);
@@ -432,15 +482,15 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
             // mi -> row + 16 mi: row-blocked, 256 bytes inside the 32-row block for odd mi and one block (ld * 192 bytes) per two; row-major 16 rows
             const int64_t step_m1 = blk ? 256 : a.ldcs * 96, step_m2 = blk ? a.ldcs * 192 : a.ldcs * 192;
             const int step_n = blk ? 4 * 3 * 512 : 4 * 48, step_p = blk ? 512 : 16;            // ni -> + 32 columns = 4 k-groups; piece
-            f32x4 bv[4];                                  // the bias of this lane's columns, once (the stores below would force a reload per row tile)
+            f32x4 bv[NI];                                  // the bias of this lane's columns, once (the stores below would force a reload per row tile)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) bv[ni] = EPI == EPI_NONE ? f32x4{0.f, 0.f, 0.f, 0.f} : bias4(a, n0 + ni * 16 + 4 * g);
+            for (int ni = 0; ni < NI; ++ni) bv[ni] = EPI == EPI_NONE ? f32x4{0.f, 0.f, 0.f, 0.f} : bias4(a, n0 + ni * 16 + 4 * g);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int m = mb + mi * 16, mc = min(m, a.M - 1);
                 char* cm = cb + (mi & 1) * step_m1 + (mi >> 1) * step_m2;
 #pragma unroll
-                for (int ni = 0; ni < 4; ni += 2) {
+                for (int ni = 0; ni < NI; ni += 2) {
                     f32x4 x = epi4<EPI>(a, acc[mi][ni], bv[ni], mc, n0 + ni * 16 + 4 * g);
                     f32x4 y = epi4<EPI>(a, acc[mi][ni + 1], bv[ni + 1], mc, n0 + (ni + 1) * 16 + 4 * g);
 #pragma unroll
@@ -464,15 +514,15 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
             }
         } else {
             const bool vec = (a.ldc & 3) == 0 && ((uintptr_t)a.C & 15) == 0;
-            f32x4 bv[4];
+            f32x4 bv[NI];
             if constexpr (!PERSIST)                       // (the persistent instantiations are short of registers here: they load it per row tile)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) bv[ni] = EPI == EPI_NONE ? f32x4{0.f, 0.f, 0.f, 0.f} : bias4(a, n0 + ni * 16 + 4 * g);
+                for (int ni = 0; ni < NI; ++ni) bv[ni] = EPI == EPI_NONE ? f32x4{0.f, 0.f, 0.f, 0.f} : bias4(a, n0 + ni * 16 + 4 * g);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int m = m0 + mi * 16 + l15;
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
+                for (int ni = 0; ni < NI; ++ni) {
                     const int n = n0 + ni * 16 + 4 * g;
                     if constexpr (PERSIST) bv[ni] = EPI == EPI_NONE ? f32x4{0.f, 0.f, 0.f, 0.f} : bias4(a, n);
                     const f32x4 v = epi4<EPI>(a, acc[mi][ni], bv[ni], min(m, a.M - 1), n);
@@ -500,7 +550,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 #pragma unroll
                         for (int pc = 0; pc < 3; ++pc) {
                             if (t < 3) read_a(buf, t, pc);
-                            read_w(buf, buf, t, pc);
+                            if (t < NI) read_w(buf, buf, t, pc);
                         }
                 };
                 if (par) refill(IntC<1>{}); else refill(IntC<0>{});
@@ -523,10 +573,10 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 // (__launch_bounds__(512) for the 4-wave instantiation too: told that a workgroup has 256 threads hipcc budgets 512 registers per lane,
 // parks fragments in AGPRs and copies them back inside the K loop — ~40 v_accvgpr moves per 192 MFMAs.  A bound of 512 threads = 256
 // registers gives it the 8-wave instantiation's allocation: none.)
-template <int WN, int EPI, bool PERSIST, bool ABLK>
+template <int WN, int NI, int EPI, bool PERSIST, bool ABLK, int NST = 2>
 __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles_m, int tiles_n, int nwg, Ws16 ws) {
-    __shared__ __attribute__((aligned(16))) char smem[split16_lds_bytes<WN>()];
-    split16_body<WN, EPI, PERSIST, ABLK>(a, tiles_m, tiles_n, nwg, ws, smem, -1, -1);
+    __shared__ __attribute__((aligned(16))) char smem[split16_lds_bytes<WN, NI, NST>()];
+    split16_body<WN, NI, EPI, PERSIST, ABLK, NST>(a, tiles_m, tiles_n, nwg, ws, smem, -1, -1);
 }
 
 // One workgroup per 128 x 256 tile EXCEPT the ragged last round, which runs as 128 x 128 half tiles (round 5).  With T
@@ -536,69 +586,82 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles
 // 8-wave workgroups on wide tiles; each of the remaining rem = q mod 32 <= 16 tiles becomes TWO blocks whose waves 0-3 run the 4-wave body on
 // one 128 x 128 half (waves 4-7 exit at once): 2 rem <= 32 blocks per XCD, one per CU, each with half the matrix work — the last round takes
 // about half a tile time instead of a whole one.  Same K order per element as every other instantiation: bit-identical results (tests).
-template <int EPI, bool ABLK>
+template <int EPI, bool ABLK, bool TAIL8>
 __global__ __launch_bounds__(512) void gemm_split16_tail_kernel(GemmArgs a, int tiles_m, int tiles_n, int q, int tail_from) {
     __shared__ __attribute__((aligned(16))) char smem[split16_lds_bytes<4>()];
     const Ws16 none{nullptr, nullptr};
     const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;           // workgroup-uniform
     if (within < tail_from) {
-        split16_body<4, EPI, false, ABLK>(a, tiles_m, tiles_n, 0, none, smem, xcd * q + within, -1);
+        split16_body<4, 4, EPI, false, ABLK>(a, tiles_m, tiles_n, 0, none, smem, xcd * q + within, -1);
     } else {
-        if (threadIdx.x >= 256) return;                                 // (an ended wave no longer counts at s_barrier)
         const int h = within - tail_from;
-        split16_body<2, EPI, false, ABLK>(a, tiles_m, tiles_n, 0, none, smem, xcd * q + tail_from + (h >> 1), h & 1);
+        if constexpr (TAIL8) {                                          // round 6: the half tile on all eight waves (64 x 32 wave tiles)
+            split16_body<4, 2, EPI, false, ABLK>(a, tiles_m, tiles_n, 0, none, smem, xcd * q + tail_from + (h >> 1), h & 1);
+        } else {
+            if (threadIdx.x >= 256) return;                             // (an ended wave no longer counts at s_barrier)
+            split16_body<2, 4, EPI, false, ABLK>(a, tiles_m, tiles_n, 0, none, smem, xcd * q + tail_from + (h >> 1), h & 1);
+        }
     }
 }
 
-template <int WN, int EPI, bool PERSIST, bool ABLK>
+template <int WN, int NI, int EPI, bool PERSIST, bool ABLK, int NST>
 int launch16(const GemmArgs& a, const Ws16& ws, hipStream_t s) {
-    constexpr int BN = WN * 64;
+    constexpr int BN = WN * NI * 16;
     const int tiles_m = (a.M + QBM - 1) / QBM, tiles_n = (a.N + BN - 1) / BN;
     const int nwg = PERSIST ? Q_NWG : tiles_m * tiles_n * (a.ksplit > 1 ? a.ksplit : 1);
-    hipLaunchKernelGGL((gemm_split16_kernel<WN, EPI, PERSIST, ABLK>), dim3(nwg), dim3(2 * WN * 64), 0, s, a, tiles_m, tiles_n, nwg, ws);
+    hipLaunchKernelGGL((gemm_split16_kernel<WN, NI, EPI, PERSIST, ABLK, NST>), dim3(nwg), dim3(2 * WN * 64), 0, s, a, tiles_m, tiles_n, nwg, ws);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int WN, bool PERSIST>
+template <int WN, int NI, bool PERSIST, int NST = 2>
 int dispatch16(const GemmArgs& a, int epi, const Ws16& ws, hipStream_t s) {
     if (a.a_blk) {      // row-blocked A (fc2's operand): bias + residual, or no epilogue
-        if (epi == EPI_BIAS_RESID) return launch16<WN, EPI_BIAS_RESID, PERSIST, true>(a, ws, s);
-        if (epi == EPI_NONE) return launch16<WN, EPI_NONE, PERSIST, true>(a, ws, s);
+        if (epi == EPI_BIAS_RESID) return launch16<WN, NI, EPI_BIAS_RESID, PERSIST, true, NST>(a, ws, s);
+        if (epi == EPI_NONE) return launch16<WN, NI, EPI_NONE, PERSIST, true, NST>(a, ws, s);
         return -1;
     }
     switch (epi) {
-        case EPI_NONE: return launch16<WN, EPI_NONE, PERSIST, false>(a, ws, s);
-        case EPI_BIAS: return launch16<WN, EPI_BIAS, PERSIST, false>(a, ws, s);
-        case EPI_BIAS_GELU: return launch16<WN, EPI_BIAS_GELU, PERSIST, false>(a, ws, s);
-        case EPI_BIAS_RESID: return launch16<WN, EPI_BIAS_RESID, PERSIST, false>(a, ws, s);
-        case EPI_BIAS_QSCALE: return launch16<WN, EPI_BIAS_QSCALE, PERSIST, false>(a, ws, s);
+        case EPI_NONE: return launch16<WN, NI, EPI_NONE, PERSIST, false, NST>(a, ws, s);
+        case EPI_BIAS: return launch16<WN, NI, EPI_BIAS, PERSIST, false, NST>(a, ws, s);
+        case EPI_BIAS_GELU: return launch16<WN, NI, EPI_BIAS_GELU, PERSIST, false, NST>(a, ws, s);
+        case EPI_BIAS_RESID: return launch16<WN, NI, EPI_BIAS_RESID, PERSIST, false, NST>(a, ws, s);
+        case EPI_BIAS_QSCALE: return launch16<WN, NI, EPI_BIAS_QSCALE, PERSIST, false, NST>(a, ws, s);
         case EPI_BIAS_POS:
-            if constexpr (!PERSIST) return (a.N % 4) == 0 && a.resid != nullptr && a.c_split == nullptr ? launch16<WN, EPI_BIAS_POS, false, false>(a, ws, s) : -1;
+            if constexpr (!PERSIST) return (a.N % 4) == 0 && a.resid != nullptr && a.c_split == nullptr ? launch16<WN, NI, EPI_BIAS_POS, false, false, NST>(a, ws, s) : -1;
             return -1;
         default: return -1;
     }
 }
 
 template <int EPI, bool ABLK>
-int launch16_tail(const GemmArgs& a, int tiles_m, int tiles_n, int q, int tail_from, hipStream_t s) {
+int launch16_tail(const GemmArgs& a, int tiles_m, int tiles_n, int q, int tail_from, bool tail8, hipStream_t s) {
     const int nwg = 8 * (tail_from + 2 * (q - tail_from));
-    hipLaunchKernelGGL((gemm_split16_tail_kernel<EPI, ABLK>), dim3(nwg), dim3(512), 0, s, a, tiles_m, tiles_n, q, tail_from);
+    if (tail8) hipLaunchKernelGGL((gemm_split16_tail_kernel<EPI, ABLK, true>), dim3(nwg), dim3(512), 0, s, a, tiles_m, tiles_n, q, tail_from);
+    else hipLaunchKernelGGL((gemm_split16_tail_kernel<EPI, ABLK, false>), dim3(nwg), dim3(512), 0, s, a, tiles_m, tiles_n, q, tail_from);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 }  // namespace
 
-// one workgroup per tile (and K slice): wide = 128 x 256 tile on 8 waves, else 128 x 128 on 4.  a.ksplit > 1: raw partial sums (epi must be EPI_NONE)
-int launch_split16_tiles(const GemmArgs& a, int epi, bool wide, hipStream_t s) {
+// one workgroup per tile (and K slice): shape 0 = 128 x 256 tile on 8 waves, 1 = 128 x 128 on 4 waves, 2 = 128 x 128 on 8 waves of 64 x 32,
+// 3 = 128 x 128 on 4 waves with a THREE-stage K ring (two stages of copies in flight).
+// a.ksplit > 1: raw partial sums (epi must be EPI_NONE)
+int launch_split16_tiles(const GemmArgs& a, int epi, int shape, hipStream_t s) {
     if (a.c_split != nullptr && epi == EPI_BIAS_RESID) return -1;
     const Ws16 none{nullptr, nullptr};
-    return wide ? dispatch16<4, false>(a, epi, none, s) : dispatch16<2, false>(a, epi, none, s);
+    switch (shape) {
+        case 0: return dispatch16<4, 4, false>(a, epi, none, s);
+        case 1: return dispatch16<2, 4, false>(a, epi, none, s);
+        case 2: return dispatch16<4, 2, false>(a, epi, none, s);
+        case 3: return dispatch16<2, 4, false, 3>(a, epi, none, s);
+        default: return -1;
+    }
 }
 
 // The 128 x 256 tiling with its ragged last round as 128 x 128 half tiles (gemm_split16_tail_kernel).  `cus` = compute units of the device.
 // Applies when the tile count divides by the 8 XCDs, an XCD's share q leaves 1 ... cus / 16 tiles after its full rounds and N % 256 == 0;
 // returns 1 (nothing launched) when it does not — the caller then launches the plain grid.
-int launch_split16_tiles_tail(const GemmArgs& a, int epi, int cus, hipStream_t s) {
+int launch_split16_tiles_tail(const GemmArgs& a, int epi, int cus, bool tail8, hipStream_t s) {
     if (a.ksplit > 1 || (a.N % 256) != 0 || cus < 16 || (cus % 8) != 0) return 1;
     if (a.c_split != nullptr && epi == EPI_BIAS_RESID) return -1;
     const int tiles_m = (a.M + QBM - 1) / QBM, tiles_n = a.N / 256, T = tiles_m * tiles_n, per = cus / 8;
@@ -607,16 +670,16 @@ int launch_split16_tiles_tail(const GemmArgs& a, int epi, int cus, hipStream_t s
     if (full < 1 || rem < 1 || 2 * rem > per) return 1;
     const int tf = full * per;
     if (a.a_blk) {
-        if (epi == EPI_BIAS_RESID) return launch16_tail<EPI_BIAS_RESID, true>(a, tiles_m, tiles_n, q, tf, s);
-        if (epi == EPI_NONE) return launch16_tail<EPI_NONE, true>(a, tiles_m, tiles_n, q, tf, s);
+        if (epi == EPI_BIAS_RESID) return launch16_tail<EPI_BIAS_RESID, true>(a, tiles_m, tiles_n, q, tf, tail8, s);
+        if (epi == EPI_NONE) return launch16_tail<EPI_NONE, true>(a, tiles_m, tiles_n, q, tf, tail8, s);
         return -1;
     }
     switch (epi) {
-        case EPI_NONE: return launch16_tail<EPI_NONE, false>(a, tiles_m, tiles_n, q, tf, s);
-        case EPI_BIAS: return launch16_tail<EPI_BIAS, false>(a, tiles_m, tiles_n, q, tf, s);
-        case EPI_BIAS_GELU: return launch16_tail<EPI_BIAS_GELU, false>(a, tiles_m, tiles_n, q, tf, s);
-        case EPI_BIAS_RESID: return launch16_tail<EPI_BIAS_RESID, false>(a, tiles_m, tiles_n, q, tf, s);
-        case EPI_BIAS_QSCALE: return launch16_tail<EPI_BIAS_QSCALE, false>(a, tiles_m, tiles_n, q, tf, s);
+        case EPI_NONE: return launch16_tail<EPI_NONE, false>(a, tiles_m, tiles_n, q, tf, tail8, s);
+        case EPI_BIAS: return launch16_tail<EPI_BIAS, false>(a, tiles_m, tiles_n, q, tf, tail8, s);
+        case EPI_BIAS_GELU: return launch16_tail<EPI_BIAS_GELU, false>(a, tiles_m, tiles_n, q, tf, tail8, s);
+        case EPI_BIAS_RESID: return launch16_tail<EPI_BIAS_RESID, false>(a, tiles_m, tiles_n, q, tf, tail8, s);
+        case EPI_BIAS_QSCALE: return launch16_tail<EPI_BIAS_QSCALE, false>(a, tiles_m, tiles_n, q, tf, tail8, s);
         default: return 1;
     }
 }
@@ -627,5 +690,5 @@ int launch_split16_persist(const GemmArgs& a, int epi, void* ws_mem, hipStream_t
     Ws16 ws;
     ws.part = reinterpret_cast<float*>(ws_mem);
     ws.flag = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws_mem) + (size_t)Q_NWG * Q_SLAB * 4);
-    return dispatch16<4, true>(a, epi, ws, s);
+    return dispatch16<4, 4, true>(a, epi, ws, s);
 }
