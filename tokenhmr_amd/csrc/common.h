@@ -76,9 +76,6 @@ struct GemmArgs {
     // 128 x 128 tile on eight waves of 64 x 32 instead of four of 64 x 64, bit 1 = the half-tile tail likewise (round 6: measured slower /
     // equal, gemm_split.hip); bit 2 = the 128 x 128 tile with round 5's TWO-stage K ring instead of three stages (THMR_SPLIT3_RING3=0).  Same bits either way.
     int tile_opts;
-    // split3 GEMM, per-tile kernels: the weight warm-up's distance in K tiles ahead of the copy cursor (gemm_split16.hip PF_SINK): 0 = the
-    // default, > 0 = that many, < 0 = none (the touch re-reads the cursor's own tile).  Never changes a result.
-    int pf_dist;
 };
 
 // byte offset of chunk (row m, k-group n8, piece pc) of a split3 operand with row length ld (fp32-equivalents), row-major or row-blocked

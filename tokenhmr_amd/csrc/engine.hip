@@ -121,7 +121,6 @@ struct thmr_engine {
     bool split3_small = false;        // THMR_SPLIT3_SMALL=1: the split3 mode also serves up to six crops (ring kernel on split3 operands) — measured SLOWER, A/B only
     int split3_fc2_split = 2;         // THMR_SPLIT3_FC2_SPLIT=1: fc2 of the split3 mode unsplit from 16 crops on (A/B only)
     int s3_tile_opts = 0;             // GemmArgs::tile_opts of the split3 GEMMs (THMR_SPLIT3_NARROW8=1 -> 1, THMR_SPLIT3_TAIL8=1 -> 2; A/B only)
-    int s3_pf_dist = 0;               // GemmArgs::pf_dist of the split3 GEMMs (THMR_SPLIT3_PF=<n>: n > 0 distance, 0 = none; A/B only)
     int split3_min_b = 0;             // THMR_SPLIT3_MIN_B=<n>: A/B knob for the smallest batch the split3 mode serves (0 = kSplit3LowMinB)
     char* split_w = nullptr;          // split3 weight copies: shared, reference-counted, among the engines of one weight arena (split_share())
     bool split_w_counted = false;     // this engine holds a reference in split_share()
@@ -473,7 +472,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             char* ims = e->split_act + (size_t)M * DIM * 6;
             LAUNCH_OK(launch_im2col_patch_split3(img, ims, B, st));
             GemmArgs a = mk(reinterpret_cast<const float*>(ims), 768, reinterpret_cast<const float*>(e->pe_s), 768, e->hot.pe_b, e->hot.pos, 0, x, DIM, M, DIM, 768);
-            a.tile_opts = e->s3_tile_opts; a.pf_dist = e->s3_pf_dist;
+            a.tile_opts = e->s3_tile_opts;
             LAUNCH_OK(launch_gemm_split3(a, EPI_BIAS_POS, -1, st));
         } else {
             LAUNCH_OK(launch_im2col_patch(img, big, B, st));
@@ -563,7 +562,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             GemmArgs a = mk(reinterpret_cast<const float*>(A), K, reinterpret_cast<const float*>(Wt), K, bias, resid, N, C, N, M, N, K);
             a.qscale = qscale; a.qcols = DIM;
             a.a_blk = a_blk;
-            a.tile_opts = e->s3_tile_opts; a.pf_dist = e->s3_pf_dist;
+            a.tile_opts = e->s3_tile_opts;
             const int bit = cls == THMR_PROF_GEMM_QKV ? 1 : cls == THMR_PROF_GEMM_PROJ ? 2 : cls == THMR_PROF_GEMM_FC2 ? 8 : 0;
             if (e->s3_ws && e->s3_persist && (e->s3_persist_mask & bit) && gemm_split3_persist_ok(a)) return launch_split3_persist_serialised(e, a, epi, 0, st);
             return launch_gemm_split3(a, epi, -1, st);
@@ -586,7 +585,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 {
                     ProfScope ps(e, st, THMR_PROF_GEMM_PROJ, 2.0 * M * DIM * (double)DIM, 6.0 * ((double)M * DIM + (double)DIM * DIM) + 4.0 * s3_split * M * DIM);
                     GemmArgs a = mk(reinterpret_cast<const float*>(hs), DIM, reinterpret_cast<const float*>(ws.proj), DIM, nullptr, nullptr, 0, x, DIM, M, DIM, DIM);
-                    a.tile_opts = e->s3_tile_opts; a.pf_dist = e->s3_pf_dist;
+                    a.tile_opts = e->s3_tile_opts;
                     LAUNCH_OK(launch_gemm_split3_splitk(a, s3_split, part, st));
                 }
                 ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (s3_split + 2.0) * M * DIM + 6.0 * M * DIM);
@@ -601,7 +600,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 GemmArgs a = mk(reinterpret_cast<const float*>(hs), DIM, reinterpret_cast<const float*>(ws.fc1), DIM, w.f1b, nullptr, 0, nullptr, 0, M, MLP, DIM);
                 a.c_split = bs; a.ldcs = MLP;
                 a.cs_blk = bs_blk;
-                a.tile_opts = e->s3_tile_opts; a.pf_dist = e->s3_pf_dist;
+                a.tile_opts = e->s3_tile_opts;
                 if (e->s3_ws && e->s3_persist && e->s3_fc1_mode && (e->s3_persist_mask & 4) && gemm_split3_persist_ok(a))
                     LAUNCH_OK(launch_split3_persist_serialised(e, a, EPI_BIAS_GELU, 2, st));
                 else
@@ -612,7 +611,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                     ProfScope ps(e, st, THMR_PROF_GEMM_FC2, 2.0 * M * DIM * (double)MLP, 6.0 * ((double)M * MLP + (double)DIM * MLP) + 4.0 * s3_fc2 * M * DIM);
                     GemmArgs a = mk(reinterpret_cast<const float*>(bs), MLP, reinterpret_cast<const float*>(ws.fc2), MLP, nullptr, nullptr, 0, x, DIM, M, DIM, MLP);
                     a.a_blk = bs_blk;
-                    a.tile_opts = e->s3_tile_opts; a.pf_dist = e->s3_pf_dist;
+                    a.tile_opts = e->s3_tile_opts;
                     LAUNCH_OK(launch_gemm_split3_splitk(a, s3_fc2, part2, st));
                 }
                 ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (s3_fc2 + 3.0) * M * DIM);
@@ -819,7 +818,7 @@ int head_forward(thmr_engine* e, const float* ctx, int B, const thmr_outputs* ou
             // on the bf16 matrix pipe (1.5 -> 1.0 ms at 64 crops)
             LAUNCH_OK(launch_split3(ctx, DIM, e->split_act, DIM, M, DIM, st));
             GemmArgs a = mk(reinterpret_cast<const float*>(e->split_act), DIM, reinterpret_cast<const float*>(e->kv_s), DIM, nullptr, nullptr, 0, big, ldkv, M, ldkv, DIM);
-            a.tile_opts = e->s3_tile_opts; a.pf_dist = e->s3_pf_dist;
+            a.tile_opts = e->s3_tile_opts;
             if (e->s3_ws && e->s3_persist && (e->s3_persist_mask & 16) && gemm_split3_persist_ok(a)) LAUNCH_OK(launch_split3_persist_serialised(e, a, EPI_NONE, 0, st));
             else LAUNCH_OK(launch_gemm_split3(a, EPI_NONE, -1, st));
         } else {
@@ -1292,7 +1291,6 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* n8 = thmr_knob("THMR_SPLIT3_NARROW8"); if (n8 && n8[0] == '1') e->s3_tile_opts |= 1; }
     { const char* t8 = thmr_knob("THMR_SPLIT3_TAIL8"); if (t8 && t8[0] == '1') e->s3_tile_opts |= 2; }
     { const char* r3 = thmr_knob("THMR_SPLIT3_RING3"); if (r3 && r3[0] == '0') e->s3_tile_opts |= 4; }
-    { const char* pf = thmr_knob("THMR_SPLIT3_PF"); if (pf) { const int n = atoi(pf); e->s3_pf_dist = n > 0 ? n : -1; } }
     { const char* sp = thmr_knob("THMR_SPLIT3_PERSIST"); if (sp && sp[0] >= '0' && sp[0] <= '1') e->s3_persist = sp[0] - '0'; }
     { const char* fm = thmr_knob("THMR_SPLIT3_FC1_MODE"); if (fm && fm[0] >= '0' && fm[0] <= '2') e->s3_fc1_mode = fm[0] - '0'; }
     { const char* mk_ = thmr_knob("THMR_SPLIT3_PERSIST_MASK"); if (mk_) e->s3_persist_mask = atoi(mk_); }

@@ -114,19 +114,6 @@ __device__ __forceinline__ f32x4 epi4(const GemmArgs& a, f32x4 v, f32x4 b, int m
 // SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE, 8 instead of 4 LDS cycles per read, profiles/r4ah_pmc_lds.json.)
 __device__ __forceinline__ constexpr int rot16(int row) { return ((row >> 2) & 1) * 2; }
 
-// L2 warm-up of the WEIGHT operand (round 6).  At few crops the weights stream cold from HBM (3.8 GB per call: nothing survives in the
-// caches from one call to the next) to 90-480 workgroups, each with ONE stage of copies in flight (two with the three-stage ring), and the
-// K-tile period is the loaded round trip, not the MFMA time (NST above).  LDS has no room for another 72 KB stage of the 128 x 256 tile — but
-// the bytes do not have to wait in LDS: every K tile each wave issues ONE extra LDS-DMA copy of a DWORD per lane, lane (row, half) touching
-// byte 128 half of row `row` of the weight tile `pf` K tiles ahead of the copy cursor (2 x 128-byte lines cover a row's 192-byte K-tile
-// segment), into a 256-byte sink per wave that nobody reads.  The real copy of that tile, `pf` periods later, finds its lines in L2.  It is
-// issued after the tile's real copies, and the tile barriers wait with vmcnt(1) more than before: the newest prefetch may still be in flight.
-constexpr int PF_SINK = 8 * 256;
-
-__device__ __forceinline__ void dma4_saddr(const char* base, uint32_t voff, uint32_t lds_base) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(base), "s"(lds_base));
-}
-
 template <int WN, int NI = 4, int NST = 2>
 constexpr int split16_lds_bytes() { return NST * (QBM * ROWB + WN * NI * 16 * ROWB); }    // NST stages of (A tile + W tile): 147,456 / 98,304 bytes at two, 147,456 for three 128 x 128 stages
 
@@ -147,12 +134,15 @@ constexpr int split16_lds_bytes() { return NST * (QBM * ROWB + WN * NI * 16 * RO
 // half of it (1.55 us per 128 x 128 K tile against 0.7 us of MFMA issue at 4 crops).  Three stages (128 x 128 tile only: 3 x 48 KB = 144 KB)
 // put the copies of tile t + 2 in flight as well: tile t's barrier waits with vmcnt(NP) — everything but the newest tile's copies — so a
 // copy has two periods to land.  Fragment registers still alternate between two sets, so the K loop is unrolled by six (stage = t mod 3,
-// set = t mod 2, all LDS offsets immediates).  Same K order per element: bit-identical.
-template <int WN, int NI, int EPI, bool PERSIST, bool ABLK, int NST = 2, bool PFW = false>
+// set = t mod 2, all LDS offsets immediates).  Same K order per element: bit-identical.  Measured, whole path, same box, interleaved
+// (profiles/r6e_ab_ring2_vs_ring3_*): 386 -> 459 crops/s at 3 crops, 497 -> 558 at 4, 473 -> 527 at 5, 645 -> 672 at 8, 770 -> 776 at 16.
+// The 128 x 256 tile has no LDS for a third stage (3 x 72 KB).  Tried for it and not kept (commit 6294ec7, profiles/r6f_*): warming L2 with
+// the weight tile several K tiles ahead of the copy cursor — one dword LDS-DMA touch per lane and K tile into a sink — is SLOWER at every
+// batch size (+2.5 % per call at 8 crops, +7.8 % at 4, +2.7 % at 16, +3.8 % at 32, +2.5 % at 64): the extra copy and the later arrival of
+// the real ones cost more than an L2 hit saves.
+template <int WN, int NI, int EPI, bool PERSIST, bool ABLK, int NST = 2>
 __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles_n, int nwg, const Ws16& ws, char* smem, int given_tile, int half) {
     constexpr int NW = 2 * WN, BN = WN * NI * 16;
-    static_assert(!PFW || (NI == 4 && !PERSIST), "the weight warm-up: 64 x 64 wave tiles (one touch per lane covers the tile), per-tile decomposition");
-    constexpr int PFN = PFW ? 1 : 0;                                   // prefetch instructions per wave and K tile
     static_assert(NST == 2 || (NST == 3 && !PERSIST), "two stages, or three for the one-workgroup-per-tile decomposition");
     static_assert(NI == 4 || NI == 2, "wave tile 64 x 64 or 64 x 32");
     static_assert(!PERSIST || NI == 4, "the persistent decomposition uses the 64 x 64 wave tile");
@@ -222,13 +212,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     // ---- copies: wave instruction q = wave + i NW of an operand fills LDS chunks 64 q ... 64 q + 63 of its stage (rows past the edge clamped)
     const int64_t arow = a.lda * 6, wrow = a.ldw * 6;
     uint32_t Aoff[A_P], Woff[B_P];
-    uint32_t pfoff = 0;                                                // weight warm-up: this lane's (row, 128-byte half) of the weight tile
-    const int pf_dist = PFW ? (a.pf_dist < 0 ? 0 : a.pf_dist == 0 ? 4 : a.pf_dist) : 0;      // K tiles ahead of the copy cursor (0 = re-touch the cursor's own tile)
     auto set_offsets = [&](int bm0, int bn0) {
-        if constexpr (PFW) {
-            const int prow = (wave * 64 + lane) >> 1;                  // 2 BN touches on NW x 64 lanes: BN / NW = 32 rows per wave
-            pfoff = (uint32_t)(min(bn0 + prow, a.N - 1) - bn0) * (uint32_t)wrow + (uint32_t)(lane & 1) * 128u;
-        }
 #pragma unroll
         for (int i = 0; i < A_P; ++i) {
             const int c = (wave + i * NW) * 64 + lane;
@@ -295,11 +279,11 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     // one K tile out of buffer `buf` (weight fragment set `buf`)
     constexpr int NRB = 3 + NI;                                        // reads per block 1-3: one activation tile (3 pieces) + NI of the 3 NI weight fragments
     constexpr int DB = (NP + 2) / 3;                                   // copies per block 1-3
-    static_assert(NRB + DB + PFN <= NPROD * NI, "block too small for the staging interleave");
+    static_assert(NRB + DB <= NPROD * NI, "block too small for the staging interleave");
     // wait for every copy of this wave but the newest `keep` tiles' (the compiler does not count LDS-DMA copies: explicit), + its LDS reads; barrier
     auto ring_wait_barrier = [&](auto keepc) {
         constexpr int keep = decltype(keepc){};
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(keep * (NP + PFN) + PFN) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(keep * NP) : "memory");
     };
     // K tile t out of LDS stage `buf` = t mod NST with weight fragment set `set` = t mod 2: reads tile t + 1 from stage buf + 1, copies tile t + NST into stage buf
     auto ktile = [&](auto bufc, auto setc) {
@@ -324,17 +308,14 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                         } else if (idx - NRB < DB && (mi - 1) * DB + (idx - NRB) < NP) {
                             dma_piece(buf, (mi - 1) * DB + (idx - NRB));                        // K tile t + NST, into this stage
                             any = true;
-                        } else if (PFW && mi == 3 && idx == NRB + DB) {                         // after the tile's last real copy: the weight warm-up
-                            dma4_saddr(fW + min(pf_dist, fke - 1 - fk) * ROWB, pfoff, lds_addr_b(smem + NST * (A_STAGE + B_STAGE) + wave * 256));
-                            any = true;
                         }
                     }
                     if (any) __builtin_amdgcn_sched_barrier(0);
                 }
             if (mi == 0) {
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (NST == 2 && !PFW) dma_wait_barrier();
-                else ring_wait_barrier(IntC<NST - 2>{});             // tile t + 1 has landed; the copies of t + 2 (three stages) and the newest warm-up touch may still be in flight
+                if constexpr (NST == 2) dma_wait_barrier();
+                else ring_wait_barrier(IntC<NST - 2>{});             // tile t + 1 has landed; the copies of t + 2 may still be in flight
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -354,7 +335,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 #pragma unroll
             for (int p = 0; p < NP; ++p) dma_piece(2, p);
             fetch_advance();
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NP) : "memory");      // tile 0 has landed
+            ring_wait_barrier(IntC<2>{});                            // tile 0 has landed
         } else {
             dma_wait_barrier();
         }
@@ -599,9 +580,8 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 // registers gives it the 8-wave instantiation's allocation: none.)
 template <int WN, int NI, int EPI, bool PERSIST, bool ABLK, int NST = 2>
 __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles_m, int tiles_n, int nwg, Ws16 ws) {
-    constexpr bool PFW = !PERSIST && NI == 4;                           // the weight warm-up: every per-tile instantiation with 64 x 64 wave tiles
-    __shared__ __attribute__((aligned(16))) char smem[split16_lds_bytes<WN, NI, NST>() + (PFW ? PF_SINK : 0)];
-    split16_body<WN, NI, EPI, PERSIST, ABLK, NST, PFW>(a, tiles_m, tiles_n, nwg, ws, smem, -1, -1);
+    __shared__ __attribute__((aligned(16))) char smem[split16_lds_bytes<WN, NI, NST>()];
+    split16_body<WN, NI, EPI, PERSIST, ABLK, NST>(a, tiles_m, tiles_n, nwg, ws, smem, -1, -1);
 }
 
 // One workgroup per 128 x 256 tile EXCEPT the ragged last round, which runs as 128 x 128 half tiles (round 5).  With T
@@ -613,18 +593,18 @@ __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles
 // about half a tile time instead of a whole one.  Same K order per element as every other instantiation: bit-identical results (tests).
 template <int EPI, bool ABLK, bool TAIL8>
 __global__ __launch_bounds__(512) void gemm_split16_tail_kernel(GemmArgs a, int tiles_m, int tiles_n, int q, int tail_from) {
-    __shared__ __attribute__((aligned(16))) char smem[split16_lds_bytes<4>() + PF_SINK];
+    __shared__ __attribute__((aligned(16))) char smem[split16_lds_bytes<4>()];
     const Ws16 none{nullptr, nullptr};
     const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;           // workgroup-uniform
     if (within < tail_from) {
-        split16_body<4, 4, EPI, false, ABLK, 2, true>(a, tiles_m, tiles_n, 0, none, smem, xcd * q + within, -1);
+        split16_body<4, 4, EPI, false, ABLK>(a, tiles_m, tiles_n, 0, none, smem, xcd * q + within, -1);
     } else {
         const int h = within - tail_from;
         if constexpr (TAIL8) {                                          // round 6: the half tile on all eight waves (64 x 32 wave tiles)
             split16_body<4, 2, EPI, false, ABLK>(a, tiles_m, tiles_n, 0, none, smem, xcd * q + tail_from + (h >> 1), h & 1);
         } else {
             if (threadIdx.x >= 256) return;                             // (an ended wave no longer counts at s_barrier)
-            split16_body<2, 4, EPI, false, ABLK, 2, true>(a, tiles_m, tiles_n, 0, none, smem, xcd * q + tail_from + (h >> 1), h & 1);
+            split16_body<2, 4, EPI, false, ABLK>(a, tiles_m, tiles_n, 0, none, smem, xcd * q + tail_from + (h >> 1), h & 1);
         }
     }
 }
