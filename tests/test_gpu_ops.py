@@ -232,7 +232,7 @@ def test_gemm_split3(built_lib, cuda_dev, shape):
     bound = (a.double().abs() @ w.double().abs().t())                       # |a| . |w|: what a dot product's rounding error scales with
     e32 = ((ops.gemm(da, dw, variant="128x160").cpu().double() - ref64).abs() / bound).max().item()
     outs = {}
-    for variant in ("128x256/w8", "128x256/w4", "128x128/w4", "128x128/w8", "128x128/w4/s3", "256x256/w4"):
+    for variant in ("128x256/w8", "128x256/w4", "128x128/w4", "128x128/w8", "128x128/w4/s3", "128x128/w8/s3", "256x256/w4"):
         o = ops.gemm_split3(sa, sw, variant=variant)
         es = ((o.cpu().double() - ref64).abs() / bound).max().item()
         assert es <= max(2.0 * e32, 2.0 ** -22), (variant, es, e32)
@@ -246,9 +246,10 @@ def test_gemm_split3(built_lib, cuda_dev, shape):
     assert torch.equal(outs["128x128/w4"], outs["128x256/w8"]) and torch.equal(ops.gemm_split3(sa, sw, variant="auto"), outs["128x256/w8"])
     # round 6: the 128 x 128 tile on eight waves of 64 x 32, and on four waves with a three-stage K ring
     assert torch.equal(outs["128x128/w8"], outs["128x256/w8"]) and torch.equal(outs["128x128/w4/s3"], outs["128x256/w8"])
+    assert torch.equal(outs["128x128/w8/s3"], outs["128x256/w8"])
     for epi, kw in (("bias_gelu", {}), ("bias_resid", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
         rr = dr if epi == "bias_resid" else None
-        for v in ("128x128/w8", "128x128/w4/s3"):
+        for v in ("128x128/w8", "128x128/w4/s3", "128x128/w8/s3"):
             assert torch.equal(ops.gemm_split3(sa, sw, db, rr, epi=epi, variant=v, **kw), ops.gemm_split3(sa, sw, db, rr, epi=epi, variant="128x256/w8", **kw)), (v, epi)
     # the round-3 / first round-4 kernels on 32x32x16 MFMAs (experiments build): bit-identical among themselves — 64x64 and 64x128 wave
     # tiles, the 256x256 tile, the small-M ring kernel without split-K — and equal to the product kernels to fp32 rounding (another

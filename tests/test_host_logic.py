@@ -312,8 +312,6 @@ def test_gemm_k_loops_carry_no_valu_instruction(built_lib, tmp_path):
                                 # round 6: the 128 x 128 tile with a three-stage K ring (six K tiles per loop trip), GELU / raw partial sums
                                 ("gemm_split16.o", r"gemm_split16_kernelILi2ELi4ELi2ELb0ELb0ELi3E", 576),
                                 ("gemm_split16.o", r"gemm_split16_kernelILi2ELi4ELi0ELb0ELb0ELi3E", 576),
-                                # ... and on eight waves of 64 x 32 (48 MFMAs per K tile and wave)
-                                ("gemm_split16.o", r"gemm_split16_kernelILi4ELi2ELi0ELb0ELb0ELi2E", 96),
                                 # round 5: the mixed grid (8-wave body on wide tiles, 4-wave body on the half tiles of the last round): fc1's instantiation
                                 ("gemm_split16.o", r"gemm_split16_tail_kernelILi2ELb0ELb0E", 192)):
         seg = k_loop(name, sym, min_mfma)

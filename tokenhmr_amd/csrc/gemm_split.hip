@@ -691,7 +691,8 @@ static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStrea
         // round 6: the four-wave 128 x 128 tile with a THREE-stage K ring (variant 8: two stages of copies in flight per CU)
         static const int ring3 = [] { const char* e = thmr_knob("THMR_SPLIT3_RING3"); return e ? atoi(e) : -1; }();
         const bool r3 = ring3 >= 0 ? ring3 != 0 : !(a.tile_opts & 4);
-        variant = t128 <= 256 ? ((narrow8 || (a.tile_opts & 1)) ? 6 : r3 ? 8 : 2) : 0;
+        const bool n8 = narrow8 || (a.tile_opts & 1);
+        variant = t128 <= 256 ? (n8 ? (r3 ? 9 : 6) : r3 ? 8 : 2) : 0;
         by_rule = true;
     }
     if ((by_rule && variant == 0) || variant == 5 || variant == 7) {
@@ -716,6 +717,7 @@ static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStrea
         case 2: return launch_split16_tiles(a, epi, 1, s);
         case 6: return launch_split16_tiles(a, epi, 2, s);
         case 8: return launch_split16_tiles(a, epi, 3, s);
+        case 9: return launch_split16_tiles(a, epi, 4, s);
 #ifdef THMR_EXPERIMENTS
         case 20: return launch_split3_cfg<2, 4, 2, 2>(a, epi, s);
         case 22: return launch_split3_cfg<2, 2, 2, 2>(a, epi, s);

@@ -641,15 +641,20 @@ int dispatch16(const GemmArgs& a, int epi, const Ws16& ws, hipStream_t s) {
 template <int EPI, bool ABLK>
 int launch16_tail(const GemmArgs& a, int tiles_m, int tiles_n, int q, int tail_from, bool tail8, hipStream_t s) {
     const int nwg = 8 * (tail_from + 2 * (q - tail_from));
+#ifdef THMR_EXPERIMENTS
     if (tail8) hipLaunchKernelGGL((gemm_split16_tail_kernel<EPI, ABLK, true>), dim3(nwg), dim3(512), 0, s, a, tiles_m, tiles_n, q, tail_from);
-    else hipLaunchKernelGGL((gemm_split16_tail_kernel<EPI, ABLK, false>), dim3(nwg), dim3(512), 0, s, a, tiles_m, tiles_n, q, tail_from);
+    else
+#else
+    if (tail8) return -1;
+#endif
+    hipLaunchKernelGGL((gemm_split16_tail_kernel<EPI, ABLK, false>), dim3(nwg), dim3(512), 0, s, a, tiles_m, tiles_n, q, tail_from);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 }  // namespace
 
 // one workgroup per tile (and K slice): shape 0 = 128 x 256 tile on 8 waves, 1 = 128 x 128 on 4 waves, 2 = 128 x 128 on 8 waves of 64 x 32,
-// 3 = 128 x 128 on 4 waves with a THREE-stage K ring (two stages of copies in flight).
+// 3 = 128 x 128 on 4 waves with a THREE-stage K ring (two stages of copies in flight), 4 = the same ring under 8 waves of 64 x 32.
 // a.ksplit > 1: raw partial sums (epi must be EPI_NONE)
 int launch_split16_tiles(const GemmArgs& a, int epi, int shape, hipStream_t s) {
     if (a.c_split != nullptr && epi == EPI_BIAS_RESID) return -1;
@@ -657,8 +662,11 @@ int launch_split16_tiles(const GemmArgs& a, int epi, int shape, hipStream_t s) {
     switch (shape) {
         case 0: return dispatch16<4, 4, false>(a, epi, none, s);
         case 1: return dispatch16<2, 4, false>(a, epi, none, s);
-        case 2: return dispatch16<4, 2, false>(a, epi, none, s);
         case 3: return dispatch16<2, 4, false, 3>(a, epi, none, s);
+#ifdef THMR_EXPERIMENTS      // the eight-wave forms lost their A/B (3-6 % slower with two stages, 2-3 % with three: profiles/r6d_*, r6g_*)
+        case 2: return dispatch16<4, 2, false>(a, epi, none, s);
+        case 4: return dispatch16<4, 2, false, 3>(a, epi, none, s);      // eight waves of 64 x 32 AND the three-stage ring
+#endif
         default: return -1;
     }
 }
