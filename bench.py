@@ -200,9 +200,22 @@ def cpu_baseline(cfg, sd, tok, smpl, workload, budget_s=150.0):
                     break
             ts.sort()
             res[B] = (B / ts[len(ts) // 2], len(ts))
+    ref_ratio = None
+    try:        # how the port's rate relates to the reference's own modules, measured where the reference exists (scripts/cpu_reference_vs_port.py)
+        with open(os.path.join(ROOT, "profiles", "r6_cpu_reference_vs_port.json")) as f:
+            rj = json.load(f)
+        ref_ratio = {"port_over_reference_b8": rj["b8"]["port_over_reference"], "port_over_reference_b1": rj["b1"]["port_over_reference"],
+                     "outputs_bit_identical": rj["outputs_bit_identical"], "threads": rj["threads"],
+                     "reference_crops_s_b8": rj["b8"]["reference_crops_s"], "port_crops_s_b8": rj["b8"]["port_crops_s"],
+                     "where": "build container (8 cores), profiles/r6_cpu_reference_vs_port.json: recorded, not measured on this host"}
+    except (OSError, ValueError, KeyError):
+        pass
     return {"value": round(res[8][0], 3), "unit": "crops/s", "cores": threads, "kind": "port",
+            "value_per_thread": round(res[8][0] / threads, 4),
             "kind_note": ("port = oracle/tokenhmr_oracle.py, the CPU restatement pinned bit-exact to the reference's modules — NOT the reference's own "
-                          "modules: /root/reference does not exist on the GPU box"),
+                          "modules: the reference is Python and cannot travel to the GPU box in any form.  The same torch CPU operators in the same "
+                          "order: timed side by side where the reference exists, the port runs at `reference_ratio` of the reference's own rate"),
+            "reference_ratio": ref_ratio,
             "host_cpus": ncpu,
             "usable_cpus": usable, "sweep": sweep,
             "value_b1": round(res[1][0], 3), "value_b8": round(res[8][0], 3),
@@ -733,6 +746,22 @@ def main():
             sync()
             cross = {"ranks_checked": world - 1, "bit_identical": bool(same), "max_abs_diff_verts_joints_m": worst,
                      "how": "rank 0 recomputed every other rank's seeded shard on its own engine and compared the gathered records"}
+    # This rank's shard ALONE — same engine, same resident crops, no collective, no barrier — right after the timed region: the sum over ranks is
+    # what N GPUs deliver if the gather and the barriers cost nothing at THIS shard size (`multi_gpu.expected`), so a poor first 8-GPU curve
+    # separates "small shards run slower per crop" (see batch_sweep: 4 crops per GPU = 0.63 of the 64-crop rate) from "the gather / broadcast hurts"
+    local_rate = None
+    if use_dist and not cpu_dry and a.workload == "full":
+        def local():
+            n_loc = max(3, min(a.steps, 10))
+            for _ in range(2):
+                eng.forward(img, outputs=outs)
+            sync()
+            t_l = time.perf_counter()
+            for _ in range(n_loc):
+                eng.forward(img, outputs=outs)
+            sync()
+            return B * n_loc / (time.perf_counter() - t_l)
+        local_rate = in_turns(local)
     rank_step = None
     if use_dist:
         t = torch.tensor([elapsed], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
@@ -742,6 +771,7 @@ def main():
         # launch stream, exposed gather wait, and who read the checkpoint
         mine = {"rank": rank, "step_ms_median": round(step_ms[len(step_ms) // 2], 3) if step_ms else None,
                 "gather_wait_ms_per_step": round(gather_wait_ms, 4), "read_checkpoint": bool(read_ckpt), "crops": B,
+                "local_crops_per_s": round(local_rate, 2) if local_rate else None,
                 "bcast_ms": round(bcast_ms, 1) if bcast_ms is not None else None}
         rank_step = [None] * world
         dist.all_gather_object(rank_step, mine)
@@ -1004,6 +1034,13 @@ def main():
                 "checkpoint_readers": [r["rank"] for r in rank_step if r["read_checkpoint"]],
                 "devices": [{k: i[k] for k in ("rank", "local_rank", "device", "uuid")} for i in idents],
                 "cross_rank_check": cross,
+                "expected": (round(sum(r["local_crops_per_s"] for r in rank_step), 2) if all(r.get("local_crops_per_s") for r in rank_step) else None),
+                "efficiency_vs_expected": (round(value / sum(r["local_crops_per_s"] for r in rank_step), 4)
+                                           if all(r.get("local_crops_per_s") for r in rank_step) and not a.single_device else None),
+                "expected_note": ("expected = sum over ranks of that rank's own shard timed ALONE on its GPU right after the timed region (per_rank[*]."
+                                  "local_crops_per_s: no gather, no barrier); efficiency_vs_expected = value / expected = what the collectives and the "
+                                  "barriers cost at this shard size; how the shard size itself costs is batch_sweep of the 1-GPU line"
+                                  + ("; --single-device: the ranks time-slice ONE GPU in turns, value is serialised and the ratio is not formed" if a.single_device else "")),
                 "note": ("bcast_ms: one broadcast of the packed weight arena (max over ranks, host clock, synchronised); "
                          "gather_ms_exposed: time the launch stream waited per step for the previous step's packed all-gather "
                          "(HIP events around the join; 0 = hidden under the next ViT); rank_step_ms: per-rank median step on the "
@@ -1013,7 +1050,8 @@ def main():
         if cpu_dry:
             line["dry_run"] = "fake engine on CPU tensors: orchestration only, `value` is meaningless"
         if a.single_device:
-            line["dry_run"] = "--single-device: real engines, all ranks time-slicing cuda:0 over gloo: orchestration + cross-rank check only, `value` is meaningless"
+            line["dry_run"] = ("--single-device: real engines, all ranks time-slicing cuda:0 over gloo, forwards SERIALISED rank by rank between barriers inside "
+                               "the timed region: orchestration + cross-rank check only, `value` is not concurrent throughput")
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
             line["gpu_over_cpu_b1"] = round(value / cpu["value_b1"], 1)

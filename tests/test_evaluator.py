@@ -85,17 +85,28 @@ def test_evaluator_fills_its_host_arrays_lazily(monkeypatch):
     r1 = ev(out, batch)
     assert ev.counter == 8 and len(ev._pending) == 2 and ev.imgnames == ["a", "b", "c", "d"] * 2
     assert not ev._arrays["mode_mpjpe"][:8].any()                       # nothing copied yet
-    assert list(r1["mode_mpjpe"]) == [100.0, 101.0, 102.0, 103.0]       # looking at a returned batch dict fills the arrays
-    assert len(ev._pending) == 0 and list(r0["mode_re"]) == [0.25, 1.25, 2.25, 3.25]
+    assert list(r1["mode_mpjpe"]) == [100.0, 101.0, 102.0, 103.0]       # a returned batch result materialises ITS OWN values ...
+    assert len(ev._pending) == 2 and list(r0["mode_re"]) == [0.25, 1.25, 2.25, 3.25]      # ... without touching the evaluator's arrays
+    assert not ev._arrays["mode_mpjpe"][:8].any()
     assert set(r0.keys()) == {"mode_mpjpe", "mode_re", "mode_pve"} and r0.get("nope") is None and len(r0.get("mode_pve")) == 4
+    assert type(r0.to_dict()) is dict and list(r0.to_dict()["mode_pve"]) == [0.5, 1.5, 2.5, 3.5]
+    ev(out, batch)                                                      # max_pending (3) batches: flushed without being asked
+    assert len(ev._pending) == 0 and ev._arrays["mode_mpjpe"][4] == 100.0
     ev(out, batch)
     ev(out, batch)
     assert len(ev._pending) == 2
-    ev(out, batch)                                                      # max_pending batches: flushed without being asked
-    assert len(ev._pending) == 0 and ev._arrays["mode_pve"][16] == 400.5
-    ev(out, batch)
     assert hasattr(ev, "mode_pve") and not hasattr(ev, "mode_nope")
-    assert ev.mode_mpjpe[20] == 500.0 and len(ev._pending) == 0          # reading a metric array is "looking"
+    assert ev.mode_pve[16] == 400.5 and len(ev._pending) == 0            # reading a metric array is "looking": it fills the host arrays
+    ev(out, batch)
+    assert ev.mode_mpjpe[20] == 500.0 and len(ev._pending) == 0
+    r5 = ev(out, batch)
+    ev.mode_mpjpe = np.full((100,), -1.0)                                # merge_evaluator replaces the arrays: a batch result read AFTERWARDS is still its own
+    assert list(r5["mode_mpjpe"]) == [600.0, 601.0, 602.0, 603.0]
+    ev.mode_mpjpe = np.concatenate([np.array([b * 100.0 + i for b in range(6) for i in range(4)]), np.zeros(76)])
+    ev.counter = 24
+    eager = EV.Evaluator(dataset_length=10, keypoint_list=[0, 1], pelvis_ind=0, metrics=["mode_re", "mode_mpjpe"], eager_results=True)
+    re = eager({"pred_keypoints_3d": torch.zeros(2, 44, 3)}, {"keypoints_3d": torch.zeros(2, 44, 4), "imgname": []})
+    assert type(re) is dict and set(re) == {"mode_mpjpe", "mode_re"} and re["mode_re"].shape == (2,)
     d = ev.get_metrics_dict()
     assert abs(d["mode_mpjpe"] - np.mean([b * 100 + i for b in range(6) for i in range(4)])) < 1e-9
     ev.mode_re = np.full((100,), 7.0)                                    # merge_evaluator (dist.py) replaces arrays wholesale

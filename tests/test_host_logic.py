@@ -537,31 +537,35 @@ def test_attention_b16_images_are_conflict_free_under_gfx950_lane_groups():
 
 
 def test_batch_metrics_is_a_faithful_read_only_mapping():
-    """the per-batch result of `Evaluator.__call__` was a dict subclass with placeholder values — `dict(res)`, `{**res}`, `==`
-    bypassed its `__getitem__`.  As a Mapping every route goes through `__getitem__`, values are copies of the batch's slice (the reference
-    returns fresh arrays, pose_utils.py:246) and stay what they were at first access."""
-    import types
+    """the per-batch result of `Evaluator.__call__`.  Round 4 returned a dict subclass with placeholder values (`dict(res)`,
+    `{**res}`, `==` bypassed its `__getitem__`); round 5's Mapping read the EVALUATOR's arrays at first access (so a read after
+    `merge_evaluator` returned the merged arrays' slice) and kept the evaluator alive.  Now: a Mapping over the batch's OWN (3, B) result,
+    every access a fresh copy (pose_utils.py:246), `to_dict()` = the reference's plain dict, `Evaluator(eager_results=True)` returns it."""
     import numpy as np
     from tokenhmr_amd.evaluator import _BatchMetrics
-    ev = types.SimpleNamespace(mode_mpjpe=np.arange(10.0), mode_re=np.arange(10.0) * 2)
-    res = _BatchMetrics(ev, 2, 5, ["mode_mpjpe", "mode_re"])
-    other = _BatchMetrics(ev, 5, 8, ["mode_mpjpe", "mode_re"])
+    own = torch.tensor([[2.0, 3.0, 4.0], [4.0, 6.0, 8.0], [0.0, 0.0, 0.0]])
+    res = _BatchMetrics(own.clone(), ["mode_mpjpe", "mode_re"])
+    other = _BatchMetrics(own.clone() + 3.0, ["mode_mpjpe", "mode_re"])
     assert list(res) == ["mode_mpjpe", "mode_re"] and len(res) == 2 and "mode_re" in res and "mode_pve" not in res
     np.testing.assert_array_equal(res["mode_mpjpe"], [2.0, 3.0, 4.0])
+    assert res["mode_mpjpe"].dtype == np.float64
     d = dict(res)
     assert set(d) == {"mode_mpjpe", "mode_re"} and d["mode_re"] is not None
     np.testing.assert_array_equal({**res}["mode_re"], [4.0, 6.0, 8.0])
     np.testing.assert_array_equal(res.get("mode_re"), [4.0, 6.0, 8.0])
     assert res.get("mode_pve") is None
     assert not np.array_equal(dict(res)["mode_mpjpe"], dict(other)["mode_mpjpe"])      # two batches are not "equal"
-    res["mode_mpjpe"][0] = -1.0                                # a caller's write does not reach the evaluator ...
-    assert ev.mode_mpjpe[2] == 2.0 and res["mode_mpjpe"][0] == 2.0
-    ev.mode_mpjpe[2] = 99.0                                    # ... and a later change of the evaluator's arrays does not reach a batch already read
+    res["mode_mpjpe"][0] = -1.0                                # a caller's write does not reach the stored values
+    assert res["mode_mpjpe"][0] == 2.0
+    assert res._dev3 is None and not hasattr(res, "_ev")       # materialised once; nothing of the evaluator is kept alive
+    plain = res.to_dict()
+    assert type(plain) is dict and set(plain) == {"mode_mpjpe", "mode_re"}
+    plain["mode_mpjpe"] = np.zeros(3)                          # the plain dict is the caller's
     assert res["mode_mpjpe"][0] == 2.0
     with pytest.raises(KeyError):
         res["nope"]
     with pytest.raises(TypeError):
-        res["mode_re"] = np.zeros(3)                           # read-only
+        res["mode_re"] = np.zeros(3)                           # the Mapping is read-only
 
 
 def test_split3_handover_epoch_protocol_model():

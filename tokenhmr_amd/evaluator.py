@@ -71,23 +71,29 @@ def regress_joints_gpu(J, verts):
 
 
 class _BatchMetrics(Mapping):
-    """What `Evaluator.__call__` returns: the reference's {'mode_mpjpe': (B,) array, ...} — filled from the device on first access
-    (eval.py:149 ignores the return value, so a batch normally never pays a device synchronisation for it).  A read-only Mapping, not a
-    dict subclass (CPython's fast paths for dict subclasses — `dict(res)`, `res.copy()`, `{**res}`, `==` — bypass an overridden
-    `__getitem__` and would hand out the placeholder values): every access goes through `__getitem__`, which returns a COPY of this
-    batch's slice as the reference does (`pose_utils.py:246` returns fresh arrays), so a caller can neither rewrite the evaluator's
-    stored metrics through it nor see them change after `merge_evaluator`."""
+    """What `Evaluator.__call__` returns by default: the reference's {'mode_mpjpe': (B,) array, ...} — filled from the device on first
+    access (eval.py:149 ignores the return value, so a batch normally never pays a device synchronisation for it).  A read-only Mapping,
+    not a dict subclass (CPython's fast paths for dict subclasses — `dict(res)`, `res.copy()`, `{**res}`, `==` — bypass an overridden
+    `__getitem__` and would hand out placeholder values).  It holds THIS batch's own (3, B) device result — not the evaluator — so its
+    values are the batch's whatever `merge_evaluator` does to the evaluator's arrays later, and it keeps nothing else alive; every access
+    returns a fresh copy, as the reference does (`pose_utils.py:246`).  `to_dict()` gives the reference's plain dict; an evaluator built
+    with `eager_results=True` returns that plain dict from every call (one device synchronisation per batch, like the reference)."""
 
-    def __init__(self, ev, lo, hi, keys):
-        self._ev, self._lo, self._hi, self._keys = ev, lo, hi, tuple(keys)
-        self._cache = {}
+    _ROWS = ("mode_mpjpe", "mode_re", "mode_pve")
+
+    def __init__(self, dev3, keys):
+        self._dev3, self._keys, self._host = dev3, tuple(keys), None
+
+    def _materialise(self):
+        if self._host is None:
+            self._host = self._dev3.cpu().numpy().astype(np.float64)       # the evaluator's arrays are float64 (np.zeros), like the reference's
+            self._dev3 = None
+        return self._host
 
     def __getitem__(self, k):
         if k not in self._keys:
             raise KeyError(k)
-        if k not in self._cache:                     # the values of THIS batch, frozen at first access
-            self._cache[k] = np.array(getattr(self._ev, k)[self._lo:self._hi], copy=True)
-        return self._cache[k].copy()
+        return self._materialise()[self._ROWS.index(k)].copy()
 
     def __iter__(self):
         return iter(self._keys)
@@ -95,8 +101,12 @@ class _BatchMetrics(Mapping):
     def __len__(self):
         return len(self._keys)
 
+    def to_dict(self):
+        """a plain dict of fresh arrays: what the reference's Evaluator.__call__ returns (isinstance(..., dict), item assignment, pickling)"""
+        return {k: self[k] for k in self._keys}
+
     def __repr__(self):
-        return "{" + ", ".join(f"{k!r}: {self[k]!r}" for k in self._keys) + "}"
+        return repr(self.to_dict())
 
 
 class Evaluator:
@@ -107,7 +117,7 @@ class Evaluator:
     to the host every batch, pose_utils.py:139-143,246)."""
 
     def __init__(self, dataset_length, keypoint_list, pelvis_ind, metrics=("mode_mpjpe", "mode_re", "model_pve"),
-                 J_regressor_24_SMPL=None, dataset="", max_pending=64):
+                 J_regressor_24_SMPL=None, dataset="", max_pending=64, eager_results=False):
         self.dataset_length = dataset_length
         self.keypoint_list = list(keypoint_list)
         self.pelvis_ind = pelvis_ind
@@ -117,6 +127,7 @@ class Evaluator:
         self._arrays = {m: np.zeros((dataset_length,)) for m in self.metrics}
         self._pending = []                       # (first sample, stacked (3, B) device tensor)
         self._max_pending = max(1, int(max_pending))
+        self._eager = bool(eager_results)        # True: __call__ returns the reference's plain dict (a device synchronisation per batch)
         self.counter = 0
         self.imgnames = []
 
@@ -175,8 +186,11 @@ class Evaluator:
                                         self.pelvis_ind, 0, output["pred_vertices"] if want_pve else None,
                                         batch["vertices"] if want_pve else None)
         B = mp.shape[0]
-        self._pending.append((self.counter, torch.stack([mp, re, pve if pve is not None else torch.zeros_like(mp)], 0)))
-        res = _BatchMetrics(self, self.counter, self.counter + B, [m for m in ("mode_mpjpe", "mode_re", "mode_pve") if m in self._arrays])
+        dev3 = torch.stack([mp, re, pve if pve is not None else torch.zeros_like(mp)], 0)
+        self._pending.append((self.counter, dev3))
+        res = _BatchMetrics(dev3, [m for m in ("mode_mpjpe", "mode_re", "mode_pve") if m in self._arrays])
+        if self._eager:
+            res = res.to_dict()
         self.counter += B
         if len(self._pending) >= self._max_pending:
             self._flush()
