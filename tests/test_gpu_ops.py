@@ -337,6 +337,49 @@ def test_gemm_split3_persistent(built_lib, cuda_dev, shape):
     assert torch.equal(ops.gemm_split3(sa, sw, variant="persist"), base)
 
 
+# few-crop shapes whose 128 x 128 grid is more than one round of 256 workgroups: qkv / fc1 at 6, 8 and 16 crops, an odd number of K tiles
+# (phases of the three-stage ring carried across segment boundaries), the smallest stream (256 tiles: every lane's ranges exactly one tile)
+PERSIST_NARROW_SHAPES = [(1152, 3840, 1280), (1536, 3840, 1280), (1536, 5120, 1280), (3072, 3840, 1280), (2048, 2048, 352), (2176, 4096, 96)]
+
+
+@pytest.mark.parametrize("shape", PERSIST_NARROW_SHAPES)
+def test_gemm_split3_persistent_narrow(built_lib, cuda_dev, shape):
+    """Round 6: 256 persistent workgroups over the stream of 128 x 128 tiles with the three-stage K ring — a tile's K
+    range shared by two workgroups at every range boundary, the raw accumulators handed over through the slab, the ring's phase carried
+    across segments — is BIT-IDENTICAL to one workgroup per tile: every epilogue, the split3 output (row-major and row-blocked),
+    repeatedly, and alternating with the 128 x 256 stream on the same workspace."""
+    import torch
+    from tokenhmr_amd import ops
+    if torch.cuda.get_device_properties(cuda_dev).multi_processor_count != 256:
+        pytest.skip("the persistent decomposition is 8 XCDs x 32 CUs")
+    M, N, K = shape
+    a, w, b = _rand(M, K, seed=51), _rand(N, K, seed=52, scale=1 / math.sqrt(K)), _rand(N, seed=53)
+    a[:, ::7] *= 30.0
+    da, dw, db = a.to(cuda_dev), w.to(cuda_dev), b.to(cuda_dev)
+    dr = _rand(M, N, seed=54).to(cuda_dev)
+    sa, sw = ops.split3(da), ops.split3(dw)
+    base = ops.gemm_split3(sa, sw, variant="128x256/w8")
+    for rep in range(3):
+        o = ops.gemm_split3(sa, sw, variant="persist/128x128")
+        assert torch.equal(o, base), (rep, int((o != base).sum()), (o - base).abs().max().item())
+    for epi, kw in (("bias", {}), ("bias_gelu", {}), ("bias_resid", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
+        rr = dr if epi == "bias_resid" else None
+        want = ops.gemm_split3(sa, sw, db, rr, epi=epi, variant="128x256/w8", **kw)
+        got = ops.gemm_split3(sa, sw, db, rr, epi=epi, variant="persist/128x128", **kw)
+        assert torch.equal(got, want), (epi, int((got != want).sum()))
+    for epi in ("none", "bias_gelu"):
+        bb = None if epi == "none" else db
+        for blocked in (False, True):
+            want = ops.gemm_split3(sa, sw, bb, epi=epi, variant="128x256/w8", out_split=True, out_blocked=blocked)
+            got = ops.gemm_split3(sa, sw, bb, epi=epi, variant="persist/128x128", out_split=True, out_blocked=blocked)
+            assert torch.equal(got, want), (epi, blocked, int((got != want).sum()))
+    if M * N // (128 * 256) >= 256 and N % 256 == 0:
+        assert torch.equal(ops.gemm_split3(sa, sw, variant="persist"), base)          # the 128 x 256 stream on the same workspace in between
+        assert torch.equal(ops.gemm_split3(sa, sw, variant="persist/128x128"), base)
+    with pytest.raises(Exception):
+        ops.gemm_split3(ops.split3(da[:640].contiguous()), sw[:1280].contiguous(), variant="persist/128x128")      # 5 x 10 tiles: fewer than 256
+
+
 # (M, N, K) whose 128 x 256 tile count T divides by 8 and leaves, per XCD (q = T / 8 tiles on 32 CUs), 1 ... 16 tiles after the full rounds:
 # fc1 of a 64-crop batch (q = 240 = 7 x 32 + 16), qkv / proj of 48 crops (q = 135 = 4 x 32 + 7; q = 45 = 32 + 13), a ragged-M case with 3 K tiles
 TAIL_SHAPES = [(12288, 5120, 1280), (9216, 3840, 1280), (9216, 1280, 1280), (12238, 5120, 96)]

@@ -381,13 +381,16 @@ int launch_gemm_split3_splitk(const GemmArgs& a, int ksplit, float* part, hipStr
 size_t gemm_split3_persist_ws_bytes();
 bool gemm_split3_persist_ok(const GemmArgs& a);        // shape served by the persistent kernel (M % 128, N % 256, >= 256 tiles, no split-K)
 int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws, hipStream_t s);
+// round 6: the same stream over 128 x 128 tiles with the three-stage K ring (few crops: 257 ... kPersistNarrowMaxTiles tiles of 128 x 128)
+bool gemm_split3_persist_narrow_ok(const GemmArgs& a);   // M % 128, N % 128, >= 256 tiles of 128 x 128, row-major A, no split-K
+int launch_gemm_split3_persist_narrow(const GemmArgs& a, int epi, void* ws, hipStream_t s);
 int gemm_split3_persist_error(void* ws, hipStream_t s, unsigned* err_out);   // synchronises s; *err_out != 0: a hand-over spin timed out
 int gemm_split3_persist_bind_host_err(void* ws, unsigned* const* host_err_slot, hipStream_t s);   // a timed-out consumer ALSO writes the host-mapped word *slot (slot: stable storage; after zeroing ws)
 void* gemm_split3_persist_op_ws(hipStream_t s);        // zeroed workspace per (device, stream) for the stateless operators
 // gemm_split16.hip: the split3 GEMM on v_mfma_f32_16x16x32_bf16 (what launch_gemm_split3 / _splitk / _persist run since round 4):
 // one workgroup per tile (wide = 128 x 256 on 8 waves, else 128 x 128 on 4; a.ksplit copies of the grid) or 256 persistent workgroups
 int launch_split16_tiles(const GemmArgs& a, int epi, int shape, hipStream_t s);      // shape 0: 128 x 256 / 8 waves, 1: 128 x 128 / 4 waves, 2: 128 x 128 / 8 waves
-int launch_split16_persist(const GemmArgs& a, int epi, void* ws, hipStream_t s);
+int launch_split16_persist(const GemmArgs& a, int epi, void* ws, bool narrow, hipStream_t s);
 // the wide grid with its ragged last round as 128 x 128 half tiles; 0 launched, 1 = does not apply to this shape (nothing launched), < 0 error
 int launch_split16_tiles_tail(const GemmArgs& a, int epi, int cus, bool tail8, hipStream_t s);
 // small-M split3 GEMM (64x64 tiles, LDS-DMA ring, optional split-K into part[ksplit][M][N] without epilogue)

@@ -120,6 +120,11 @@ struct thmr_engine {
     int vit_gemm_mode = 1;
     bool split3_small = false;        // THMR_SPLIT3_SMALL=1: the split3 mode also serves up to six crops (ring kernel on split3 operands) — measured SLOWER, A/B only
     int split3_fc2_split = 2;         // THMR_SPLIT3_FC2_SPLIT=1: fc2 of the split3 mode unsplit from 16 crops on (A/B only)
+    // round 6: qkv (bit 0), fc1 (bit 1) and proj (bit 2) of few-crop calls as 256 persistent workgroups over the 128 x 128 tile stream (three-stage ring) when
+    // that grid is more than one round, at most s3_pn_max tiles, and the 128 x 256 grid would fill its rounds to at most s3_pn_fill per cent (gemm_split16.hip launch_split16_persist narrow); bit-identical to the
+    // per-tile kernels.  THMR_SPLIT3_PN_MASK / THMR_SPLIT3_PN_MAX (experiments build)
+    int s3_pw_fill = 72;              // the 128 x 256 stream for qkv when its per-tile grid fills its rounds to at most this many per cent (THMR_SPLIT3_PW_FILL)
+    int s3_pn_mask = 3, s3_pn_max = 600, s3_pn_fill = 72;      // s3_pn_fill: use the stream when the 128 x 256 grid fills its rounds to at most this many per cent
     int s3_tile_opts = 0;             // GemmArgs::tile_opts of the split3 GEMMs (THMR_SPLIT3_NARROW8=1 -> 1, THMR_SPLIT3_TAIL8=1 -> 2; A/B only)
     int split3_min_b = 0;             // THMR_SPLIT3_MIN_B=<n>: A/B knob for the smallest batch the split3 mode serves (0 = kSplit3LowMinB)
     char* split_w = nullptr;          // split3 weight copies: shared, reference-counted, among the engines of one weight arena (split_share())
@@ -557,6 +562,26 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             static const bool no_blk = [] { const char* k = thmr_knob("THMR_SPLIT3_BS_BLK"); return k && k[0] == '0'; }();      // A/B (experiments build)
             if (no_blk) bs_blk = 0;
         }
+        // The 128 x 128 grid is more than one round of 256 workgroups, and the 128 x 256 grid it would otherwise run fills its rounds badly:
+        // then the stream over 128 x 128 tiles wins (a K tile costs it ~1.3 us + ~10 us per launch, against 2.15 us per wide K tile and whole
+        // rounds).  Measured per class, same box (profiles/r6k_*): qkv at 6 / 12 crops (135 / 270 wide tiles, rounds 53 % full) 2.75 -> 2.13 and
+        // 4.87 -> 3.64 ms per call, fc1 at 6 / 10 crops (70 % / 59 %) 2.92 -> 2.63 and 5.10 -> 3.94; at 8 crops qkv (70 %) 2.70 -> 2.62; it
+        // LOSES where the wide rounds are full (fc1 at 8 crops, 94 %: +0.26; qkv at 10, 88 %: +0.34) and from ~700 tiles on (qkv at 16: +0.25).
+        auto narrow_stream = [&](const GemmArgs& a) {
+            const long rows = (a.M + 127) / 128, t128 = rows * ((a.N + 127) / 128), wide = rows * ((a.N + 255) / 256);
+            const long rounds = (wide + 255) / 256;
+            return e->s3_ws && e->s3_persist && t128 > 256 && t128 <= e->s3_pn_max && 100 * wide <= e->s3_pn_fill * 256 * rounds &&
+                   gemm_split3_persist_narrow_ok(a);
+        };
+        // ... and the stream over 128 x 256 tiles (round 4's persistent kernel; until round 6 fc2's only, where it wins at every size) for qkv
+        // too WHEN its one-workgroup-per-tile grid fills its rounds badly and the 128 x 128 stream above does not apply: at 64 crops (94 % full)
+        // the hand-overs cost qkv +6 %; at 24 crops its 540 tiles are 2.1 rounds = three rounds of time: 7.49 -> 6.93 ms per call, at 14 crops
+        // (315 tiles, 62 %) 5.02 -> 4.45 (profiles/r6m_*).  Not for fc1 / proj: measured equal or slower (fc1's GELU + split3 epilogue spills
+        // in the persistent form: +0.16 ms at 12 crops where its rounds are 70 % full; proj +0.12 at 36)
+        auto wide_stream = [&](const GemmArgs& a) {
+            const long wide = (long)((a.M + 127) / 128) * ((a.N + 255) / 256), rounds = (wide + 255) / 256;
+            return e->s3_ws && e->s3_persist && wide >= 256 && 100 * wide <= e->s3_pw_fill * 256 * rounds && gemm_split3_persist_ok(a);
+        };
         auto gemm_s = [&](int cls, const char* A, int K, const char* Wt, const float* bias, const float* resid, float* C, int N, int epi, int a_blk = 0) -> int {
             ProfScope ps(e, st, cls, 2.0 * M * (double)N * K, 6.0 * ((double)M * K + (double)N * K) + 4.0 * M * N * (resid ? 2.0 : 1.0));
             GemmArgs a = mk(reinterpret_cast<const float*>(A), K, reinterpret_cast<const float*>(Wt), K, bias, resid, N, C, N, M, N, K);
@@ -565,6 +590,9 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             a.tile_opts = e->s3_tile_opts;
             const int bit = cls == THMR_PROF_GEMM_QKV ? 1 : cls == THMR_PROF_GEMM_PROJ ? 2 : cls == THMR_PROF_GEMM_FC2 ? 8 : 0;
             if (e->s3_ws && e->s3_persist && (e->s3_persist_mask & bit) && gemm_split3_persist_ok(a)) return launch_split3_persist_serialised(e, a, epi, 0, st);
+            if ((cls == THMR_PROF_GEMM_QKV && (e->s3_pn_mask & 1)) || (cls == THMR_PROF_GEMM_PROJ && (e->s3_pn_mask & 4)))
+                if (narrow_stream(a)) return launch_gemm_split3_persist_narrow(a, epi, e->s3_ws, st);
+            if (cls == THMR_PROF_GEMM_QKV && wide_stream(a)) return launch_split3_persist_serialised(e, a, epi, 0, st);
             return launch_gemm_split3(a, epi, -1, st);
         };
         {
@@ -603,6 +631,8 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 a.tile_opts = e->s3_tile_opts;
                 if (e->s3_ws && e->s3_persist && e->s3_fc1_mode && (e->s3_persist_mask & 4) && gemm_split3_persist_ok(a))
                     LAUNCH_OK(launch_split3_persist_serialised(e, a, EPI_BIAS_GELU, 2, st));
+                else if ((e->s3_pn_mask & 2) && narrow_stream(a))
+                    LAUNCH_OK(launch_gemm_split3_persist_narrow(a, EPI_BIAS_GELU, e->s3_ws, st));
                 else
                     LAUNCH_OK(launch_gemm_split3(a, EPI_BIAS_GELU, -1, st));
             }
@@ -1291,6 +1321,10 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* n8 = thmr_knob("THMR_SPLIT3_NARROW8"); if (n8 && n8[0] == '1') e->s3_tile_opts |= 1; }
     { const char* t8 = thmr_knob("THMR_SPLIT3_TAIL8"); if (t8 && t8[0] == '1') e->s3_tile_opts |= 2; }
     { const char* r3 = thmr_knob("THMR_SPLIT3_RING3"); if (r3 && r3[0] == '0') e->s3_tile_opts |= 4; }
+    { const char* pm = thmr_knob("THMR_SPLIT3_PN_MASK"); if (pm) e->s3_pn_mask = atoi(pm); }
+    { const char* px = thmr_knob("THMR_SPLIT3_PN_MAX"); if (px) e->s3_pn_max = atoi(px); }
+    { const char* pf = thmr_knob("THMR_SPLIT3_PN_FILL"); if (pf) e->s3_pn_fill = atoi(pf); }
+    { const char* pw = thmr_knob("THMR_SPLIT3_PW_FILL"); if (pw) e->s3_pw_fill = atoi(pw); }
     { const char* sp = thmr_knob("THMR_SPLIT3_PERSIST"); if (sp && sp[0] >= '0' && sp[0] <= '1') e->s3_persist = sp[0] - '0'; }
     { const char* fm = thmr_knob("THMR_SPLIT3_FC1_MODE"); if (fm && fm[0] >= '0' && fm[0] <= '2') e->s3_fc1_mode = fm[0] - '0'; }
     { const char* mk_ = thmr_knob("THMR_SPLIT3_PERSIST_MASK"); if (mk_) e->s3_persist_mask = atoi(mk_); }
@@ -1872,12 +1906,20 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
             return fail(e, THMR_ERR_INVALID, "split3 GEMM with a row-blocked A: variants 1000, 1002, 1006, 1008, 1202, 1204, 1300 and epilogues 0 / 4 only");
     }
     if (!(variant >= -1 && variant <= 9) && variant != 31 && variant != 32 && variant != 34 && variant != 37 && !(variant >= 100 && variant <= 102) &&
-        variant != 202 && variant != 204 && variant != 300 && variant != 20 && variant != 22 && variant != 310)
+        variant != 202 && variant != 204 && variant != 300 && variant != 320 && variant != 20 && variant != 22 && variant != 310)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 2, 6 (128 x 128 on 8 waves), 8 (128 x 128, three-stage ring), 5 / 7 (half-tile tail on 4 / 8 waves), 202, 204, 300; experiments build: 1, 4, 20, 22, 100-102, 310 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, resid, ldc, C, ldc, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
     a.a_blk = a_blk;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (variant == 320) {      // round 6: the persistent stream over 128 x 128 tiles with the three-stage ring
+        if (!gemm_split3_persist_narrow_ok(a)) return fail(e, THMR_ERR_INVALID, "persistent 128 x 128 split3 GEMM: M % 128 == 0, N % 128 == 0, >= 256 tiles, K >= 96, row-major A");
+        if (!device_has_256_cus()) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM: its 8 x 32 workgroup decomposition needs a 256-CU device");
+        void* ws = gemm_split3_persist_op_ws(st);
+        if (!ws) return fail(e, THMR_ERR_NOMEM, "persistent split3 GEMM: workspace allocation failed");
+        LAUNCH_OK(launch_gemm_split3_persist_narrow(a, epi, ws, st));
+        return 0;
+    }
     if (variant == 300 || variant == 310) {
         // 256 persistent workgroups over a tile stream: M % 128 == 0, N % 256 == 0, at least 256 tiles.  300 = the product kernel (gemm_split16.hip),
         // 310 = the round-4 first version on 32x32x16 MFMAs (gemm_split_persist.hip; experiments build)
@@ -1961,12 +2003,20 @@ int thmr_op_gemm_split3_out_split3(const void* A, int64_t lda, const void* W, in
         cs_blk = 1;
         variant -= 1000;
     }
-    if ((variant < -1 || variant > 2) && variant != 4 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && variant != 100 && variant != 20 && variant != 22 && variant != 302 && variant != 311 && variant != 312)
+    if ((variant < -1 || variant > 2) && variant != 4 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && variant != 100 && variant != 20 && variant != 22 && variant != 302 && variant != 320 && variant != 311 && variant != 312)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 2, 6, 5 / 7 (half-tile tail), 302 (persistent workgroups); experiments build: 1, 4, 20, 22, 100 (ring kernel), 311 / 312 (32x32x16 persistent kernel: LDS / swapped-role epilogue)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, nullptr, 0, nullptr, 0, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
     a.c_split = Cs; a.ldcs = ldcs;
     a.cs_blk = cs_blk;
+    if (variant == 320) {
+        if (!gemm_split3_persist_narrow_ok(a)) return fail(e, THMR_ERR_INVALID, "persistent 128 x 128 split3 GEMM: M % 128 == 0, N % 128 == 0, >= 256 tiles, K >= 96, row-major A");
+        if (!device_has_256_cus()) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM: its 8 x 32 workgroup decomposition needs a 256-CU device");
+        void* ws = gemm_split3_persist_op_ws(static_cast<hipStream_t>(stream));
+        if (!ws) return fail(e, THMR_ERR_NOMEM, "persistent split3 GEMM: workspace allocation failed");
+        LAUNCH_OK(launch_gemm_split3_persist_narrow(a, epi, ws, static_cast<hipStream_t>(stream)));
+        return 0;
+    }
     if (variant >= 302) {
 #ifndef THMR_EXPERIMENTS
         if (variant != 302) return fail(e, THMR_ERR_INVALID, "split3 GEMM: this persistent variant exists only in the experiments build");

@@ -143,7 +143,8 @@ constexpr int split16_lds_bytes() { return NST * (QBM * ROWB + WN * NI * 16 * RO
 template <int WN, int NI, int EPI, bool PERSIST, bool ABLK, int NST = 2>
 __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles_n, int nwg, const Ws16& ws, char* smem, int given_tile, int half) {
     constexpr int NW = 2 * WN, BN = WN * NI * 16;
-    static_assert(NST == 2 || (NST == 3 && !PERSIST), "two stages, or three for the one-workgroup-per-tile decomposition");
+    static_assert((NST == 2 && (!PERSIST || WN == 4)) || (NST == 3 && WN * NI == 8 && (!PERSIST || WN == 2)),
+                  "two stages (persistent: the 128 x 256 tile), or three under the 128 x 128 tile (persistent: its four-wave form)");
     static_assert(NI == 4 || NI == 2, "wave tile 64 x 64 or 64 x 32");
     static_assert(!PERSIST || NI == 4, "the persistent decomposition uses the 64 x 64 wave tile");
     constexpr int A_Q = QBM * SLOTS / 64, B_Q = BN * SLOTS / 64;
@@ -153,7 +154,6 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     constexpr int A_KSTEP = ABLK ? SLOTS * 512 : ROWB;                 // bytes a K tile advances the A source by
     static_assert(NST * (A_STAGE + B_STAGE) <= 160 * 1024 && NST * (A_STAGE + B_STAGE) == split16_lds_bytes<WN, NI, NST>(), "LDS");
     static_assert((NST - 1) * A_STAGE + 3 * 16 * ROWB < 65536 && (NST - 1) * B_STAGE + (NI - 1) * 16 * ROWB < 65536, "fragment offsets must stay 16-bit immediates");
-    static_assert(!PERSIST || WN == 4, "the persistent decomposition uses the 128 x 256 tile");
 
     char* As = smem;
     char* Bs = smem + NST * A_STAGE;
@@ -280,6 +280,8 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     constexpr int NRB = 3 + NI;                                        // reads per block 1-3: one activation tile (3 pieces) + NI of the 3 NI weight fragments
     constexpr int DB = (NP + 2) / 3;                                   // copies per block 1-3
     static_assert(NRB + DB <= NPROD * NI, "block too small for the staging interleave");
+    int par = 0;                 // fragment set (and, with two stages, LDS buffer) of the next K tile
+    int pub_pending = 0;         // the slab's stores are issued; the flag goes out after the next K tile's barrier (every wave has drained them)
     // wait for every copy of this wave but the newest `keep` tiles' (the compiler does not count LDS-DMA copies: explicit), + its LDS reads; barrier
     auto ring_wait_barrier = [&](auto keepc) {
         constexpr int keep = decltype(keepc){};
@@ -315,11 +317,71 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
             if (mi == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (NST == 2) dma_wait_barrier();
-                else ring_wait_barrier(IntC<NST - 2>{});             // tile t + 1 has landed; the copies of t + 2 may still be in flight
+                else if constexpr (PERSIST) {
+                    // the K tile behind a slab store drains EVERYTHING (the publish that follows it relies on the stores having left, and
+                    // stores need not retire in order with the copies)
+                    if (pub_pending) dma_wait_barrier();
+                    else ring_wait_barrier(IntC<NST - 2>{});
+                } else ring_wait_barrier(IntC<NST - 2>{});           // tile t + 1 has landed; the copies of t + 2 may still be in flight
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         fetch_advance();
+    };
+    // The persistent three-stage form.  Its segments start at whatever point of the ring the previous one ended on, and stage x fragment set
+    // has period six: with both compile-time (the six-fold unrolled loop of the per-tile kernel) every segment would begin and end with up to
+    // five single steps out of a switch, whose register assignments the allocator reconciles with accumulation-register moves — measured as a
+    // first version: 1.45 us per K tile against the per-tile kernel's 1.15.  Here the STAGE is a run-time scalar (three stage offsets added to
+    // the per-lane fragment bases once per K tile: nine vector adds against 96 MFMAs — the one K loop of this file that carries vector
+    // instructions) and only the fragment set stays compile-time: the loop is the two-stage kernel's, two K tiles per trip.
+    int stage = 0;               // (K tiles this workgroup has multiplied) mod NST
+    auto ktile_rt = [&](auto setc) {
+        constexpr int set = decltype(setc){};
+        static_assert(!ABLK, "row-major A only");
+        const int nstage = stage == NST - 1 ? 0 : stage + 1;
+        uint32_t ac[3], an[3], wn[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            ac[pc] = foa[pc] + (uint32_t)(stage * A_STAGE);
+            an[pc] = foa[pc] + (uint32_t)(nstage * A_STAGE);
+            wn[pc] = fow[pc] + (uint32_t)(nstage * B_STAGE);
+        }
+        const uint32_t dA = lds_addr_b(As) + (uint32_t)(stage * A_STAGE), dB = lds_addr_b(Bs) + (uint32_t)(stage * B_STAGE);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+            for (int p = 0; p < NPROD; ++p)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int idx = p * NI + ni;
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[set][ni][piece_w(p)], af[mi][piece_a(p)], acc[mi][ni], 0, 0, 0);
+                    bool any = false;
+                    if (mi == 0) {
+                        if (idx < 3) { af[3][idx] = *reinterpret_cast<lds_frag_ptr>((uintptr_t)(ac[idx] + (uint32_t)(3 * 16 * ROWB))); any = true; }
+                    } else {
+                        if (idx < 3) { af[mi - 1][idx] = *reinterpret_cast<lds_frag_ptr>((uintptr_t)(an[idx] + (uint32_t)((mi - 1) * 16 * ROWB))); any = true; }
+                        else if (idx < NRB) {
+                            const int q = (mi - 1) * NI + (idx - 3);
+                            wf[set ^ 1][q / 3][q % 3] = *reinterpret_cast<lds_frag_ptr>((uintptr_t)(wn[q % 3] + (uint32_t)((q / 3) * 16 * ROWB)));
+                            any = true;
+                        } else if (idx - NRB < DB && (mi - 1) * DB + (idx - NRB) < NP) {
+                            const int pp = (mi - 1) * DB + (idx - NRB);
+                            if (pp < A_P) dma16_saddr(fA, Aoff[pp], dA + (uint32_t)((wave + pp * NW) * 1024));
+                            else dma16_saddr(fW, Woff[pp - A_P], dB + (uint32_t)((wave + (pp - A_P) * NW) * 1024));
+                            any = true;
+                        }
+                    }
+                    if (any) __builtin_amdgcn_sched_barrier(0);
+                }
+            if (mi == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (pub_pending) dma_wait_barrier();                 // behind a slab store: drain everything (see ktile)
+                else ring_wait_barrier(IntC<NST - 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        fetch_advance();
+        stage = nstage;
     };
     // fill: the first two K tiles of segment n into buffers 0 / 1, every fragment of tile 0 into registers
     auto fill = [&](int n) {
@@ -350,8 +412,6 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ws.part, 0, Q_NWG * Q_SLAB * 4, 0x00020000);
     const uint32_t slab_lane = (uint32_t)(wave * 16 * 1024 + lane * 16);       // a wave's 16 accumulators of 1 KiB each
-    int par = 0;                 // buffer of the next K tile
-    int pub_pending = 0;         // the slab's stores are issued; the flag goes out after the next K tile's barrier (every wave has drained them)
     __shared__ uint32_t pub_slot[4];          // {flag address lo, hi, epoch}: what the cold publish branch needs, parked in LDS so that NOTHING
                                               // but `pub_pending` is live across the K loop on its behalf (see the measurements above)
     // this launch's epoch (see Ws16): read once (requested here, consumed after the first fill so that its round trip runs under the
@@ -434,7 +494,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
             }
         };
         int cnt = ke - kb;
-        if constexpr (NST == 3) {
+        if constexpr (NST == 3 && !PERSIST) {
             // one segment per workgroup: stage = t mod 3, fragment set = t mod 2
             for (; cnt >= 6; cnt -= 6) {
                 ktile(IntC<0>{}, IntC<0>{});
@@ -449,6 +509,20 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
             if (cnt > 2) ktile(IntC<2>{}, IntC<0>{});
             if (cnt > 3) ktile(IntC<0>{}, IntC<1>{});
             if (cnt > 4) ktile(IntC<1>{}, IntC<0>{});
+        } else if constexpr (NST == 3) {
+            // persistent: run-time stage, fragment set = par (the two-stage kernel's loop)
+            if (cnt > 0 && par) {
+                ktile_rt(IntC<1>{});
+                after_tile();
+                --cnt; par = 0;
+            }
+            for (; cnt >= 2; cnt -= 2) {
+                ktile_rt(IntC<0>{});
+                after_tile();
+                ktile_rt(IntC<1>{});
+                after_tile();
+            }
+            if (cnt) { ktile_rt(IntC<0>{}); after_tile(); par = 1; }
         } else {
             if (cnt > 0 && par) {
                 ktile(IntC<1>{}, IntC<1>{});
@@ -558,7 +632,19 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                             if (t < NI) read_w(buf, buf, t, pc);
                         }
                 };
-                if (par) refill(IntC<1>{}); else refill(IntC<0>{});
+                if constexpr (NST == 3) {
+                    auto refill_rt = [&](auto setc) {
+                        constexpr int set = decltype(setc){};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc) {
+                                if (t < 3) af[t][pc] = *reinterpret_cast<lds_frag_ptr>((uintptr_t)(foa[pc] + (uint32_t)(stage * A_STAGE + t * 16 * ROWB)));
+                                wf[set][t][pc] = *reinterpret_cast<lds_frag_ptr>((uintptr_t)(fow[pc] + (uint32_t)(stage * B_STAGE + t * 16 * ROWB)));
+                            }
+                    };
+                    if (par) refill_rt(IntC<1>{}); else refill_rt(IntC<0>{});
+                } else if (par) refill(IntC<1>{}); else refill(IntC<0>{});
             }
         }
     }
@@ -582,6 +668,15 @@ template <int WN, int NI, int EPI, bool PERSIST, bool ABLK, int NST = 2>
 __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles_m, int tiles_n, int nwg, Ws16 ws) {
     __shared__ __attribute__((aligned(16))) char smem[split16_lds_bytes<WN, NI, NST>()];
     split16_body<WN, NI, EPI, PERSIST, ABLK, NST>(a, tiles_m, tiles_n, nwg, ws, smem, -1, -1);
+}
+
+// The persistent 128 x 128 stream (four waves, three-stage ring): its own entry point with __launch_bounds__(256) — under the 512-thread
+// bound of the kernel above (256 registers per lane) the segment bookkeeping on top of the ring's 250 registers spills 1200-1380 registers
+// to scratch; with 256 threads declared the allocator may use the accumulation registers as well (one wave per SIMD: 512 per lane).
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_split16_persist_narrow_kernel(GemmArgs a, int tiles_m, int tiles_n, int nwg, Ws16 ws) {
+    __shared__ __attribute__((aligned(16))) char smem[split16_lds_bytes<2, 4, 3>()];
+    split16_body<2, 4, EPI, true, false, 3>(a, tiles_m, tiles_n, nwg, ws, smem, -1, -1);
 }
 
 // One workgroup per 128 x 256 tile EXCEPT the ragged last round, which runs as 128 x 128 half tiles (round 5).  With T
@@ -697,11 +792,27 @@ int launch_split16_tiles_tail(const GemmArgs& a, int epi, int cus, bool tail8, h
     }
 }
 
-// 256 persistent workgroups (gemm_split3_persist_ok shapes); ws = gemm_split3_persist_ws_bytes() of zeroed device memory
-int launch_split16_persist(const GemmArgs& a, int epi, void* ws_mem, hipStream_t s) {
+// 256 persistent workgroups (gemm_split3_persist_ok shapes); ws = gemm_split3_persist_ws_bytes() of zeroed device memory.
+// narrow (round 6): the same tile stream over 128 x 128 tiles on four waves with the three-stage K ring (gemm_split3_persist_narrow_ok
+// shapes) — for the few-crop calls whose 128 x 128 grid is MORE than one round (257 ... ~1000 tiles): 1.4 rounds of one-workgroup-per-tile
+// cost two K-loop latencies, the stream costs 1.4.
+int launch_split16_persist(const GemmArgs& a, int epi, void* ws_mem, bool narrow, hipStream_t s) {
     if (a.c_split != nullptr && epi == EPI_BIAS_RESID) return -1;
     Ws16 ws;
     ws.part = reinterpret_cast<float*>(ws_mem);
     ws.flag = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws_mem) + (size_t)Q_NWG * Q_SLAB * 4);
+    if (narrow) {
+        if (a.a_blk) return -1;
+        const int tiles_m = a.M / 128, tiles_n = a.N / 128;
+        switch (epi) {      // what the engine runs this way: qkv, fc1 (split3 output), and raw / bias / residual for the tests
+            case EPI_NONE: hipLaunchKernelGGL((gemm_split16_persist_narrow_kernel<EPI_NONE>), dim3(Q_NWG), dim3(256), 0, s, a, tiles_m, tiles_n, Q_NWG, ws); break;
+            case EPI_BIAS: hipLaunchKernelGGL((gemm_split16_persist_narrow_kernel<EPI_BIAS>), dim3(Q_NWG), dim3(256), 0, s, a, tiles_m, tiles_n, Q_NWG, ws); break;
+            case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_split16_persist_narrow_kernel<EPI_BIAS_GELU>), dim3(Q_NWG), dim3(256), 0, s, a, tiles_m, tiles_n, Q_NWG, ws); break;
+            case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm_split16_persist_narrow_kernel<EPI_BIAS_RESID>), dim3(Q_NWG), dim3(256), 0, s, a, tiles_m, tiles_n, Q_NWG, ws); break;
+            case EPI_BIAS_QSCALE: hipLaunchKernelGGL((gemm_split16_persist_narrow_kernel<EPI_BIAS_QSCALE>), dim3(Q_NWG), dim3(256), 0, s, a, tiles_m, tiles_n, Q_NWG, ws); break;
+            default: return -1;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     return dispatch16<4, 4, true>(a, epi, ws, s);
 }

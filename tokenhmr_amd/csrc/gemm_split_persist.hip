@@ -411,7 +411,7 @@ int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws_me
     if (!gemm_split3_persist_ok(a) || ws_mem == nullptr) return -1;
     if (mode == 0 || mode == 2) {
         if ((mode == 0) != (a.c_split == nullptr)) return -1;
-        return launch_split16_persist(a, epi, ws_mem, s);
+        return launch_split16_persist(a, epi, ws_mem, false, s);
     }
 #ifndef THMR_EXPERIMENTS
     return -1;
@@ -445,6 +445,20 @@ int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws_me
 #undef THMR_PERSIST_CASE
     return -1;
 #endif  // THMR_EXPERIMENTS
+}
+
+bool gemm_split3_persist_narrow_ok(const GemmArgs& a) {
+    if (a.M <= 0 || a.N <= 0 || a.K < 3 * SBK || (a.K % SBK) != 0 || (a.M % 128) != 0 || (a.N % 128) != 0) return false;
+    if ((int64_t)(a.M / 128) * (a.N / 128) < P_NWG) return false;                  // every lane's list holds >= 8 tiles: a range >= one tile
+    if ((a.lda % 8) != 0 || (a.ldw % 8) != 0 || a.lda * 6 * 128 >= (int64_t(1) << 32) || a.ldw * 6 * 128 >= (int64_t(1) << 32)) return false;
+    if (a.cs_out != nullptr || a.ksplit > 1 || a.a_blk) return false;
+    if (a.c_split != nullptr && ((a.N % 8) != 0 || (a.ldcs % 8) != 0 || a.ldcs < a.N)) return false;
+    return true;
+}
+
+int launch_gemm_split3_persist_narrow(const GemmArgs& a, int epi, void* ws_mem, hipStream_t s) {
+    if (!gemm_split3_persist_narrow_ok(a) || ws_mem == nullptr) return -1;
+    return launch_split16_persist(a, epi, ws_mem, true, s);
 }
 
 // the workspace's error word (a consumer's bounded spin ran out): 0 = none.  Synchronises the stream.
