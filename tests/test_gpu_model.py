@@ -251,7 +251,7 @@ class _GoldenRows:
 # Every regime of the batch size (csrc/engine.hip: the association of the proj / fc2 K sums, the head's kernels) on both sides of each
 # boundary — split3: 1-2 | 3-4 | 5-15 | 16-31 | >= 32 (head: 6 | 7); f32: 1-2 | 3-6 | 7-16 | >= 17 — incl. demo.py:70's batch of 8 and
 # README.md:316's 32.
-REGIME_BATCHES = (1, 2, 3, 4, 5, 6, 7, 8, 15, 16, 17, 31, 32)
+REGIME_BATCHES = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 14, 15, 16, 17, 24, 31, 32)      # incl. the sizes whose qkv / fc1 run as tile streams (round 6: 5-7, 9, 10, 12-14, 24)
 
 
 @pytest.mark.parametrize("golden", B64_GOLDENS)
@@ -259,7 +259,7 @@ def test_full_depth_tokens_every_batch_regime(built_lib, cuda_dev, golden):
     """"bit-identical pose-token indices" 32 blocks deep at EVERY batch regime, not only at 2 and >= 32 crops.  The first
     B crops of each 64-crop depth-32 fixture (the reference's own modules, oracle/gen_golden.py) run alone, for B on both sides of every
     regime boundary, in both ViT GEMM modes: token indices equal to the reference's (0 mismatches — the same bound as at 64 crops), joints /
-    vertices / rotations / camera inside _check_b64_golden's bounds.  4 fixtures x 13 sizes x 2 modes; 160 B tokens each."""
+    vertices / rotations / camera inside _check_b64_golden's bounds.  4 fixtures x 18 sizes x 2 modes; 160 B tokens each."""
     from tokenhmr_amd.config import RELEASE
     from tokenhmr_amd.model import TokenHMR
     from tokenhmr_amd import weights as W

@@ -339,7 +339,8 @@ def test_gemm_split3_persistent(built_lib, cuda_dev, shape):
 
 # few-crop shapes whose 128 x 128 grid is more than one round of 256 workgroups: qkv / fc1 at 6, 8 and 16 crops, an odd number of K tiles
 # (phases of the three-stage ring carried across segment boundaries), the smallest stream (256 tiles: every lane's ranges exactly one tile)
-PERSIST_NARROW_SHAPES = [(1152, 3840, 1280), (1536, 3840, 1280), (1536, 5120, 1280), (3072, 3840, 1280), (2048, 2048, 352), (2176, 4096, 96)]
+PERSIST_NARROW_SHAPES = [(1152, 3840, 1280), (1536, 3840, 1280), (1536, 5120, 1280), (3072, 3840, 1280), (2048, 2048, 352), (2176, 4096, 96),
+                         (1344, 3840, 1280), (960, 5120, 1280), (2496, 3840, 160)]      # ragged M: 7 / 5 / 13 crops (192 B rows: the last row tile half full)
 
 
 @pytest.mark.parametrize("shape", PERSIST_NARROW_SHAPES)
@@ -373,7 +374,7 @@ def test_gemm_split3_persistent_narrow(built_lib, cuda_dev, shape):
             want = ops.gemm_split3(sa, sw, bb, epi=epi, variant="128x256/w8", out_split=True, out_blocked=blocked)
             got = ops.gemm_split3(sa, sw, bb, epi=epi, variant="persist/128x128", out_split=True, out_blocked=blocked)
             assert torch.equal(got, want), (epi, blocked, int((got != want).sum()))
-    if M * N // (128 * 256) >= 256 and N % 256 == 0:
+    if M % 128 == 0 and M * N // (128 * 256) >= 256 and N % 256 == 0:
         assert torch.equal(ops.gemm_split3(sa, sw, variant="persist"), base)          # the 128 x 256 stream on the same workspace in between
         assert torch.equal(ops.gemm_split3(sa, sw, variant="persist/128x128"), base)
     with pytest.raises(Exception):

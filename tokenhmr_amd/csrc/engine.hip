@@ -1913,7 +1913,7 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
     a.a_blk = a_blk;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (variant == 320) {      // round 6: the persistent stream over 128 x 128 tiles with the three-stage ring
-        if (!gemm_split3_persist_narrow_ok(a)) return fail(e, THMR_ERR_INVALID, "persistent 128 x 128 split3 GEMM: M % 128 == 0, N % 128 == 0, >= 256 tiles, K >= 96, row-major A");
+        if (!gemm_split3_persist_narrow_ok(a)) return fail(e, THMR_ERR_INVALID, "persistent 128 x 128 split3 GEMM: N % 128 == 0, >= 256 tiles, K >= 96, row-major A");
         if (!device_has_256_cus()) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM: its 8 x 32 workgroup decomposition needs a 256-CU device");
         void* ws = gemm_split3_persist_op_ws(st);
         if (!ws) return fail(e, THMR_ERR_NOMEM, "persistent split3 GEMM: workspace allocation failed");
@@ -2010,7 +2010,7 @@ int thmr_op_gemm_split3_out_split3(const void* A, int64_t lda, const void* W, in
     a.c_split = Cs; a.ldcs = ldcs;
     a.cs_blk = cs_blk;
     if (variant == 320) {
-        if (!gemm_split3_persist_narrow_ok(a)) return fail(e, THMR_ERR_INVALID, "persistent 128 x 128 split3 GEMM: M % 128 == 0, N % 128 == 0, >= 256 tiles, K >= 96, row-major A");
+        if (!gemm_split3_persist_narrow_ok(a)) return fail(e, THMR_ERR_INVALID, "persistent 128 x 128 split3 GEMM: N % 128 == 0, >= 256 tiles, K >= 96, row-major A");
         if (!device_has_256_cus()) return fail(e, THMR_ERR_INVALID, "persistent split3 GEMM: its 8 x 32 workgroup decomposition needs a 256-CU device");
         void* ws = gemm_split3_persist_op_ws(static_cast<hipStream_t>(stream));
         if (!ws) return fail(e, THMR_ERR_NOMEM, "persistent split3 GEMM: workspace allocation failed");

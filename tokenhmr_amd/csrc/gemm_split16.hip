@@ -241,6 +241,11 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
         fke = ke;
         fA = reinterpret_cast<const char*>(a.A) + (int64_t)bm0 * arow + (int64_t)kb * A_KSTEP;
         fW = reinterpret_cast<const char*>(a.W) + (int64_t)bn0 * wrow + (int64_t)kb * ROWB;
+        // the 128 x 128 stream takes a ragged M (an odd number of crops: 192 B rows): the row clamps of the LAST row tile differ, so the copy
+        // offsets follow the segment the cursor enters (a cold branch of the K loop; every other instantiation keeps one set of offsets)
+        if constexpr (PERSIST && NST == 3) {
+            if ((a.M & (QBM - 1)) != 0) set_offsets(bm0, bn0);
+        }
     };
     auto fetch_advance = [&]() {
         if (fk + 1 < fke) { ++fk; fA += A_KSTEP; fW += ROWB; }
@@ -803,7 +808,7 @@ int launch_split16_persist(const GemmArgs& a, int epi, void* ws_mem, bool narrow
     ws.flag = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws_mem) + (size_t)Q_NWG * Q_SLAB * 4);
     if (narrow) {
         if (a.a_blk) return -1;
-        const int tiles_m = a.M / 128, tiles_n = a.N / 128;
+        const int tiles_m = (a.M + 127) / 128, tiles_n = a.N / 128;
         switch (epi) {      // what the engine runs this way: qkv, fc1 (split3 output), and raw / bias / residual for the tests
             case EPI_NONE: hipLaunchKernelGGL((gemm_split16_persist_narrow_kernel<EPI_NONE>), dim3(Q_NWG), dim3(256), 0, s, a, tiles_m, tiles_n, Q_NWG, ws); break;
             case EPI_BIAS: hipLaunchKernelGGL((gemm_split16_persist_narrow_kernel<EPI_BIAS>), dim3(Q_NWG), dim3(256), 0, s, a, tiles_m, tiles_n, Q_NWG, ws); break;

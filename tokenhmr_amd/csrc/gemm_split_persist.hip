@@ -448,8 +448,8 @@ int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws_me
 }
 
 bool gemm_split3_persist_narrow_ok(const GemmArgs& a) {
-    if (a.M <= 0 || a.N <= 0 || a.K < 3 * SBK || (a.K % SBK) != 0 || (a.M % 128) != 0 || (a.N % 128) != 0) return false;
-    if ((int64_t)(a.M / 128) * (a.N / 128) < P_NWG) return false;                  // every lane's list holds >= 8 tiles: a range >= one tile
+    if (a.M <= 0 || a.N <= 0 || a.K < 3 * SBK || (a.K % SBK) != 0 || (a.N % 128) != 0) return false;      // (M may be ragged: a multiple of 192 rows)
+    if ((int64_t)((a.M + 127) / 128) * (a.N / 128) < P_NWG) return false;          // every lane's list holds >= 8 tiles: a range >= one tile
     if ((a.lda % 8) != 0 || (a.ldw % 8) != 0 || a.lda * 6 * 128 >= (int64_t(1) << 32) || a.ldw * 6 * 128 >= (int64_t(1) << 32)) return false;
     if (a.cs_out != nullptr || a.ksplit > 1 || a.a_blk) return false;
     if (a.c_split != nullptr && ((a.N % 8) != 0 || (a.ldcs % 8) != 0 || a.ldcs < a.N)) return false;
