@@ -249,7 +249,7 @@ def test_gemm_split3(built_lib, cuda_dev, shape):
     assert torch.equal(outs["128x128/w8/s3"], outs["128x256/w8"])
     for epi, kw in (("bias_gelu", {}), ("bias_resid", {}), ("bias_qscale", dict(qscale=80 ** -0.5, qcols=N // 3))):
         rr = dr if epi == "bias_resid" else None
-        for v in ("128x128/w8", "128x128/w4/s3", "128x128/w8/s3"):
+        for v in ("128x128/w8", "128x128/w4/s3", "128x128/w8/s3", "128x256/w8/front", "128x128/w4/s3/front"):
             assert torch.equal(ops.gemm_split3(sa, sw, db, rr, epi=epi, variant=v, **kw), ops.gemm_split3(sa, sw, db, rr, epi=epi, variant="128x256/w8", **kw)), (v, epi)
     # the round-3 / first round-4 kernels on 32x32x16 MFMAs (experiments build): bit-identical among themselves — 64x64 and 64x128 wave
     # tiles, the 256x256 tile, the small-M ring kernel without split-K — and equal to the product kernels to fp32 rounding (another

@@ -74,7 +74,8 @@ struct GemmArgs {
     int a_blk, cs_blk;
     // split3 GEMM, A/B only (experiments build: the engine sets it from THMR_SPLIT3_NARROW8=1 / THMR_SPLIT3_TAIL8=1 at thmr_create): bit 0 = the
     // 128 x 128 tile on eight waves of 64 x 32 instead of four of 64 x 64, bit 1 = the half-tile tail likewise (round 6: measured slower /
-    // equal, gemm_split.hip); bit 2 = the 128 x 128 tile with round 5's TWO-stage K ring instead of three stages (THMR_SPLIT3_RING3=0).  Same bits either way.
+    // equal, gemm_split.hip); bit 2 = the 128 x 128 tile with round 5's TWO-stage K ring instead of three stages (THMR_SPLIT3_RING3=0);
+    // bit 3 = small 128 x 256 grids keep their copies spread over the K tile (THMR_SPLIT3_FRONT=0).  Same bits either way.
     int tile_opts;
 };
 

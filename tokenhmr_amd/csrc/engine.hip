@@ -1321,6 +1321,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* n8 = thmr_knob("THMR_SPLIT3_NARROW8"); if (n8 && n8[0] == '1') e->s3_tile_opts |= 1; }
     { const char* t8 = thmr_knob("THMR_SPLIT3_TAIL8"); if (t8 && t8[0] == '1') e->s3_tile_opts |= 2; }
     { const char* r3 = thmr_knob("THMR_SPLIT3_RING3"); if (r3 && r3[0] == '0') e->s3_tile_opts |= 4; }
+    { const char* fr = thmr_knob("THMR_SPLIT3_FRONT"); if (fr && fr[0] == '0') e->s3_tile_opts |= 8; }
     { const char* pm = thmr_knob("THMR_SPLIT3_PN_MASK"); if (pm) e->s3_pn_mask = atoi(pm); }
     { const char* px = thmr_knob("THMR_SPLIT3_PN_MAX"); if (px) e->s3_pn_max = atoi(px); }
     { const char* pf = thmr_knob("THMR_SPLIT3_PN_FILL"); if (pf) e->s3_pn_fill = atoi(pf); }
@@ -1893,7 +1894,7 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: epilogue must be 0, 1, 2, 4, 5 or 6");
     if (epi != EPI_NONE && !bias) return fail(e, THMR_ERR_INVALID, "epilogue needs bias");
     if ((epi == EPI_BIAS_RESID || epi == EPI_BIAS_POS) && !resid) return fail(e, THMR_ERR_INVALID, "epilogue needs resid");
-    if (epi == EPI_BIAS_POS && ((N % 4) != 0 || (variant != -1 && variant != 0 && variant != 2 && variant != 6 && variant != 8 && variant != 9))) return fail(e, THMR_ERR_INVALID, "split3 GEMM: the pos-embed epilogue needs N % 4 == 0 and a per-tile variant (-1, 0, 2, 6, 8, 9)");
+    if (epi == EPI_BIAS_POS && ((N % 4) != 0 || (variant != -1 && variant != 0 && variant != 2 && variant != 6 && variant != 8 && variant != 9 && variant != 10 && variant != 11))) return fail(e, THMR_ERR_INVALID, "split3 GEMM: the pos-embed epilogue needs N % 4 == 0 and a per-tile variant (-1, 0, 2, 6, 8, 9)");
     if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || lda < K || ldw < K || ldc < N)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: K % 32 == 0, lda / ldw multiples of 8 and >= K, ldc >= N");
     // + 1000: A is a ROW-BLOCKED split3 operand ([M / 32][K / 8][3][32][8], rows padded to 32; GemmArgs::a_blk) — tiles 0 / 2, split-K 202 / 204
@@ -1905,7 +1906,7 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
         if ((variant != 0 && variant != 2 && variant != 6 && variant != 8 && variant != 9 && variant != 202 && variant != 204 && variant != 300) || (epi != EPI_NONE && epi != EPI_BIAS_RESID))
             return fail(e, THMR_ERR_INVALID, "split3 GEMM with a row-blocked A: variants 1000, 1002, 1006, 1008, 1202, 1204, 1300 and epilogues 0 / 4 only");
     }
-    if (!(variant >= -1 && variant <= 9) && variant != 31 && variant != 32 && variant != 34 && variant != 37 && !(variant >= 100 && variant <= 102) &&
+    if (!(variant >= -1 && variant <= 11) && variant != 31 && variant != 32 && variant != 34 && variant != 37 && !(variant >= 100 && variant <= 102) &&
         variant != 202 && variant != 204 && variant != 300 && variant != 320 && variant != 20 && variant != 22 && variant != 310)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 2, 6 (128 x 128 on 8 waves), 8 (128 x 128, three-stage ring), 5 / 7 (half-tile tail on 4 / 8 waves), 202, 204, 300; experiments build: 1, 4, 20, 22, 100-102, 310 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, resid, ldc, C, ldc, M, N, K);
@@ -1980,7 +1981,7 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
         return 0;
     }
 #else
-    if (variant >= 100 || variant == 1 || variant == 3 || variant == 4 || variant == 6 || variant == 7 || variant > 8)
+    if (variant >= 100 || variant == 1 || variant == 3 || variant == 4 || variant == 6 || variant == 7 || variant == 9 || variant > 10)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: this variant exists only in the experiments build (libtokenhmr_hip_exp.so)");
 #endif
     LAUNCH_OK(launch_gemm_split3(a, epi, variant, st));
@@ -2003,7 +2004,7 @@ int thmr_op_gemm_split3_out_split3(const void* A, int64_t lda, const void* W, in
         cs_blk = 1;
         variant -= 1000;
     }
-    if ((variant < -1 || variant > 2) && variant != 4 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && variant != 100 && variant != 20 && variant != 22 && variant != 302 && variant != 320 && variant != 311 && variant != 312)
+    if ((variant < -1 || variant > 2) && variant != 4 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && variant != 10 && variant != 11 && variant != 100 && variant != 20 && variant != 22 && variant != 302 && variant != 320 && variant != 311 && variant != 312)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 2, 6, 5 / 7 (half-tile tail), 302 (persistent workgroups); experiments build: 1, 4, 20, 22, 100 (ring kernel), 311 / 312 (32x32x16 persistent kernel: LDS / swapped-role epilogue)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, nullptr, 0, nullptr, 0, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
@@ -2035,7 +2036,7 @@ int thmr_op_gemm_split3_out_split3(const void* A, int64_t lda, const void* W, in
         return 0;
     }
 #else
-    if (variant == 100 || variant == 1 || variant == 4 || variant == 6 || variant == 7 || variant == 9 || variant >= 20)
+    if (variant == 100 || variant == 1 || variant == 4 || variant == 6 || variant == 7 || variant == 9 || variant == 11 || variant >= 20)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: this variant exists only in the experiments build (libtokenhmr_hip_exp.so)");
 #endif
     LAUNCH_OK(launch_gemm_split3(a, epi, variant, static_cast<hipStream_t>(stream)));

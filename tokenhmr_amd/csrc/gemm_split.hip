@@ -710,6 +710,14 @@ static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStrea
         }
         if (variant == 5 || variant == 7) return -1;
     }
+    if (by_rule && variant == 0 && !(a.tile_opts & 8) && !a.a_blk) {
+        // round 6: a 128 x 256 grid of at most two rounds issues every copy of a K tile right behind the barrier (gemm_split16.hip FRONT): its
+        // period is the weights' round trip, not the MFMA time.  Same box, per call (profiles/r6o_*): fc2 at 32 crops (240 tiles) 10.83 -> 10.38
+        // ms, fc1 / fc2 at 16 crops -0.12 / -0.16, fc1 at 8 -0.08; equal at 64 crops (not used there: more rounds); the three-stage
+        // 128 x 128 tile LOSES with it (12 copies in a row stall its one wave per SIMD: +0.1 ... +0.26 ms per class at 4 / 8 crops)
+        const long ks = a.ksplit > 1 ? a.ksplit : 1;
+        if ((long)((a.M + 127) / 128) * ((a.N + 255) / 256) * ks <= 512) variant = 10;
+    }
     switch (variant) {
         // round 4: the product kernels multiply on v_mfma_f32_16x16x32_bf16 (gemm_split16.hip); the 32x32x16 kernels of this file are the
         // experiments build's variants 20 / 22 (and 1, 4, 3x below) — another grouping of k inside the MFMA, so equal to rounding only
@@ -718,6 +726,8 @@ static int launch_split3_tiles(const GemmArgs& a, int epi, int variant, hipStrea
         case 6: return launch_split16_tiles(a, epi, 2, s);
         case 8: return launch_split16_tiles(a, epi, 3, s);
         case 9: return launch_split16_tiles(a, epi, 4, s);
+        case 10: return launch_split16_tiles(a, epi, 5, s);
+        case 11: return launch_split16_tiles(a, epi, 6, s);
 #ifdef THMR_EXPERIMENTS
         case 20: return launch_split3_cfg<2, 4, 2, 2>(a, epi, s);
         case 22: return launch_split3_cfg<2, 2, 2, 2>(a, epi, s);

@@ -140,7 +140,11 @@ constexpr int split16_lds_bytes() { return NST * (QBM * ROWB + WN * NI * 16 * RO
 // the weight tile several K tiles ahead of the copy cursor — one dword LDS-DMA touch per lane and K tile into a sink — is SLOWER at every
 // batch size (+2.5 % per call at 8 crops, +7.8 % at 4, +2.7 % at 16, +3.8 % at 32, +2.5 % at 64): the extra copy and the later arrival of
 // the real ones cost more than an L2 hit saves.
-template <int WN, int NI, int EPI, bool PERSIST, bool ABLK, int NST = 2>
+// FRONT (round 6): where in K tile t the copies of tile t + NST are issued.  false: spread over blocks 1-3, one every few MFMAs (the last
+// ones ~80 % into the tile: they have under half a K-tile period to land before the next tile's barrier — plenty where the period is the MFMA
+// time and the round trip short: 64 crops).  true: ALL of them in block 1, right behind the barrier that freed their stage: every copy has
+// ~0.95 of a period.  For the few-crop calls, whose period IS the round trip of cold weights (see NST).  Same results either way.
+template <int WN, int NI, int EPI, bool PERSIST, bool ABLK, int NST = 2, bool FRONT = false>
 __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles_n, int nwg, const Ws16& ws, char* smem, int given_tile, int half) {
     constexpr int NW = 2 * WN, BN = WN * NI * 16;
     static_assert((NST == 2 && (!PERSIST || WN == 4)) || (NST == 3 && WN * NI == 8 && (!PERSIST || WN == 2)),
@@ -284,7 +288,8 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     // one K tile out of buffer `buf` (weight fragment set `buf`)
     constexpr int NRB = 3 + NI;                                        // reads per block 1-3: one activation tile (3 pieces) + NI of the 3 NI weight fragments
     constexpr int DB = (NP + 2) / 3;                                   // copies per block 1-3
-    static_assert(NRB + DB <= NPROD * NI, "block too small for the staging interleave");
+    static_assert(NRB + (FRONT ? NP : DB) <= NPROD * NI, "block too small for the staging interleave");
+    static_assert(!FRONT || !PERSIST, "front-loaded copies: the per-tile decomposition");
     int par = 0;                 // fragment set (and, with two stages, LDS buffer) of the next K tile
     int pub_pending = 0;         // the slab's stores are issued; the flag goes out after the next K tile's barrier (every wave has drained them)
     // wait for every copy of this wave but the newest `keep` tiles' (the compiler does not count LDS-DMA copies: explicit), + its LDS reads; barrier
@@ -312,8 +317,11 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
                             const int q = (mi - 1) * NI + (idx - 3);
                             read_w(nbuf, set ^ 1, q / 3, q % 3);
                             any = true;
-                        } else if (idx - NRB < DB && (mi - 1) * DB + (idx - NRB) < NP) {
+                        } else if (!FRONT && idx - NRB < DB && (mi - 1) * DB + (idx - NRB) < NP) {
                             dma_piece(buf, (mi - 1) * DB + (idx - NRB));                        // K tile t + NST, into this stage
+                            any = true;
+                        } else if (FRONT && mi == 1 && idx - NRB < NP) {
+                            dma_piece(buf, idx - NRB);                                          // ... all of it right behind the barrier
                             any = true;
                         }
                     }
@@ -669,10 +677,10 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
 // (__launch_bounds__(512) for the 4-wave instantiation too: told that a workgroup has 256 threads hipcc budgets 512 registers per lane,
 // parks fragments in AGPRs and copies them back inside the K loop — ~40 v_accvgpr moves per 192 MFMAs.  A bound of 512 threads = 256
 // registers gives it the 8-wave instantiation's allocation: none.)
-template <int WN, int NI, int EPI, bool PERSIST, bool ABLK, int NST = 2>
+template <int WN, int NI, int EPI, bool PERSIST, bool ABLK, int NST = 2, bool FRONT = false>
 __global__ __launch_bounds__(512) void gemm_split16_kernel(GemmArgs a, int tiles_m, int tiles_n, int nwg, Ws16 ws) {
     __shared__ __attribute__((aligned(16))) char smem[split16_lds_bytes<WN, NI, NST>()];
-    split16_body<WN, NI, EPI, PERSIST, ABLK, NST>(a, tiles_m, tiles_n, nwg, ws, smem, -1, -1);
+    split16_body<WN, NI, EPI, PERSIST, ABLK, NST, FRONT>(a, tiles_m, tiles_n, nwg, ws, smem, -1, -1);
 }
 
 // The persistent 128 x 128 stream (four waves, three-stage ring): its own entry point with __launch_bounds__(256) — under the 512-thread
@@ -709,30 +717,31 @@ __global__ __launch_bounds__(512) void gemm_split16_tail_kernel(GemmArgs a, int 
     }
 }
 
-template <int WN, int NI, int EPI, bool PERSIST, bool ABLK, int NST>
+template <int WN, int NI, int EPI, bool PERSIST, bool ABLK, int NST, bool FRONT = false>
 int launch16(const GemmArgs& a, const Ws16& ws, hipStream_t s) {
     constexpr int BN = WN * NI * 16;
     const int tiles_m = (a.M + QBM - 1) / QBM, tiles_n = (a.N + BN - 1) / BN;
     const int nwg = PERSIST ? Q_NWG : tiles_m * tiles_n * (a.ksplit > 1 ? a.ksplit : 1);
-    hipLaunchKernelGGL((gemm_split16_kernel<WN, NI, EPI, PERSIST, ABLK, NST>), dim3(nwg), dim3(2 * WN * 64), 0, s, a, tiles_m, tiles_n, nwg, ws);
+    hipLaunchKernelGGL((gemm_split16_kernel<WN, NI, EPI, PERSIST, ABLK, NST, FRONT>), dim3(nwg), dim3(2 * WN * 64), 0, s, a, tiles_m, tiles_n, nwg, ws);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int WN, int NI, bool PERSIST, int NST = 2>
+template <int WN, int NI, bool PERSIST, int NST = 2, bool FRONT = false>
 int dispatch16(const GemmArgs& a, int epi, const Ws16& ws, hipStream_t s) {
     if (a.a_blk) {      // row-blocked A (fc2's operand): bias + residual, or no epilogue
+        if constexpr (FRONT) return -1;
         if (epi == EPI_BIAS_RESID) return launch16<WN, NI, EPI_BIAS_RESID, PERSIST, true, NST>(a, ws, s);
         if (epi == EPI_NONE) return launch16<WN, NI, EPI_NONE, PERSIST, true, NST>(a, ws, s);
         return -1;
     }
     switch (epi) {
-        case EPI_NONE: return launch16<WN, NI, EPI_NONE, PERSIST, false, NST>(a, ws, s);
-        case EPI_BIAS: return launch16<WN, NI, EPI_BIAS, PERSIST, false, NST>(a, ws, s);
-        case EPI_BIAS_GELU: return launch16<WN, NI, EPI_BIAS_GELU, PERSIST, false, NST>(a, ws, s);
-        case EPI_BIAS_RESID: return launch16<WN, NI, EPI_BIAS_RESID, PERSIST, false, NST>(a, ws, s);
-        case EPI_BIAS_QSCALE: return launch16<WN, NI, EPI_BIAS_QSCALE, PERSIST, false, NST>(a, ws, s);
+        case EPI_NONE: return launch16<WN, NI, EPI_NONE, PERSIST, false, NST, FRONT>(a, ws, s);
+        case EPI_BIAS: return launch16<WN, NI, EPI_BIAS, PERSIST, false, NST, FRONT>(a, ws, s);
+        case EPI_BIAS_GELU: return launch16<WN, NI, EPI_BIAS_GELU, PERSIST, false, NST, FRONT>(a, ws, s);
+        case EPI_BIAS_RESID: return launch16<WN, NI, EPI_BIAS_RESID, PERSIST, false, NST, FRONT>(a, ws, s);
+        case EPI_BIAS_QSCALE: return launch16<WN, NI, EPI_BIAS_QSCALE, PERSIST, false, NST, FRONT>(a, ws, s);
         case EPI_BIAS_POS:
-            if constexpr (!PERSIST) return (a.N % 4) == 0 && a.resid != nullptr && a.c_split == nullptr ? launch16<WN, NI, EPI_BIAS_POS, false, false, NST>(a, ws, s) : -1;
+            if constexpr (!PERSIST) return (a.N % 4) == 0 && a.resid != nullptr && a.c_split == nullptr ? launch16<WN, NI, EPI_BIAS_POS, false, false, NST, FRONT>(a, ws, s) : -1;
             return -1;
         default: return -1;
     }
@@ -754,7 +763,8 @@ int launch16_tail(const GemmArgs& a, int tiles_m, int tiles_n, int q, int tail_f
 }  // namespace
 
 // one workgroup per tile (and K slice): shape 0 = 128 x 256 tile on 8 waves, 1 = 128 x 128 on 4 waves, 2 = 128 x 128 on 8 waves of 64 x 32,
-// 3 = 128 x 128 on 4 waves with a THREE-stage K ring (two stages of copies in flight), 4 = the same ring under 8 waves of 64 x 32.
+// 3 = 128 x 128 on 4 waves with a THREE-stage K ring (two stages of copies in flight), 4 = the same ring under 8 waves of 64 x 32,
+// 5 / 6 = shapes 0 / 3 with every copy of a K tile issued right behind the barrier (FRONT).
 // a.ksplit > 1: raw partial sums (epi must be EPI_NONE)
 int launch_split16_tiles(const GemmArgs& a, int epi, int shape, hipStream_t s) {
     if (a.c_split != nullptr && epi == EPI_BIAS_RESID) return -1;
@@ -763,7 +773,9 @@ int launch_split16_tiles(const GemmArgs& a, int epi, int shape, hipStream_t s) {
         case 0: return dispatch16<4, 4, false>(a, epi, none, s);
         case 1: return dispatch16<2, 4, false>(a, epi, none, s);
         case 3: return dispatch16<2, 4, false, 3>(a, epi, none, s);
-#ifdef THMR_EXPERIMENTS      // the eight-wave forms lost their A/B (3-6 % slower with two stages, 2-3 % with three: profiles/r6d_*, r6g_*)
+        case 5: return dispatch16<4, 4, false, 2, true>(a, epi, none, s);      // the 128 x 256 tile with front-loaded copies (few crops)
+#ifdef THMR_EXPERIMENTS
+        case 6: return dispatch16<2, 4, false, 3, true>(a, epi, none, s);      // the three-stage 128 x 128 tile likewise: slower (profiles/r6o_*)      // the eight-wave forms lost their A/B (3-6 % slower with two stages, 2-3 % with three: profiles/r6d_*, r6g_*)
         case 2: return dispatch16<4, 2, false>(a, epi, none, s);
         case 4: return dispatch16<4, 2, false, 3>(a, epi, none, s);      // eight waves of 64 x 32 AND the three-stage ring
 #endif

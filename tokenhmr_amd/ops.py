@@ -73,7 +73,8 @@ def gemm(a, w, bias=None, resid=None, epi="none", qscale=1.0, qcols=0, variant="
 
 
 SPLIT3_VARIANT = {"auto": -1, "128x256/w8": 0, "tail": 5,        # tail: the 128x256 grid with its ragged last round as 128x128 half tiles (qualifying shapes only)
-                   "128x128/w8": 6, "tail/w8": 7, "128x128/w4/s3": 8, "128x128/w8/s3": 9,   # s3: the four-wave tile with a three-stage K ring
+                   "128x128/w8": 6, "tail/w8": 7, "128x128/w4/s3": 8, "128x128/w8/s3": 9, "128x256/w8/front": 10, "128x128/w4/s3/front": 11,   # front: every copy of a K tile issued right behind the barrier
+                      # s3: the four-wave tile with a three-stage K ring
                                    # round 6: the 128x128 tile / the tail's half tiles on eight waves of 64x32 (measured slower / equal: not the rule's choice)
                    "128x256/w4": 1, "128x128/w4": 2, "256x256/w4": 4, "ring": 100, "ring/k2": 101, "ring/k4": 102, "auto/k2": 202, "auto/k4": 204,
                   # 256 persistent workgroups over a tile stream (csrc/gemm_split_persist.hip; M % 128 == 0, N % 256 == 0, >= 256 tiles):
@@ -87,7 +88,7 @@ SPLIT3_VARIANT = {"auto": -1, "128x256/w8": 0, "tail": 5,        # tail: the 128
 
 # variants that exist only in the experiments build (measured slower or timing-only; csrc/gemm_split.hip, gemm_split_persist.hip): asking
 # for one of them routes THAT call to libtokenhmr_hip_exp.so
-SPLIT3_EXP_ONLY = {"128x128/w8", "128x128/w8/s3", "tail/w8", "128x256/w4", "256x256/w4", "ring", "ring/k2", "ring/k4", "exp/reads-every-2nd", "abl/no-copies",
+SPLIT3_EXP_ONLY = {"128x128/w4/s3/front", "128x128/w8", "128x128/w8/s3", "tail/w8", "128x256/w4", "256x256/w4", "ring", "ring/k2", "ring/k4", "exp/reads-every-2nd", "abl/no-copies",
                    "abl/no-barrier", "abl/no-reads", "abl/none", "old/128x256/w8", "old/128x128/w4", "old/persist", "old/persist/lds", "old/persist/swap"}
 
 
