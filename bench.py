@@ -808,14 +808,16 @@ def main():
             # profiles/; FETCH_SIZE doubled per the gfx950 correction) — cannot be collected live inside this process, so it is a
             # RECORDED number and labelled as such
             alg = {"gemm_fc1": (6.0 if split_mode else 4.0) * (12288 * 1280 + 5120 * 1280 + 12288 * 5120)}
-            for pmc_file in ("r5_final_pmc.json", "r4_final_pmc.json"):
+            for pmc_file in ("r6_final_pmc.json", "r5_final_pmc.json", "r4_final_pmc.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                         pj = json.load(f)
                 except (OSError, ValueError):
                     continue
                 # fc1 of a 64-crop batch runs the mixed grid (half-tile tail) since round 5; the round-4 file knows only the plain grid
-                keys = (["gemm_split16_tail_kernel<2, false>", "gemm_split16_kernel<4, 2, false, false>"] if split_mode else ["gemm_f32_kernel"]) if dom == "gemm_fc1" else []
+                # (round 6 added template parameters: the same two kernels under their new names first)
+                keys = (["gemm_split16_tail_kernel<2, false, false>", "gemm_split16_kernel<4, 4, 2, false, false, 2, false>",
+                         "gemm_split16_tail_kernel<2, false>", "gemm_split16_kernel<4, 2, false, false>"] if split_mode else ["gemm_f32_kernel"]) if dom == "gemm_fc1" else []
                 pmc = next((pj[k] for k in keys if k in pj), None)
                 if pmc and a.batch == 64 and a.workload in ("full", "vit"):
                     roof["traffic"] = round(pmc["traffic_bytes"])

@@ -438,9 +438,13 @@ int launch_vit_attention_b16(const float* qkv, void* out, int B, bool out_split,
     float* o = reinterpret_cast<float*>(out);
     const int nitems = B * NH * (3 / qt);                        // a multiple of 16: the kernel splits items and grid by the 8 XCDs
     static_assert(NH % 8 == 0, "items per crop must divide by the XCD count");
-    const dim3 grid(nitems < 512 ? nitems : 512);
+    dim3 grid(nitems < 512 ? nitems : 512);
 #ifdef THMR_EXPERIMENTS
     {
+        // THMR_ATTN_GRID=<n>: cap the grid (256 = ONE workgroup per CU: how much do the two co-resident workgroups overlap each other?)
+        const char* gk = thmr_knob("THMR_ATTN_GRID");
+        const int gcap = gk ? atoi(gk) : 0;
+        if (gcap >= 8 && (gcap % 8) == 0 && (unsigned)gcap < grid.x) grid = dim3(gcap);
         const char* ek = thmr_knob("THMR_ATTN_EARLY");
         const int early = ek ? atoi(ek) : 0;
         if (early > 0 && qt == 3 && out_split) {
