@@ -23,13 +23,14 @@ g = torch.Generator().manual_seed(77)
 qkv = torch.randn(B, 192, 3840, generator=g)
 qkv[:, :, :1280] *= 80 ** -0.5
 d = qkv.to(dev)
-variants = [0, 1, 2, 3, 4, 5, 7, "e1", "e2", "e3", "g256", "g128"]      # eN: THMR_ATTN_EARLY=N (real results: K / V requested N-1 k steps into the S phase)
+variants = [0, 1, 2, 3, 4, 5, 7, "e1", "e2", "e3", "g256", "g128", "o0", "o1", "o2", "o3"]      # oN: compiled for one workgroup per CU (512 registers), THMR_ATTN_EARLY=N      # eN: THMR_ATTN_EARLY=N (real results: K / V requested N-1 k steps into the S phase)
 ts = {v: [] for v in variants}
 
 
 def run(v):
     os.environ["THMR_ATTN_ABL"] = "0" if isinstance(v, str) else str(v)
-    os.environ["THMR_ATTN_EARLY"] = v[1:] if isinstance(v, str) and v[0] == "e" else "0"
+    os.environ["THMR_ATTN_EARLY"] = v[1:] if isinstance(v, str) and v[0] in "eo" else "0"
+    os.environ["THMR_ATTN_OCC"] = "1" if isinstance(v, str) and v[0] == "o" else "0"
     os.environ["THMR_ATTN_GRID"] = v[1:] if isinstance(v, str) and v[0] == "g" else "0"      # gN: at most N workgroups (256 = one per CU)
     return ops.vit_attention_b16(d, out_split=True, qt=3)
 
@@ -52,6 +53,7 @@ early_equal = {v: bool(torch.equal(run(v), ref)) for v in variants if isinstance
 os.environ["THMR_ATTN_ABL"] = "0"
 os.environ["THMR_ATTN_EARLY"] = "0"
 os.environ["THMR_ATTN_GRID"] = "0"
+os.environ["THMR_ATTN_OCC"] = "0"
 res = {"B": B, "iters": iters, "reps": reps,
        "us_per_launch_median": {str(v): round(statistics.median(t), 2) for v, t in ts.items()},
        "us_per_launch_min": {str(v): round(min(t), 2) for v, t in ts.items()},

@@ -69,8 +69,11 @@ __device__ __forceinline__ bf16x8 pieces8(uint32_t a, uint32_t b, uint32_t c, ui
 // EARLY (experiments build, round 6): the block's V and the next block's K are requested at the START of the S^T phase's k step EARLY - 1
 // (1 = before step 0, 2 = before step 1, 3 = before step 2) instead of after it — a whole MFMA phase for the loads to land instead of the
 // softmax's ~270 vector instructions; 40 more registers live through the phase.
-template <int QT, bool SPLIT, int ABL = 0, int EARLY = 0>
-__global__ __launch_bounds__(256, 2) void vit_attention_b16_kernel(const float* __restrict__ qkv, float* __restrict__ out, int nitems) {
+// OCC (round 6 experiment): workgroups per CU the kernel is COMPILED for.  2 = 256 registers per wave (what ships); 1 = one workgroup per CU
+// and 512 registers (256 + 256 accumulation) per wave: the grid experiment showed the second co-resident workgroup adds only 9 %, so the
+// registers it costs may be worth more than it — no spills, and room for the earlier loads that spill at OCC 2.
+template <int QT, bool SPLIT, int ABL = 0, int EARLY = 0, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void vit_attention_b16_kernel(const float* __restrict__ qkv, float* __restrict__ out, int nitems) {
     constexpr int QB = 3 / QT;
     static_assert(QT == 1 || QT == 3, "192 queries = QB workgroups x 4 waves x QT tiles of 16");
     __shared__ __attribute__((aligned(16))) char smem[K_IMG + V_IMG];
@@ -447,6 +450,18 @@ int launch_vit_attention_b16(const float* qkv, void* out, int B, bool out_split,
         if (gcap >= 8 && (gcap % 8) == 0 && (unsigned)gcap < grid.x) grid = dim3(gcap);
         const char* ek = thmr_knob("THMR_ATTN_EARLY");
         const int early = ek ? atoi(ek) : 0;
+        const char* ok = thmr_knob("THMR_ATTN_OCC");
+        if (ok && ok[0] == '1' && qt == 3 && out_split) {      // compiled for one workgroup per CU (512 registers per wave), at most 256 workgroups
+            if (grid.x > 256) grid = dim3(256);
+            switch (early) {
+                case 0: hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, 0, 0, 1>), grid, dim3(256), 0, s, qkv, o, nitems); break;
+                case 1: hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, 0, 1, 1>), grid, dim3(256), 0, s, qkv, o, nitems); break;
+                case 2: hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, 0, 2, 1>), grid, dim3(256), 0, s, qkv, o, nitems); break;
+                case 3: hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, 0, 3, 1>), grid, dim3(256), 0, s, qkv, o, nitems); break;
+                default: return -1;
+            }
+            return hipGetLastError() == hipSuccess ? 0 : -2;
+        }
         if (early > 0 && qt == 3 && out_split) {
             switch (early) {
                 case 1: hipLaunchKernelGGL((vit_attention_b16_kernel<3, true, 0, 1>), grid, dim3(256), 0, s, qkv, o, nitems); break;
