@@ -381,6 +381,34 @@ def test_gemm_split3_persistent_narrow(built_lib, cuda_dev, shape):
         ops.gemm_split3(ops.split3(da[:640].contiguous()), sw[:1280].contiguous(), variant="persist/128x128")      # 5 x 10 tiles: fewer than 256
 
 
+# split-K launches whose (tile, K slice) units run as the 128 x 128 stream: fc2 at 9 / 18 crops and proj at 10 crops two ways, a four-way case
+SPLITK_STREAM_SHAPES = [(1728, 1280, 5120, 2), (3456, 1280, 5120, 2), (1920, 1280, 1280, 2), (1152, 1280, 5120, 4)]
+
+
+@pytest.mark.parametrize("shape", SPLITK_STREAM_SHAPES)
+def test_gemm_split3_splitk_through_the_stream(built_lib, cuda_dev, shape):
+    """Round 6: a split-K launch as (tile, K slice) units of the persistent 128 x 128 stream writes the SAME raw partial sums as the
+    grid copies of the per-tile kernel — the reduced result (fixed-order reduce + bias + residual) is bit-identical — repeatedly, ragged M
+    included; a launch with fewer than 256 units is refused."""
+    import torch
+    from tokenhmr_amd import ops
+    if torch.cuda.get_device_properties(cuda_dev).multi_processor_count != 256:
+        pytest.skip("the persistent decomposition is 8 XCDs x 32 CUs")
+    M, N, K, ks = shape
+    a, w, b = _rand(M, K, seed=61), _rand(N, K, seed=62, scale=1 / math.sqrt(K)), _rand(N, seed=63)
+    a[:, ::7] *= 30.0
+    da, dw, db = a.to(cuda_dev), w.to(cuda_dev), b.to(cuda_dev)
+    dr = _rand(M, N, seed=64).to(cuda_dev)
+    sa, sw = ops.split3(da), ops.split3(dw)
+    want = ops.gemm_split3(sa, sw, db, dr, epi="bias_resid", variant=f"auto/k{ks}")
+    for rep in range(3):
+        got = ops.gemm_split3(sa, sw, db, dr, epi="bias_resid", variant=f"persist/128x128/k{ks}")
+        assert torch.equal(got, want), (rep, int((got != want).sum()), (got - want).abs().max().item())
+    assert torch.allclose(want.cpu(), _gemm_ref(a, w, b, dr.cpu(), "bias_resid", 1.0, 0), atol=2e-4, rtol=1e-5)
+    with pytest.raises(Exception):
+        ops.gemm_split3(ops.split3(da[:512].contiguous()), sw, db, dr[:512].contiguous(), epi="bias_resid", variant=f"persist/128x128/k{ks}")      # 4 x 10 x ks units
+
+
 # (M, N, K) whose 128 x 256 tile count T divides by 8 and leaves, per XCD (q = T / 8 tiles on 32 CUs), 1 ... 16 tiles after the full rounds:
 # fc1 of a 64-crop batch (q = 240 = 7 x 32 + 16), qkv / proj of 48 crops (q = 135 = 4 x 32 + 7; q = 45 = 32 + 13), a ragged-M case with 3 K tiles
 TAIL_SHAPES = [(12288, 5120, 1280), (9216, 3840, 1280), (9216, 1280, 1280), (12238, 5120, 96)]

@@ -385,6 +385,7 @@ int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws, h
 // round 6: the same stream over 128 x 128 tiles with the three-stage K ring (few crops: 257 ... kPersistNarrowMaxTiles tiles of 128 x 128)
 bool gemm_split3_persist_narrow_ok(const GemmArgs& a);   // N % 128, >= 256 tiles of 128 x 128 (M may be ragged), row-major A, no split-K
 int launch_gemm_split3_persist_narrow(const GemmArgs& a, int epi, void* ws, hipStream_t s);
+int launch_gemm_split3_splitk_stream(const GemmArgs& a, int ksplit, float* part, void* ws, hipStream_t s);      // a.ksplit > 1 units: (tile, K slice), epilogue none
 int gemm_split3_persist_error(void* ws, hipStream_t s, unsigned* err_out);   // synchronises s; *err_out != 0: a hand-over spin timed out
 int gemm_split3_persist_bind_host_err(void* ws, unsigned* const* host_err_slot, hipStream_t s);   // a timed-out consumer ALSO writes the host-mapped word *slot (slot: stable storage; after zeroing ws)
 void* gemm_split3_persist_op_ws(hipStream_t s);        // zeroed workspace per (device, stream) for the stateless operators

@@ -124,7 +124,7 @@ struct thmr_engine {
     // that grid is more than one round, at most s3_pn_max tiles, and the 128 x 256 grid would fill its rounds to at most s3_pn_fill per cent (gemm_split16.hip launch_split16_persist narrow); bit-identical to the
     // per-tile kernels.  THMR_SPLIT3_PN_MASK / THMR_SPLIT3_PN_MAX (experiments build)
     int s3_pw_fill = 72;              // the 128 x 256 stream for qkv when its per-tile grid fills its rounds to at most this many per cent (THMR_SPLIT3_PW_FILL)
-    int s3_pn_mask = 3, s3_pn_max = 600, s3_pn_fill = 72;      // s3_pn_fill: use the stream when the 128 x 256 grid fills its rounds to at most this many per cent
+    int s3_pn_mask = 11, s3_pn_max = 600, s3_pn_fill = 72, s3_pk_max = 1000;      // mask bit 3: split-K launches (proj / fc2 partial sums) as (tile, K slice) units, up to s3_pk_max units      // s3_pn_fill: use the stream when the 128 x 256 grid fills its rounds to at most this many per cent
     int s3_tile_opts = 0;             // GemmArgs::tile_opts of the split3 GEMMs (THMR_SPLIT3_NARROW8=1 -> 1, THMR_SPLIT3_TAIL8=1 -> 2; A/B only)
     int split3_min_b = 0;             // THMR_SPLIT3_MIN_B=<n>: A/B knob for the smallest batch the split3 mode serves (0 = kSplit3LowMinB)
     char* split_w = nullptr;          // split3 weight copies: shared, reference-counted, among the engines of one weight arena (split_share())
@@ -582,6 +582,16 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             const long wide = (long)((a.M + 127) / 128) * ((a.N + 255) / 256), rounds = (wide + 255) / 256;
             return e->s3_ws && e->s3_persist && wide >= 256 && 100 * wide <= e->s3_pw_fill * 256 * rounds && gemm_split3_persist_ok(a);
         };
+        // split-K launches (proj / fc2 below 16 / 32 crops) through the same stream: units = (tile, K slice); taken where the grid the rule would
+        // launch fills its rounds badly — e.g. fc2 at 18 crops = 270 workgroups of 128 x 256 x (K / 2) = two rounds for 1.05 rounds of work
+        auto splitk_stream = [&](const GemmArgs& a, int ks) {
+            const long rows = (a.M + 127) / 128, units = rows * ((a.N + 127) / 128) * ks, wide = rows * ((a.N + 255) / 256) * ks;
+            const long rounds = (wide + 255) / 256;
+            GemmArgs t = a;
+            t.ksplit = ks; t.bias = nullptr; t.resid = nullptr;
+            return e->s3_ws && e->s3_persist && (e->s3_pn_mask & 8) && units > 256 && units <= e->s3_pk_max && 100 * wide <= e->s3_pn_fill * 256 * rounds &&
+                   gemm_split3_persist_narrow_ok(t);
+        };
         auto gemm_s = [&](int cls, const char* A, int K, const char* Wt, const float* bias, const float* resid, float* C, int N, int epi, int a_blk = 0) -> int {
             ProfScope ps(e, st, cls, 2.0 * M * (double)N * K, 6.0 * ((double)M * K + (double)N * K) + 4.0 * M * N * (resid ? 2.0 : 1.0));
             GemmArgs a = mk(reinterpret_cast<const float*>(A), K, reinterpret_cast<const float*>(Wt), K, bias, resid, N, C, N, M, N, K);
@@ -614,7 +624,8 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                     ProfScope ps(e, st, THMR_PROF_GEMM_PROJ, 2.0 * M * DIM * (double)DIM, 6.0 * ((double)M * DIM + (double)DIM * DIM) + 4.0 * s3_split * M * DIM);
                     GemmArgs a = mk(reinterpret_cast<const float*>(hs), DIM, reinterpret_cast<const float*>(ws.proj), DIM, nullptr, nullptr, 0, x, DIM, M, DIM, DIM);
                     a.tile_opts = e->s3_tile_opts;
-                    LAUNCH_OK(launch_gemm_split3_splitk(a, s3_split, part, st));
+                    if (splitk_stream(a, s3_split)) LAUNCH_OK(launch_gemm_split3_splitk_stream(a, s3_split, part, e->s3_ws, st));
+                    else LAUNCH_OK(launch_gemm_split3_splitk(a, s3_split, part, st));
                 }
                 ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (s3_split + 2.0) * M * DIM + 6.0 * M * DIM);
                 LAUNCH_OK(launch_splitk_resid_ln(part, s3_split, M, DIM, w.pb, x, x, w.n2w, w.n2b, reinterpret_cast<float*>(hs), VIT_EPS, st, true));
@@ -642,7 +653,8 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                     GemmArgs a = mk(reinterpret_cast<const float*>(bs), MLP, reinterpret_cast<const float*>(ws.fc2), MLP, nullptr, nullptr, 0, x, DIM, M, DIM, MLP);
                     a.a_blk = bs_blk;
                     a.tile_opts = e->s3_tile_opts;
-                    LAUNCH_OK(launch_gemm_split3_splitk(a, s3_fc2, part2, st));
+                    if (!a.a_blk && splitk_stream(a, s3_fc2)) LAUNCH_OK(launch_gemm_split3_splitk_stream(a, s3_fc2, part2, e->s3_ws, st));
+                    else LAUNCH_OK(launch_gemm_split3_splitk(a, s3_fc2, part2, st));
                 }
                 ProfScope ps(e, st, THMR_PROF_LN, 0, 4.0 * (s3_fc2 + 3.0) * M * DIM);
                 if (last)
@@ -1325,6 +1337,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* pm = thmr_knob("THMR_SPLIT3_PN_MASK"); if (pm) e->s3_pn_mask = atoi(pm); }
     { const char* px = thmr_knob("THMR_SPLIT3_PN_MAX"); if (px) e->s3_pn_max = atoi(px); }
     { const char* pf = thmr_knob("THMR_SPLIT3_PN_FILL"); if (pf) e->s3_pn_fill = atoi(pf); }
+    { const char* pk = thmr_knob("THMR_SPLIT3_PK_MAX"); if (pk) e->s3_pk_max = atoi(pk); }
     { const char* pw = thmr_knob("THMR_SPLIT3_PW_FILL"); if (pw) e->s3_pw_fill = atoi(pw); }
     { const char* sp = thmr_knob("THMR_SPLIT3_PERSIST"); if (sp && sp[0] >= '0' && sp[0] <= '1') e->s3_persist = sp[0] - '0'; }
     { const char* fm = thmr_knob("THMR_SPLIT3_FC1_MODE"); if (fm && fm[0] >= '0' && fm[0] <= '2') e->s3_fc1_mode = fm[0] - '0'; }
@@ -1907,7 +1920,7 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
             return fail(e, THMR_ERR_INVALID, "split3 GEMM with a row-blocked A: variants 1000, 1002, 1006, 1008, 1202, 1204, 1300 and epilogues 0 / 4 only");
     }
     if (!(variant >= -1 && variant <= 11) && variant != 31 && variant != 32 && variant != 34 && variant != 37 && !(variant >= 100 && variant <= 102) &&
-        variant != 202 && variant != 204 && variant != 300 && variant != 320 && variant != 20 && variant != 22 && variant != 310)
+        variant != 202 && variant != 204 && variant != 300 && variant != 320 && variant != 322 && variant != 324 && variant != 20 && variant != 22 && variant != 310)
         return fail(e, THMR_ERR_INVALID, "split3 GEMM: variant -1 (rule), 0, 2, 6 (128 x 128 on 8 waves), 8 (128 x 128, three-stage ring), 5 / 7 (half-tile tail on 4 / 8 waves), 202, 204, 300; experiments build: 1, 4, 20, 22, 100-102, 310 (3, 31, 32, 34, 37: schedule experiments, epilogue 0 only)");
     GemmArgs a = mk(static_cast<const float*>(A), lda, static_cast<const float*>(W), ldw, bias, resid, ldc, C, ldc, M, N, K);
     a.qscale = qscale; a.qcols = qcols;
@@ -1931,9 +1944,11 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
         LAUNCH_OK(launch_gemm_split3_persist(a, epi, variant == 300 ? 0 : 10, ws, st));
         return 0;
     }
-    if (variant == 202 || variant == 204) {
-        // split-K 2 / 4 on the big tiles; partial sums in a grow-only workspace per (device, stream), then the fixed-order reduce + epilogue
-        const int ksplit = variant - 200;
+    if (variant == 202 || variant == 204 || variant == 322 || variant == 324) {
+        // split-K 2 / 4 on the big tiles (202 / 204) or as (tile, K slice) units of the 128 x 128 stream (322 / 324); partial sums in a grow-only
+        // workspace per (device, stream), then the fixed-order reduce + epilogue
+        const bool stream_k = variant >= 300;
+        const int ksplit = variant - (stream_k ? 320 : 200);
         if ((K % (32 * ksplit)) != 0) return fail(e, THMR_ERR_INVALID, "split3 split-K GEMM: K must be a multiple of 32 * ksplit");
         static std::mutex mu4;
         static std::map<std::pair<int, void*>, std::pair<float*, size_t>> pool4;
@@ -1948,7 +1963,12 @@ int thmr_op_gemm_split3(const void* A, int64_t lda, const void* W, int64_t ldw, 
             HIP_OK(hipMalloc(&p, need * sizeof(float)));
             slot = {p, need};
         }
-        LAUNCH_OK(launch_gemm_split3_splitk(a, ksplit, slot.first, st));
+        if (stream_k) {
+            void* ws = gemm_split3_persist_op_ws(st);
+            if (!ws) return fail(e, THMR_ERR_NOMEM, "persistent split3 GEMM: workspace allocation failed");
+            if (launch_gemm_split3_splitk_stream(a, ksplit, slot.first, ws, st) != 0)
+                return fail(e, THMR_ERR_INVALID, "split-K through the 128 x 128 stream: N % 128 == 0, >= 256 (tile, slice) units, >= 3 K tiles per slice, row-major A");
+        } else LAUNCH_OK(launch_gemm_split3_splitk(a, ksplit, slot.first, st));
         LAUNCH_OK(launch_splitk_epilogue(a, epi, slot.first, ksplit, st));
         return 0;
     }

@@ -167,7 +167,11 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * (NI * 16);
     const int l15 = lane & 15, g = lane >> 4;
-    const int nk_all = a.K / SBK;
+    // K tiles of one unit of work.  The 128 x 128 stream also takes split-K launches (round 6): its units are (tile, K slice) pairs, unit u =
+    // slice u / tiles of tile u % tiles — the same raw partial sums into part[slice] as the grid copies of the per-tile kernel, bit for bit
+    const int ksn = (PERSIST && NST == 3 && a.ksplit > 1) ? a.ksplit : 1;
+    const int nk_all = a.K / SBK / ksn;
+    float* const c_base = a.C;
 
     // ---- segments: (tile, K tiles [kb, ke), kind 0 whole / 1 first part: store the accumulators / 2 rest: start from stored accumulators)
     int xcd = 0, ln = 0, j0 = 0, k0 = 0, j1 = 0, k1 = 0, has_pre = 0, has_post = 0, jf0 = 0, nfull = 1, nseg = 1;
@@ -175,7 +179,7 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
     if constexpr (PERSIST) {
         xcd = blockIdx.x & 7;
         ln = blockIdx.x >> 3;
-        const int T = (tiles_m * tiles_n - ln + QG - 1) / QG;          // >= 8 (launcher): a range is at least one tile long
+        const int T = (tiles_m * tiles_n * ksn - ln + QG - 1) / QG;    // >= 8 (launcher): a range is at least one unit long
         const int S0 = (int)((int64_t)xcd * T * nk_all / 8), S1 = (int)((int64_t)(xcd + 1) * T * nk_all / 8);
         j0 = S0 / nk_all; k0 = S0 - j0 * nk_all;
         j1 = (S1 - 1) / nk_all; k1 = S1 - j1 * nk_all;
@@ -206,9 +210,13 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
             j = pt_tile; kb = pt_kb; ke = pt_ke; kind = 0;
         }
     };
+    // K slice of stream unit j of this lane (0 without split-K)
+    auto slice_of = [&](int j) { return ksn > 1 ? (j * QG + ln) / (tiles_m * tiles_n) : 0; };
     auto tile_of = [&](int j, int& bm0, int& bn0) {
         int tm, tn;
-        tile_coords(tiles_m, tiles_n, PERSIST ? j * QG + ln : j, tm, tn);
+        int t = PERSIST ? j * QG + ln : j;
+        if (ksn > 1) t -= slice_of(j) * (tiles_m * tiles_n);
+        tile_coords(tiles_m, tiles_n, t, tm, tn);
         bm0 = __builtin_amdgcn_readfirstlane(tm * QBM);
         bn0 = __builtin_amdgcn_readfirstlane(half >= 0 ? tn * 256 + half * 128 : tn * BN);
     };
@@ -243,8 +251,9 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
         tile_of(j, bm0, bn0);
         fk = kb;
         fke = ke;
-        fA = reinterpret_cast<const char*>(a.A) + (int64_t)bm0 * arow + (int64_t)kb * A_KSTEP;
-        fW = reinterpret_cast<const char*>(a.W) + (int64_t)bn0 * wrow + (int64_t)kb * ROWB;
+        const int k_first = kb + (ksn > 1 ? slice_of(j) * nk_all : 0);      // the unit's K slice starts at slice * nk_all
+        fA = reinterpret_cast<const char*>(a.A) + (int64_t)bm0 * arow + (int64_t)k_first * A_KSTEP;
+        fW = reinterpret_cast<const char*>(a.W) + (int64_t)bn0 * wrow + (int64_t)k_first * ROWB;
         // the 128 x 128 stream takes a ragged M (an odd number of crops: 192 B rows): the row clamps of the LAST row tile differ, so the copy
         // offsets follow the segment the cursor enters (a cold branch of the K loop; every other instantiation keeps one set of offsets)
         if constexpr (PERSIST && NST == 3) {
@@ -459,6 +468,9 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
         int j, kb, ke, kind, bm0, bn0;
         seg_of(n, j, kb, ke, kind);
         tile_of(j, bm0, bn0);
+        if constexpr (PERSIST && NST == 3) {
+            if (ksn > 1) a.C = c_base + (int64_t)slice_of(j) * a.M * a.ldc;      // this unit's partial-sum plane
+        }
         if (PERSIST && kind == 2) {
             // the accumulators of K tiles [0, kb) from lane ln of the previous XCD: one thread polls one word, then sc1 loads
             unsigned arrived_old = 0u;

@@ -448,17 +448,29 @@ int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws_me
 }
 
 bool gemm_split3_persist_narrow_ok(const GemmArgs& a) {
-    if (a.M <= 0 || a.N <= 0 || a.K < 3 * SBK || (a.K % SBK) != 0 || (a.N % 128) != 0) return false;      // (M may be ragged: a multiple of 192 rows)
-    if ((int64_t)((a.M + 127) / 128) * (a.N / 128) < P_NWG) return false;          // every lane's list holds >= 8 tiles: a range >= one tile
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;                                    // split-K: the stream's units are (tile, K slice) pairs, raw partial sums
+    if (a.M <= 0 || a.N <= 0 || (a.K % (SBK * ks)) != 0 || a.K / ks < 3 * SBK || (a.N % 128) != 0) return false;      // (M may be ragged: a multiple of 192 rows)
+    if ((int64_t)((a.M + 127) / 128) * (a.N / 128) * ks < P_NWG) return false;     // every lane's list holds >= 8 units: a range >= one unit
     if ((a.lda % 8) != 0 || (a.ldw % 8) != 0 || a.lda * 6 * 128 >= (int64_t(1) << 32) || a.ldw * 6 * 128 >= (int64_t(1) << 32)) return false;
-    if (a.cs_out != nullptr || a.ksplit > 1 || a.a_blk) return false;
+    if (a.cs_out != nullptr || a.a_blk) return false;
+    if (ks > 1 && (a.c_split != nullptr || a.bias != nullptr || a.resid != nullptr)) return false;
     if (a.c_split != nullptr && ((a.N % 8) != 0 || (a.ldcs % 8) != 0 || a.ldcs < a.N)) return false;
     return true;
 }
 
 int launch_gemm_split3_persist_narrow(const GemmArgs& a, int epi, void* ws_mem, hipStream_t s) {
-    if (!gemm_split3_persist_narrow_ok(a) || ws_mem == nullptr) return -1;
+    if (!gemm_split3_persist_narrow_ok(a) || ws_mem == nullptr || (a.ksplit > 1 && epi != EPI_NONE)) return -1;
     return launch_split16_persist(a, epi, ws_mem, true, s);
+}
+
+// split-K through the 128 x 128 stream: the arguments of launch_gemm_split3_splitk (raw partial sums of K slice sp into part[sp][M][N])
+int launch_gemm_split3_splitk_stream(const GemmArgs& a0, int ksplit, float* part, void* ws_mem, hipStream_t s) {
+    if (ksplit < 2 || part == nullptr) return -1;
+    GemmArgs a = a0;
+    a.ksplit = ksplit;
+    a.C = part; a.ldc = a.N;
+    a.bias = nullptr; a.resid = nullptr; a.ldr = 0;
+    return launch_gemm_split3_persist_narrow(a, EPI_NONE, ws_mem, s);
 }
 
 // the workspace's error word (a consumer's bounded spin ran out): 0 = none.  Synchronises the stream.

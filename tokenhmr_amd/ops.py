@@ -79,7 +79,7 @@ SPLIT3_VARIANT = {"auto": -1, "128x256/w8": 0, "tail": 5,        # tail: the 128
                    "128x256/w4": 1, "128x128/w4": 2, "256x256/w4": 4, "ring": 100, "ring/k2": 101, "ring/k4": 102, "auto/k2": 202, "auto/k4": 204,
                   # 256 persistent workgroups over a tile stream (csrc/gemm_split_persist.hip; M % 128 == 0, N % 256 == 0, >= 256 tiles):
                   # fp32 output / split3 output through the LDS transposition / split3 output through swapped operand roles
-                  "persist": 300, "persist/swap": 302, "persist/128x128": 320,      # 320: the stream over 128x128 tiles, three-stage ring (round 6)
+                  "persist": 300, "persist/swap": 302, "persist/128x128": 320, "persist/128x128/k2": 322, "persist/128x128/k4": 324,      # 320: the stream over 128x128 tiles, three-stage ring (round 6)
                   # round-4 first versions on v_mfma_f32_32x32x16_bf16 (the product kernels moved to 16x16x32, csrc/gemm_split16.hip): experiments build
                   "old/128x256/w8": 20, "old/128x128/w4": 22, "old/persist": 310, "old/persist/lds": 311, "old/persist/swap": 312,
                   # schedule experiments (epilogue "none" only; the abl/* ones are timing-only, their results are garbage)
