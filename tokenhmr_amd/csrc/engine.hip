@@ -124,7 +124,8 @@ struct thmr_engine {
     // that grid is more than one round, at most s3_pn_max tiles, and the 128 x 256 grid would fill its rounds to at most s3_pn_fill per cent (gemm_split16.hip launch_split16_persist narrow); bit-identical to the
     // per-tile kernels.  THMR_SPLIT3_PN_MASK / THMR_SPLIT3_PN_MAX (experiments build)
     int s3_pw_fill = 72;              // the 128 x 256 stream for qkv when its per-tile grid fills its rounds to at most this many per cent (THMR_SPLIT3_PW_FILL)
-    int s3_pn_mask = 11, s3_pn_max = 600, s3_pn_fill = 72, s3_pk_max = 1000;      // mask bit 3: split-K launches (proj / fc2 partial sums) as (tile, K slice) units, up to s3_pk_max units      // s3_pn_fill: use the stream when the 128 x 256 grid fills its rounds to at most this many per cent
+    int s3_pn_fill_proj = 60;
+    int s3_pn_mask = 15, s3_pn_max = 600, s3_pn_fill = 72, s3_pk_max = 1000;      // mask bit 3: split-K launches (proj / fc2 partial sums) as (tile, K slice) units, up to s3_pk_max units      // s3_pn_fill: use the stream when the 128 x 256 grid fills its rounds to at most this many per cent
     int s3_tile_opts = 0;             // GemmArgs::tile_opts of the split3 GEMMs (THMR_SPLIT3_NARROW8=1 -> 1, THMR_SPLIT3_TAIL8=1 -> 2; A/B only)
     int split3_min_b = 0;             // THMR_SPLIT3_MIN_B=<n>: A/B knob for the smallest batch the split3 mode serves (0 = kSplit3LowMinB)
     char* split_w = nullptr;          // split3 weight copies: shared, reference-counted, among the engines of one weight arena (split_share())
@@ -567,10 +568,10 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         // rounds).  Measured per class, same box (profiles/r6k_*): qkv at 6 / 12 crops (135 / 270 wide tiles, rounds 53 % full) 2.75 -> 2.13 and
         // 4.87 -> 3.64 ms per call, fc1 at 6 / 10 crops (70 % / 59 %) 2.92 -> 2.63 and 5.10 -> 3.94; at 8 crops qkv (70 %) 2.70 -> 2.62; it
         // LOSES where the wide rounds are full (fc1 at 8 crops, 94 %: +0.26; qkv at 10, 88 %: +0.34) and from ~700 tiles on (qkv at 16: +0.25).
-        auto narrow_stream = [&](const GemmArgs& a) {
+        auto narrow_stream = [&](const GemmArgs& a, int fill = 0) {
             const long rows = (a.M + 127) / 128, t128 = rows * ((a.N + 127) / 128), wide = rows * ((a.N + 255) / 256);
             const long rounds = (wide + 255) / 256;
-            return e->s3_ws && e->s3_persist && t128 > 256 && t128 <= e->s3_pn_max && 100 * wide <= e->s3_pn_fill * 256 * rounds &&
+            return e->s3_ws && e->s3_persist && t128 > 256 && t128 <= e->s3_pn_max && 100 * wide <= (fill ? fill : e->s3_pn_fill) * 256 * rounds &&
                    gemm_split3_persist_narrow_ok(a);
         };
         // ... and the stream over 128 x 256 tiles (round 4's persistent kernel; until round 6 fc2's only, where it wins at every size) for qkv
@@ -600,8 +601,9 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
             a.tile_opts = e->s3_tile_opts;
             const int bit = cls == THMR_PROF_GEMM_QKV ? 1 : cls == THMR_PROF_GEMM_PROJ ? 2 : cls == THMR_PROF_GEMM_FC2 ? 8 : 0;
             if (e->s3_ws && e->s3_persist && (e->s3_persist_mask & bit) && gemm_split3_persist_ok(a)) return launch_split3_persist_serialised(e, a, epi, 0, st);
-            if ((cls == THMR_PROF_GEMM_QKV && (e->s3_pn_mask & 1)) || (cls == THMR_PROF_GEMM_PROJ && (e->s3_pn_mask & 4)))
-                if (narrow_stream(a)) return launch_gemm_split3_persist_narrow(a, epi, e->s3_ws, st);
+            if (cls == THMR_PROF_GEMM_QKV && (e->s3_pn_mask & 1) && narrow_stream(a)) return launch_gemm_split3_persist_narrow(a, epi, e->s3_ws, st);
+            // proj (unsplit from 16 crops on; K = 1280, 5 wide column tiles): only where its wide rounds are at most s3_pn_fill_proj per cent full
+            if (cls == THMR_PROF_GEMM_PROJ && (e->s3_pn_mask & 4) && narrow_stream(a, e->s3_pn_fill_proj)) return launch_gemm_split3_persist_narrow(a, epi, e->s3_ws, st);
             if (cls == THMR_PROF_GEMM_QKV && wide_stream(a)) return launch_split3_persist_serialised(e, a, epi, 0, st);
             return launch_gemm_split3(a, epi, -1, st);
         };
@@ -1338,6 +1340,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* px = thmr_knob("THMR_SPLIT3_PN_MAX"); if (px) e->s3_pn_max = atoi(px); }
     { const char* pf = thmr_knob("THMR_SPLIT3_PN_FILL"); if (pf) e->s3_pn_fill = atoi(pf); }
     { const char* pk = thmr_knob("THMR_SPLIT3_PK_MAX"); if (pk) e->s3_pk_max = atoi(pk); }
+    { const char* pp = thmr_knob("THMR_SPLIT3_PN_FILL_PROJ"); if (pp) e->s3_pn_fill_proj = atoi(pp); }
     { const char* pw = thmr_knob("THMR_SPLIT3_PW_FILL"); if (pw) e->s3_pw_fill = atoi(pw); }
     { const char* sp = thmr_knob("THMR_SPLIT3_PERSIST"); if (sp && sp[0] >= '0' && sp[0] <= '1') e->s3_persist = sp[0] - '0'; }
     { const char* fm = thmr_knob("THMR_SPLIT3_FC1_MODE"); if (fm && fm[0] >= '0' && fm[0] <= '2') e->s3_fc1_mode = fm[0] - '0'; }

@@ -254,9 +254,9 @@ __device__ __forceinline__ void split16_body(GemmArgs& a, int tiles_m, int tiles
         const int k_first = kb + (ksn > 1 ? slice_of(j) * nk_all : 0);      // the unit's K slice starts at slice * nk_all
         fA = reinterpret_cast<const char*>(a.A) + (int64_t)bm0 * arow + (int64_t)k_first * A_KSTEP;
         fW = reinterpret_cast<const char*>(a.W) + (int64_t)bn0 * wrow + (int64_t)k_first * ROWB;
-        // the 128 x 128 stream takes a ragged M (an odd number of crops: 192 B rows): the row clamps of the LAST row tile differ, so the copy
-        // offsets follow the segment the cursor enters (a cold branch of the K loop; every other instantiation keeps one set of offsets)
-        if constexpr (PERSIST && NST == 3) {
+        // the streams take a ragged M (an odd number of crops: 192 B rows): the row clamps of the LAST row tile differ, so the copy offsets
+        // follow the segment the cursor enters (a cold branch of the K loop; the per-tile instantiations keep one set of offsets)
+        if constexpr (PERSIST) {
             if ((a.M & (QBM - 1)) != 0) set_offsets(bm0, bn0);
         }
     };

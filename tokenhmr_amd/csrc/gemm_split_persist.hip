@@ -394,8 +394,10 @@ int launch_persist_cfg(const GemmArgs& a, const PersistWs& ws, hipStream_t s) {
 size_t gemm_split3_persist_ws_bytes() { return (size_t)P_NWG * P_SLAB * 4 + (P_NWG + 64) * sizeof(unsigned); }
 
 bool gemm_split3_persist_ok(const GemmArgs& a) {
-    if (a.M <= 0 || a.N <= 0 || a.K < 2 * SBK || (a.K % SBK) != 0 || (a.M % PBM) != 0 || (a.N % PBN) != 0) return false;
-    if ((int64_t)(a.M / PBM) * (a.N / PBN) < P_NWG) return false;                 // every lane's list holds >= 8 tiles: a range >= one tile
+    // (round 6: M may be ragged — an odd number of crops — for the product kernel of gemm_split16.hip; the row-blocked operands hold whole
+    // 32-row blocks, which 192 B rows always are)
+    if (a.M <= 0 || a.N <= 0 || a.K < 2 * SBK || (a.K % SBK) != 0 || (a.M % 32) != 0 || (a.N % PBN) != 0) return false;
+    if ((int64_t)((a.M + PBM - 1) / PBM) * (a.N / PBN) < P_NWG) return false;     // every lane's list holds >= 8 tiles: a range >= one tile
     if ((a.lda % 8) != 0 || (a.ldw % 8) != 0 || a.lda * 6 * 256 >= (int64_t(1) << 32) || a.ldw * 6 * 256 >= (int64_t(1) << 32)) return false;
     if (a.cs_out != nullptr || a.ksplit > 1) return false;
     if (a.c_split != nullptr && ((a.N % 8) != 0 || (a.ldcs % 8) != 0 || a.ldcs < a.N)) return false;
@@ -417,7 +419,7 @@ int launch_gemm_split3_persist(const GemmArgs& a, int epi, int mode, void* ws_me
     return -1;
 #else
     mode -= 10;
-    if ((mode == 0) != (a.c_split == nullptr) || mode < 0 || mode > 2) return -1;
+    if ((mode == 0) != (a.c_split == nullptr) || mode < 0 || mode > 2 || (a.M % PBM) != 0) return -1;      // (the 32x32x16 kernels: whole row tiles only)
     // the 32x32x16 kernels of this file keep round 4's 0 / 1 flags (set by the producer, cleared by the consumer); the product kernel leaves
     // epochs in them: zero the flag words (not the control words) first
     if (hipMemsetAsync(reinterpret_cast<char*>(ws_mem) + (size_t)P_NWG * P_SLAB * 4, 0, P_NWG * sizeof(unsigned), s) != hipSuccess) return -2;
