@@ -124,8 +124,8 @@ struct thmr_engine {
     // that grid is more than one round, at most s3_pn_max tiles, and the 128 x 256 grid would fill its rounds to at most s3_pn_fill per cent (gemm_split16.hip launch_split16_persist narrow); bit-identical to the
     // per-tile kernels.  THMR_SPLIT3_PN_MASK / THMR_SPLIT3_PN_MAX (experiments build)
     int s3_pw_fill = 72;              // the 128 x 256 stream for qkv when its per-tile grid fills its rounds to at most this many per cent (THMR_SPLIT3_PW_FILL)
-    int s3_pn_fill_proj = 60;
-    int s3_pn_mask = 15, s3_pn_max = 600, s3_pn_fill = 72, s3_pk_max = 1000;      // mask bit 3: split-K launches (proj / fc2 partial sums) as (tile, K slice) units, up to s3_pk_max units      // s3_pn_fill: use the stream when the 128 x 256 grid fills its rounds to at most this many per cent
+    int s3_pn_fill_proj = 60;     // (proj: mask bit 2, OFF — 36-40 crops: proj -0.46 ... -0.59 ms per call, the call as a whole equal: profiles/r6x_*)
+    int s3_pn_mask = 11, s3_pn_max = 600, s3_pn_fill = 72, s3_pk_max = 1000;      // mask bit 3: split-K launches (proj / fc2 partial sums) as (tile, K slice) units, up to s3_pk_max units      // s3_pn_fill: use the stream when the 128 x 256 grid fills its rounds to at most this many per cent
     int s3_tile_opts = 0;             // GemmArgs::tile_opts of the split3 GEMMs (THMR_SPLIT3_NARROW8=1 -> 1, THMR_SPLIT3_TAIL8=1 -> 2; A/B only)
     int split3_min_b = 0;             // THMR_SPLIT3_MIN_B=<n>: A/B knob for the smallest batch the split3 mode serves (0 = kSplit3LowMinB)
     char* split_w = nullptr;          // split3 weight copies: shared, reference-counted, among the engines of one weight arena (split_share())
