@@ -123,6 +123,10 @@ struct thmr_engine {
     // round 6: qkv (bit 0), fc1 (bit 1) and proj (bit 2) of few-crop calls as 256 persistent workgroups over the 128 x 128 tile stream (three-stage ring) when
     // that grid is more than one round, at most s3_pn_max tiles, and the 128 x 256 grid would fill its rounds to at most s3_pn_fill per cent (gemm_split16.hip launch_split16_persist narrow); bit-identical to the
     // per-tile kernels.  THMR_SPLIT3_PN_MASK / THMR_SPLIT3_PN_MAX (experiments build)
+    // fc1 takes the 128 x 256 stream where its grid is MORE than two rounds and at most s3_pw_fill per cent full (17 / 18 crops: 520 / 540
+    // tiles = three rounds of time for 2.03 / 2.1 of work: fc1 -0.43 / -0.75 ms per call, profiles/r6z_*); below two rounds its GELU + split3
+    // epilogue (spills in the persistent form) loses what the rounds gain (12 crops: +0.16).  THMR_SPLIT3_PW_FC1=0: off (A/B)
+    int s3_pw_fc1 = 1;
     int s3_pw_fill = 72;              // the 128 x 256 stream for qkv when its per-tile grid fills its rounds to at most this many per cent (THMR_SPLIT3_PW_FILL)
     int s3_pn_fill_proj = 60;     // (proj: mask bit 2, OFF — 36-40 crops: proj -0.46 ... -0.59 ms per call, the call as a whole equal: profiles/r6x_*)
     int s3_pn_mask = 11, s3_pn_max = 600, s3_pn_fill = 72, s3_pk_max = 1000;      // mask bit 3: split-K launches (proj / fc2 partial sums) as (tile, K slice) units, up to s3_pk_max units      // s3_pn_fill: use the stream when the 128 x 256 grid fills its rounds to at most this many per cent
@@ -577,11 +581,10 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
         // ... and the stream over 128 x 256 tiles (round 4's persistent kernel; until round 6 fc2's only, where it wins at every size) for qkv
         // too WHEN its one-workgroup-per-tile grid fills its rounds badly and the 128 x 128 stream above does not apply: at 64 crops (94 % full)
         // the hand-overs cost qkv +6 %; at 24 crops its 540 tiles are 2.1 rounds = three rounds of time: 7.49 -> 6.93 ms per call, at 14 crops
-        // (315 tiles, 62 %) 5.02 -> 4.45 (profiles/r6m_*).  Not for fc1 / proj: measured equal or slower (fc1's GELU + split3 epilogue spills
-        // in the persistent form: +0.16 ms at 12 crops where its rounds are 70 % full; proj +0.12 at 36)
-        auto wide_stream = [&](const GemmArgs& a) {
+        // (315 tiles, 62 %) 5.02 -> 4.45 (profiles/r6m_*).  fc1 only above two rounds (s3_pw_fc1); not proj: measured equal or slower (+0.12 at 36)
+        auto wide_stream = [&](const GemmArgs& a, long min_tiles = 256) {
             const long wide = (long)((a.M + 127) / 128) * ((a.N + 255) / 256), rounds = (wide + 255) / 256;
-            return e->s3_ws && e->s3_persist && wide >= 256 && 100 * wide <= e->s3_pw_fill * 256 * rounds && gemm_split3_persist_ok(a);
+            return e->s3_ws && e->s3_persist && wide >= min_tiles && 100 * wide <= e->s3_pw_fill * 256 * rounds && gemm_split3_persist_ok(a);
         };
         // split-K launches (proj / fc2 below 16 / 32 crops) through the same stream: units = (tile, K slice); taken where the grid the rule would
         // launch fills its rounds badly — e.g. fc2 at 18 crops = 270 workgroups of 128 x 256 x (K / 2) = two rounds for 1.05 rounds of work
@@ -642,7 +645,7 @@ int vit_forward(thmr_engine* e, const float* img, int B, float* feats_out, hipSt
                 a.c_split = bs; a.ldcs = MLP;
                 a.cs_blk = bs_blk;
                 a.tile_opts = e->s3_tile_opts;
-                if (e->s3_ws && e->s3_persist && e->s3_fc1_mode && (e->s3_persist_mask & 4) && gemm_split3_persist_ok(a))
+                if (e->s3_ws && e->s3_persist && e->s3_fc1_mode && ((e->s3_persist_mask & 4) || (e->s3_pw_fc1 && wide_stream(a, 512))) && gemm_split3_persist_ok(a))
                     LAUNCH_OK(launch_split3_persist_serialised(e, a, EPI_BIAS_GELU, 2, st));
                 else if ((e->s3_pn_mask & 2) && narrow_stream(a))
                     LAUNCH_OK(launch_gemm_split3_persist_narrow(a, EPI_BIAS_GELU, e->s3_ws, st));
@@ -1342,6 +1345,7 @@ int thmr_create(const thmr_config* cfg, void* weight_arena_dev, void* scratch_ar
     { const char* pk = thmr_knob("THMR_SPLIT3_PK_MAX"); if (pk) e->s3_pk_max = atoi(pk); }
     { const char* pp = thmr_knob("THMR_SPLIT3_PN_FILL_PROJ"); if (pp) e->s3_pn_fill_proj = atoi(pp); }
     { const char* pw = thmr_knob("THMR_SPLIT3_PW_FILL"); if (pw) e->s3_pw_fill = atoi(pw); }
+    { const char* p1 = thmr_knob("THMR_SPLIT3_PW_FC1"); if (p1 && p1[0] == '0') e->s3_pw_fc1 = 0; }
     { const char* sp = thmr_knob("THMR_SPLIT3_PERSIST"); if (sp && sp[0] >= '0' && sp[0] <= '1') e->s3_persist = sp[0] - '0'; }
     { const char* fm = thmr_knob("THMR_SPLIT3_FC1_MODE"); if (fm && fm[0] >= '0' && fm[0] <= '2') e->s3_fc1_mode = fm[0] - '0'; }
     { const char* mk_ = thmr_knob("THMR_SPLIT3_PERSIST_MASK"); if (mk_) e->s3_persist_mask = atoi(mk_); }
