@@ -568,6 +568,67 @@ def test_batch_metrics_is_a_faithful_read_only_mapping():
         res["mode_re"] = np.zeros(3)                           # the Mapping is read-only
 
 
+def test_tile_stream_decomposition_model():
+    """The persistent split3 GEMMs' decomposition (csrc/gemm_split16.hip split16_body, PERSIST: 8 XCDs x 32 lanes; lane `ln` owns the units
+    j * 32 + ln, its list of T units x nk K tiles is cut into 8 contiguous ranges, one per XCD; a range boundary inside a unit = the first
+    part is stored to the slab by XCD x's workgroup (its FIRST segment) and continued by XCD x + 1's (its LAST segment)) restated in Python
+    and checked over the shapes the engine streams in round 6 — 128 x 256 tiles, 128 x 128 tiles, (tile, K slice) units of split-K launches,
+    ragged M: every (unit, K tile) is multiplied exactly once, a unit is shared by at most two workgroups, each workgroup has at most one
+    producer and one consumer segment, the consumer's range continues its producer's, and no range is shorter than one unit (the
+    launcher's >= 256 units), so a producer's part precedes its consumer's need."""
+    def ranges(units, nk):
+        out = {}
+        for ln in range(32):
+            T = (units - ln + 31) // 32
+            for x in range(8):
+                S0, S1 = x * T * nk // 8, (x + 1) * T * nk // 8
+                j0, k0 = divmod(S0, nk)
+                j1 = (S1 - 1) // nk
+                k1 = S1 - j1 * nk
+                has_pre, has_post = int(k1 < nk), int(k0 > 0)
+                jf0 = j0 + has_post
+                nfull = max(j1 - has_pre - jf0 + 1, 0)
+                segs = []
+                if has_pre:
+                    segs.append((j1, 0, k1, 1))
+                segs += [(jf0 + m, 0, nk, 0) for m in range(nfull)]
+                if has_post:
+                    segs.append((j0, k0, nk, 2))
+                out[(x, ln)] = segs
+        return out
+
+    cases = []
+    for crops, N, K, ks, bn in ((64, 1280, 5120, 1, 256), (35, 1280, 5120, 1, 256), (24, 3840, 1280, 1, 256), (14, 3840, 1280, 1, 256), (18, 5120, 1280, 1, 256),
+                                (6, 3840, 1280, 1, 128), (12, 3840, 1280, 1, 128), (10, 5120, 1280, 1, 128), (5, 5120, 1280, 1, 128), (13, 3840, 1280, 1, 128),
+                                (9, 1280, 5120, 2, 128), (18, 1280, 5120, 2, 128), (20, 1280, 5120, 2, 128), (10, 1280, 1280, 2, 128), (6, 1280, 5120, 4, 128)):
+        rows = (192 * crops + 127) // 128
+        cases.append((rows * (N // bn) * ks, K // 32 // ks))
+    cases += [(256, 11), (257, 3), (544, 3), (1000, 80)]
+    for units, nk in cases:
+        assert units >= 256
+        segs = ranges(units, nk)
+        seen = {}
+        for (x, ln), ss in segs.items():
+            assert sum(1 for s_ in ss if s_[3] == 1) <= 1 and sum(1 for s_ in ss if s_[3] == 2) <= 1
+            assert not ss or ss[0][3] != 2 or len(ss) == 1                       # a consumer segment is the workgroup's last
+            assert all(s_[3] != 1 for s_ in ss[1:])                              # a producer segment is its first
+            assert sum(ke - kb for _, kb, ke, _ in ss) >= nk, (units, nk, x, ln)  # no range shorter than one unit
+            for j, kb, ke, kind in ss:
+                u = j * 32 + ln
+                assert 0 <= u < units and 0 <= kb < ke <= nk
+                for k in range(kb, ke):
+                    assert (u, k) not in seen, (units, nk, u, k)
+                    seen[(u, k)] = (x, kind)
+                if kind == 2:                                                    # continues what XCD x - 1's workgroup of this lane stored
+                    prod = [s_ for s_ in segs[(x - 1, ln)] if s_[3] == 1]
+                    assert prod and prod[0][0] == j and prod[0][2] == kb and prod[0][1] == 0
+        assert len(seen) == units * nk, (units, nk, len(seen))
+        per_unit = {}
+        for (u, k), (x, kind) in seen.items():
+            per_unit.setdefault(u, set()).add(x)
+        assert max(len(v) for v in per_unit.values()) <= 2
+
+
 def test_split3_handover_epoch_protocol_model():
     """A model of the persistent split3 GEMM's slab hand-over (csrc/gemm_split16.hip: flag[xcd][lane] holds the EPOCH of the launch that
     published the slab; every workgroup reads the workspace's epoch word at its start; a consumer accepts a slab iff its flag equals this
