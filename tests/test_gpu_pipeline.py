@@ -161,7 +161,7 @@ def test_creation_flags_and_shared_split_weights(built_lib, cuda_dev):
     before = used()
     f.finalize()
     grown = used() - before
-    assert grown < 8 * 2 ** 20, f"finalize of an engine created in the f32 mode allocated {grown} bytes"
+    assert grown <= 64 * 2 ** 20, f"finalize of an engine created in the f32 mode allocated {grown} bytes"      # (allocator granularity: 0-8 MiB measured; the split copies would be 1.5 GB here)
     out_f = {k: v.clone() for k, v in f.forward(img).items()}
     # default engine: finalize builds the copies thmr_mode_bytes announces
     d = make()
@@ -478,8 +478,10 @@ def test_split3_handover_timeout_is_reported_once_and_the_engine_falls_back(buil
 def test_forward_is_captured_into_a_hip_graph_and_replays_bit_identically(built_lib, cuda_dev, mode):
     """include/tokenhmr_hip.h: thmr_forward allocates nothing and never synchronises the host, "so a call in either mode can be captured
     in a hipGraph".  Captured through torch.cuda.CUDAGraph (hipGraph on ROCm) on a side stream at 2 crops (exact-fp32 kernels, key-split
-    attention, the small-batch GEMM regime) and at 40 crops (split3: the persistent fc2 with its flag hand-over, the bf16-pipe attention
-    walking two items per workgroup, the persistent decoder kernel with its grid barrier): every replay must reproduce the eager call bit
+    attention, the small-batch GEMM regime), at 9 and 12 crops (round 6, split3: qkv / fc1 as the 128 x 128 tile stream — ragged M at 9 — and
+    fc2's split-K partial sums through it: several hand-over launches per layer on one workspace) and at 40 crops (split3: the persistent
+    fc2 with its flag hand-over, the bf16-pipe attention walking two items per workgroup, the persistent decoder kernel with its grid
+    barrier): every replay must reproduce the eager call bit
     for bit — a kernel whose device-side state (barrier counters, hand-over flags) is not re-armed by stream order alone would differ or hang —
     with new inputs copied into the captured buffer between replays."""
     from tokenhmr_amd.config import HMRConfig
@@ -493,7 +495,7 @@ def test_forward_is_captured_into_a_hip_graph_and_replays_bit_identically(built_
     eng.finalize()
     eng.set_vit_gemm(mode)
     keys = ("pred_vertices", "pred_keypoints_2d", "pred_cam", "token_idx", "cls_logits_softmax")
-    for B in (2, 40):
+    for B in (2, 9, 12, 40):
         imgs = [torch.randn(B, 3, 256, 256, generator=torch.Generator().manual_seed(50 + B + i)).to(cuda_dev) for i in range(3)]
         want = []
         for im in imgs:
